@@ -2,19 +2,31 @@
 """bench.py -- seeds queried / s on the chr22-like configuration (BASELINE.json configs[1]).
 
 A "step" is one pass of the hot path (SeedFinder::seeds_all, reference
-include/psi/seed_finder.hpp:1724-1732, as driven per chunk by src/psikt.cpp:195-204) over
-one resident batch of synthetic reads: seeding -> seed table -> FM backward search ->
-locate + map -> traverser -> hits left in HBM.  N > 1: one process per GPU, every rank holds
-the whole index and its own batch of reads (weak scaling, no data-path collective).
+include/psi/seed_finder.hpp:1724-1732, as driven per chunk by src/psikt.cpp:195-204) over one
+batch of 1 M synthetic 150-bp reads; two batches (different reads) alternate in the timed loop.
+In the default query mode a step is: seeding (k_seed_scan_*, k_seed_pack) -> one probe of the
+k-mer table per seed (k_kmer_probe: the table holds what the FM backward search and the traverser
+would return, tabulated once per index) -> emission (k_kmer_emit).  `roofline_by_mode` carries the
+same workload through the FM-index kernels (k_fm_search*, k_fm_locate*) and the query-time
+traverser (k_traverse), the kernels BASELINE.json's north_star names.
+
+`value` follows the bench contract: reads resident in HBM when the timed region starts, hits left
+in HBM.  The SURVEY 8(d) number -- H2D of the reads + kernels + device sort-unique + D2H of the hits
+through psigpu_find_seeds -- is the `end_to_end` object of the same line (with a PCIe roofline).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-prints ONE JSON line on rank 0 (contract in the task statement; `roofline` and
-`cpu_baseline` objects included).
+N > 1: one process per GPU (started here when not already under torchrun), every rank holds the
+whole index and its own read batches (weak scaling, no data-path collective); the hit lists are
+gathered on rank 0 over RCCL once, outside the timed region, and that time is reported.
+Prints ONE JSON line on rank 0 (`roofline`, `cpu_baseline`, `parity_vs_cpu_sample` included).
 """
 import argparse
+import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,7 +35,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+PCIE_PEAK_GBS = 63.0           # PCIe Gen5 x16, one direction (64 GT/s x 16 lanes, 128b/130b)
 BLOCK = 64                     # bytes per rank block / HBM sector
+PROFILE_ROUND = 'r02'
+TRAFFIC_FILES = {'kmer-table': '%s_k_traffic.json', 'locus-table': '%s_l_traffic.json', 'traverse': '%s_t_traffic.json'}
 
 
 def log(*a):
@@ -36,7 +51,7 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
     if kernel == 'k_fm_search':
         # per N-free seed one 8-byte interval-table entry; per LF step actually needed two rank
         # probes (one 64-byte block each, not discounted when both ends share a block); per SA row
-        # finished against the text its 4-byte SA value and 8 bytes (16 symbols) of text
+        # finished against its record 16 bytes (row record) -- 12 when finished against the text
         if ftab_len and k >= ftab_len:
             return 8.0 * c['n_seeds_valid'] + 2.0 * BLOCK * c['n_lf_steps'] + 12.0 * c['n_rows_verified']
         return 2.0 * k * BLOCK * c['n_seeds_valid']
@@ -44,24 +59,22 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
         # per N-free seed one 16-byte table slot and one 4-byte bitmap word, both read-modify-write
         return 2.0 * (16 + 4) * c['n_seeds_valid']
     if kernel == 'k_fm_locate':
-        # SA-order sampling at rate s: expected s-1 LF steps (one block each) + the 4-byte
-        # sample, two 64-byte segment-table probes, one 32-byte record out; hits that come from the
-        # locus k-mer table: one 16-byte entry in, one 32-byte record out
         if c['n_path_kmers']:
             # k-mer table mode: K2 is a stream -- 16 bytes of probe results + 8 bytes of (read, offset)
             # in per seed, one 32-byte record out per hit (positions were inline in the slots)
             return 24.0 * c['n_seeds'] + 32.0 * c['n_hits']
+        # SA-order sampling at rate s: expected s-1 LF steps (one block each) + the 4-byte
+        # sample, two 64-byte segment-table probes, one 32-byte record out; hits that come from the
+        # locus k-mer table: one 16-byte entry in, one 32-byte record out
         return ((sa_rate - 1) * BLOCK + 4 + 2 * BLOCK + 32) * c['n_hits_on_path'] + (16 + 32.0) * c['n_hits_table']
     if kernel in ('k_kmer_probe', 'k_lkt_probe'):
-        # per seed its 8-byte key in and 16 bytes of results out to K2 (k-mer table; the locus table
-        # leaves 12); per N-free seed one 16-byte table slot in
+        # per seed its 8-byte key in and 16 bytes of results out to K2; per N-free seed one 16-byte slot in
         return (8 + 16.0) * c['n_seeds'] + 16.0 * c['n_seeds_valid']
     if kernel == 'k_seed_pack':
-        # the read bases in (each seed's k bytes; overlapping seeds re-read), 8-byte key + 8-byte
-        # (read, offset) out per seed
+        # each seed's k bytes of bases in, 8-byte key + 8-byte (read, offset) out
         return (k + 16.0) * c['n_seeds']
     if kernel == 'k_traverse':
-        # per k-walk from a starting locus (all of them are resolved by a launch, most by pruning):
+        # per k-walk from a starting locus (a launch resolves all of them, most by pruning):
         # ceil(k/4) label bytes + 4 per edge list touched + 16-byte seed-table probe (32 B at
         # k = 21, 40 B at k = 31); 32-byte record per hit
         ck = 32 if k <= 21 else 40
@@ -69,19 +82,16 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
     raise KeyError(kernel)
 
 
-def cpu_baseline(sg, px, bases, off, k, step, n_reads_sample):
-    """The oracle (C restatement of the reference path) timed on this host: 'port'."""
+def oracle_objects(sg, px):
+    """OracleGraph + OraclePathIndex over the product's paths (the oracle's own text; its suffix array
+    is supplied by the product's SA-IS and VERIFIED by the oracle before use)."""
     import numpy as np
     import oracle
     import psi_amd
-    threads = oracle.lib().orc_max_threads()
-    og = oracle.OracleGraph(sg.node_id, sg.label_off, bytes(sg.labels), sg.edge_off,
-                            sg.edge_to.astype(np.uint64))
+    og = oracle.OracleGraph(sg.node_id, sg.label_off, bytes(sg.labels), sg.edge_off, sg.edge_to.astype(np.uint64))
     paths = [p for p in px.paths()]
     pidx = None
     if paths:
-        # the oracle's own text: reversed path sequences joined by '$', 0-terminated; its suffix
-        # array is supplied by the product's SA-IS and VERIFIED by the oracle before use
         code = np.full(256, 5, np.uint8)
         for ch, v in ((65, 2), (67, 3), (71, 4), (84, 6)):
             code[ch] = v
@@ -98,16 +108,70 @@ def cpu_baseline(sg, px, bases, off, k, step, n_reads_sample):
         text = np.concatenate(parts)
         sa = psi_amd.suffix_array(text, 7)
         pidx = oracle.OraclePathIndex(og, [p.tolist() for p in paths], ext_sa=sa.astype(np.uint32))
+    return og, pidx
+
+
+def cpu_baseline(og, pidx, px, bases, off, k, step, n_reads_sample, budget_1t_s=8.0):
+    """The oracle (C restatement of the reference path) timed on this host: 'port'.  All cores for the
+    reported value; one thread (what psikt's loop is) as two measured rates on bounded samples."""
+    import numpy as np
+    import oracle
+    threads = oracle.lib().orc_max_threads()
     ln, lo_ = px.loci
     nb = int(off[n_reads_sample])
     t0 = time.perf_counter()
     hits, st = oracle.seeds_all(og, pidx, bytes(bases[:nb]), off[:n_reads_sample + 1], k, step, ln, lo_,
                                 threads=threads, want_stats=True)
     dt = time.perf_counter() - t0
-    return {'value': st['n_seeds'] / dt, 'unit': 'seeds/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d of the %d reads of one step (%d seeds), whole index and all %d starting '
-                      'loci, %.1f s wall' % (n_reads_sample, len(off) - 1, st['n_seeds'], len(ln), dt),
-            'hits_per_s': len(hits) / dt}, hits
+    out = {'value': st['n_seeds'] / dt, 'unit': 'seeds/s', 'cores': threads, 'kind': 'port',
+           'sample': '%d of the %d reads of one step (%d seeds), whole index and all %d starting '
+                     'loci, %.1f s wall' % (n_reads_sample, len(off) - 1, st['n_seeds'], len(ln), dt),
+           'hits_per_s': len(hits) / dt}
+    # cpu-1t (BASELINE.md section 3): the reference loop is single-threaded.  One thread cannot walk
+    # all starting loci within the bench's time, so two rates are MEASURED on bounded samples -- the
+    # on-path phase on r1 reads, the traverser on the first l1 loci against the same reads -- and the
+    # chunk rate they imply is reported as derived.
+    try:
+        r1 = max(1000, min(n_reads_sample, 20_000))
+        nb1 = int(off[r1])
+        e = np.zeros(0, np.uint32)
+        t0 = time.perf_counter()
+        _, s_on = oracle.seeds_all(og, pidx, bytes(bases[:nb1]), off[:r1 + 1], k, step, e, e, threads=1, want_stats=True)
+        t_on = time.perf_counter() - t0
+        l1 = min(len(ln), 50_000)
+        t0 = time.perf_counter()
+        oracle.seeds_all(og, None, bytes(bases[:nb1]), off[:r1 + 1], k, step, ln[:l1], lo_[:l1], threads=1)
+        t_off = time.perf_counter() - t0
+        while t_off < budget_1t_s / 8 and l1 < len(ln):
+            l1 = min(len(ln), l1 * 4)
+            t0 = time.perf_counter()
+            oracle.seeds_all(og, None, bytes(bases[:nb1]), off[:r1 + 1], k, step, ln[:l1], lo_[:l1], threads=1)
+            t_off = time.perf_counter() - t0
+        seeds_rate_on = s_on['n_seeds'] / t_on
+        loci_rate = l1 / t_off
+        n_seeds_chunk = st['n_seeds'] * (len(off) - 1) / n_reads_sample
+        t_chunk = n_seeds_chunk / seeds_rate_on + len(ln) / loci_rate
+        out['cpu_1t'] = {'on_path_seeds_per_s': seeds_rate_on, 'on_path_sample': '%d reads, %.2f s' % (r1, t_on),
+                         'traverser_loci_per_s': loci_rate,
+                         'traverser_sample': 'first %d of %d starting loci against %d reads, %.2f s' % (l1, len(ln), r1, t_off),
+                         'derived_chunk_seeds_per_s': n_seeds_chunk / t_chunk,
+                         'note': 'derived = seeds of one step / (seeds / on-path rate + loci / traverser rate): '
+                                 'the reference traverses every starting locus for every chunk'}
+    except Exception as ex:            # the 1-thread series is informative only
+        out['cpu_1t'] = {'error': str(ex)}
+    return out, hits
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as CHILD processes (before anything
+    here has touched the GPU) and relay rank 0's JSON line."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -126,28 +190,34 @@ def main():
     ap.add_argument('--backbone', type=int, default=51_000_000)
     ap.add_argument('--snvs', type=int, default=1_100_000)
     ap.add_argument('--nblock', type=int, default=11_000_000)
-    ap.add_argument('--cpu-reads', type=int, default=-1, help='reads in the CPU-baseline sample (0 = skip)')
-    ap.add_argument('--check', action='store_true', help='compare the GPU hit set with the CPU sample')
+    ap.add_argument('--batches', type=int, default=2, help='read batches alternating in the timed loop')
+    ap.add_argument('--cpu-reads', type=int, default=-1, help='reads in the CPU-baseline sample (0 = skip baseline and check)')
+    ap.add_argument('--no-check', action='store_true', help='skip the comparison of the GPU hit set with the CPU sample')
+    ap.add_argument('--lean', action='store_true', help='headline only: no other modes, no end-to-end, no CPU baseline (profiling runs)')
     ap.add_argument('--mode', choices=('kmer-table', 'locus-table', 'traverse'), default='kmer-table',
                     help="kmer-table: path k-mers and the starting loci's k-walks tabulated once in HBM, one probe "
                          "per seed; locus-table: FM index on the paths, table for the loci; traverse: FM index + "
                          "every starting locus traversed per chunk, as the reference does")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        log('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world))
+        log('error: --gpus %d but WORLD_SIZE %d' % (args.gpus, world))
+        sys.exit(2)
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import psi_amd
     from psi_amd import synth
+    from psi_amd import dist as pdist
 
     # PSI_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than
-    # ranks (ranks share devices; the reductions run on the host).  The driver's runs use RCCL.
+    # ranks (ranks share devices; the collectives run on the host).  The driver's runs use RCCL.
     backend = os.environ.get('PSI_BENCH_BACKEND', 'nccl')
     n_dev = max(1, torch.cuda.device_count())
     if backend != 'nccl':
@@ -162,110 +232,158 @@ def main():
 
     k = args.k
     step = args.step or k
+    lean = args.lean
     t0 = time.time()
     sg = synth.snv_graph(args.backbone, args.snvs, n_block=args.nblock, seed=11)
     g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to,
                                paths=[sg.ref_path])
-    bases, off = synth.sim_reads_snv(sg, args.reads, args.read_len, seed=13 + rank)
+    nb = max(1, args.batches)
+    batches = [synth.sim_reads_snv(sg, args.reads, args.read_len, seed=13 + 100 * b + rank) for b in range(nb)]
     t_ix = time.time()
     px = psi_amd.PathIndex.build(g, k, args.paths, sa_rate=args.sa_rate, rng_seed=1, ftab_len=args.ftab,
                                  device=None if args.host_build else local_rank)
     t_ix = time.time() - t_ix
     finder = psi_amd.SeedFinder(g, k, device=local_rank, mode=args.mode)
     finder.set_path_index(px)
+    t_prep = time.time()
+    finder.prepare()                      # the tables of the query mode: index load time, not query time
+    t_prep = time.time() - t_prep
     if rank == 0:
-        log('setup %.1f s (index %.1f s, %s): %d nodes, %d edges, text %d, %d starting loci' %
-            (time.time() - t0, t_ix, 'host' if args.host_build else 'device', g.n_nodes, g.n_edges, px.text_len,
-             px.view.n_loci))
+        log('setup %.1f s (index %.1f s on the %s, tables %.2f s): %d nodes, %d edges, text %d, %d starting loci' %
+            (time.time() - t0, t_ix, 'host' if args.host_build else 'device', t_prep, g.n_nodes, g.n_edges,
+             px.text_len, px.view.n_loci))
 
-    d_bases = torch.from_numpy(bases).cuda()
-    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
     rec_offset = rank * args.reads
-
-    def one_step():
-        return finder.seeds_all_device(d_bases.data_ptr(), d_off.data_ptr(), args.reads, len(bases),
-                                       step=step, rec_offset=rec_offset, stream=stream)
-
-    # untimed: every k-walk from the starting loci (the unit SURVEY 8(d) prices the traverser by).
-    # Table mode enumerates them once, here, into the locus k-mer table; traverse mode counts them
-    # with one pass that has the pruning switched off (the timed steps prune)
-    if args.mode == 'traverse':
-        os.environ['PSIGPU_NO_PFX'] = '1'
-    one_step()
-    c0 = finder.counters()
-    kwalks_all = c0['n_kpaths'] if args.mode == 'traverse' else c0['n_locus_kmers']
-    os.environ.pop('PSIGPU_NO_PFX', None)
-    for _ in range(args.warmup):
-        one_step()
-    probe_name = 'k_kmer_probe' if args.mode == 'kmer-table' else 'k_lkt_probe'
-    kern = {'k_fm_search': 0.0, 'k_fm_locate': 0.0, 'k_traverse': 0.0, 'k_table_insert': 0.0, probe_name: 0.0,
-            'k_seed_pack': 0.0}
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_begin = time.perf_counter()
-    # the timed loop goes through the C ABI with prebuilt arguments: the binding's conveniences
-    # (argument objects, a dict of counters) cost tens of microseconds per call, several per cent of a step
-    import ctypes as C
     L = psi_amd.lib()
-    cs = psi_amd.Counters()
-    d_hits, n_out = C.c_void_p(), C.c_uint64()
-    call_args = (finder.ctx, d_bases.data_ptr(), d_off.data_ptr(), args.reads, len(bases), k, step, rec_offset,
-                 psi_amd.ALL, stream, C.byref(d_hits), C.byref(n_out))
-    t_search = t_locate = t_trav = t_table = t_probe = t_pack = 0.0
-    for _ in range(args.steps):
-        if L.psigpu_find_seeds_device(*call_args):
-            raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
-        L.psigpu_get_counters(finder.ctx, C.byref(cs))
-        t_search += cs.ms_search; t_locate += cs.ms_locate; t_trav += cs.ms_traverse
-        t_table += cs.ms_table; t_probe += cs.ms_probe; t_pack += cs.ms_pack
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_begin
-    ptr, n_hits = d_hits.value, n_out.value
-    c = finder.counters()
-    kern['k_fm_search'], kern['k_fm_locate'], kern['k_traverse'] = t_search, t_locate, t_trav
-    kern['k_table_insert'], kern[probe_name] = t_table, t_probe
-    kern['k_seed_pack'] = t_pack                  # + the seed-count scan in front of it
+    dev = [(torch.from_numpy(b).cuda(), torch.from_numpy(o.astype(np.int64)).cuda(), len(b)) for b, o in batches]
+
+    def time_mode(f, steps, warmup, mode, sync_ranks):
+        """K timed steps of the device-resident entry over the alternating batches; per-kernel times from
+        the library's HIP events (recorded on the streams the kernels run on)."""
+        # untimed: every k-walk from the starting loci (the unit SURVEY 8(d) prices the traverser by).
+        # Table modes enumerate them once into the locus k-mer table; traverse mode counts them
+        # with one pass that has the pruning switched off (the timed steps prune)
+        if mode == 'traverse':
+            os.environ['PSIGPU_NO_PFX'] = '1'
+        f.seeds_all_device(dev[0][0].data_ptr(), dev[0][1].data_ptr(), args.reads, dev[0][2], step=step,
+                           rec_offset=rec_offset, stream=stream)
+        c0 = f.counters()
+        kwalks_all = c0['n_kpaths'] if mode == 'traverse' else c0['n_locus_kmers']
+        os.environ.pop('PSIGPU_NO_PFX', None)
+        cs = psi_amd.Counters()
+        d_hits, n_out = C.c_void_p(), C.c_uint64()
+        # the timed loop goes through the C ABI with prebuilt arguments: the binding's conveniences
+        # (argument objects, a dict of counters) cost tens of microseconds per call
+        calls = [(f.ctx, d[0].data_ptr(), d[1].data_ptr(), args.reads, d[2], k, step, rec_offset, psi_amd.ALL, stream,
+                  C.byref(d_hits), C.byref(n_out)) for d in dev]
+        for i in range(warmup):
+            if L.psigpu_find_seeds_device(*calls[i % nb]):
+                raise RuntimeError(L.psigpu_last_error(f.ctx).decode())
+        probe_name = 'k_kmer_probe' if mode == 'kmer-table' else 'k_lkt_probe'
+        kern = {'k_fm_search': 0.0, 'k_fm_locate': 0.0, 'k_traverse': 0.0, 'k_table_insert': 0.0, probe_name: 0.0,
+                'k_seed_pack': 0.0}
+        seeds = hits = 0
+        torch.cuda.synchronize()
+        if sync_ranks and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_begin = time.perf_counter()
+        for i in range(steps):
+            if L.psigpu_find_seeds_device(*calls[i % nb]):
+                raise RuntimeError(L.psigpu_last_error(f.ctx).decode())
+            L.psigpu_get_counters(f.ctx, C.byref(cs))
+            kern['k_fm_search'] += cs.ms_search; kern['k_fm_locate'] += cs.ms_locate; kern['k_traverse'] += cs.ms_traverse
+            kern['k_table_insert'] += cs.ms_table; kern[probe_name] += cs.ms_probe; kern['k_seed_pack'] += cs.ms_pack
+            seeds += cs.n_seeds; hits += cs.n_hits
+        torch.cuda.synchronize()
+        if sync_ranks and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_begin
+        c = f.counters()
+        c['n_kwalks_all'] = kwalks_all
+        c['n_hits_table'] = c['n_hits_off_path'] if c['n_locus_kmers'] and not c['n_loci_traversed'] else 0
+        return {'elapsed': elapsed, 'kern': kern, 'seeds': seeds, 'hits': hits, 'c': c, 'steps': steps}
+
+    def roofline_of(res, mode, kernel=None):
+        """Roofline object of one kernel of a mode (default: the one with the largest summed event time)."""
+        kern, c, steps = res['kern'], res['c'], res['steps']
+        dom = kernel or max(kern, key=lambda n: kern[n])
+        avg_ms = kern[dom] / steps
+        abytes = algorithmic_bytes(dom, c, k, args.sa_rate, int(px.view.ftab_len))
+        achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM-side traffic per launch from separate rocprofv3 --pmc passes over this same command
+        # (tools/profile.sh -> profiles/<round>_*_traffic.json, committed); null when not collected
+        traffic, src = None, None
+        tname = TRAFFIC_FILES[mode] % PROFILE_ROUND
+        tpath = os.path.join(ROOT, 'profiles', tname)
+        if os.path.exists(tpath) and world == 1 and args.reads == 1_000_000 and k == 21 and step == 21 and args.paths == 1:
+            tj = json.load(open(tpath))
+            pl = tj.get('per_launch', {})
+            names = {'k_fm_locate': ['k_kmer_emit', 'k_fm_locate_direct', 'k_fm_locate'],
+                     'k_fm_search': ['k_fm_search_direct', 'k_fm_search'],
+                     'k_traverse': ['void k_traverse<false>', 'k_traverse<false>', 'k_traverse'],
+                     'k_seed_pack': ['k_seed_pack'], 'k_table_insert': ['k_table_insert']}.get(dom, [dom])
+            for nme in names:
+                t = pl.get(nme)
+                if t and tj.get('mode') == mode:
+                    traffic = t.get('fetch_size_bytes', 0.0) + t.get('write_size_bytes', 0.0)
+                    src = 'profiles/' + tname + ':' + nme
+                    break
+        out = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+               'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': src,
+               'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': abytes,
+               'traffic_gbs': (traffic / (avg_ms * 1e-3) / 1e9) if traffic and avg_ms > 0 else None,
+               'kernel_ms_per_step': {n: v / steps for n, v in kern.items()}}
+        if dom == 'k_kmer_probe':
+            # secondary bound (SURVEY 8d): divergent 16-byte loads per second against the rate
+            # tools/rand_sector2.hip measures on this part for a table of this size
+            out['random_loads_per_s'] = c['n_seeds_valid'] / (avg_ms * 1e-3) if avg_ms > 0 else None
+            out['random_load_peak_per_s'] = 41.4e9
+            # SURVEY's price for the search this probe replaces (2*k*64 B per seed)
+            out['survey_8d_bytes_per_launch'] = algorithmic_bytes('k_fm_search', c, k, args.sa_rate, 0)
+        return out
+
+    main_res = time_mode(finder, args.steps, args.warmup, args.mode, True)
+    elapsed = main_res['elapsed']
+    seeds_total, hits_total = float(main_res['seeds']), float(main_res['hits'])
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([c['n_seeds'], c['n_hits']], dtype=torch.float64, device=red_dev)
+        tot = torch.tensor([seeds_total, hits_total], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        seeds_per_step, hits_per_step = float(tot[0].item()), float(tot[1].item())
-    else:
-        seeds_per_step, hits_per_step = float(c['n_seeds']), float(c['n_hits'])
+        seeds_total, hits_total = float(tot[0].item()), float(tot[1].item())
+
+    # the one exchange the path has (BASELINE north_star: "RCCL over xGMI only to gather hit lists"):
+    # every rank's sort-unique hits of one batch to rank 0, once, outside the timed region
+    gather = None
+    if world > 1:
+        ptr, n = finder.seeds_all_device(dev[0][0].data_ptr(), dev[0][1].data_ptr(), args.reads, dev[0][2], step=step,
+                                         rec_offset=rec_offset, flags=psi_amd.ALL | psi_amd.SORT_UNIQUE, stream=stream)
+        mine = torch.from_numpy(finder.copy_hits(ptr, n).view(np.int64))
+        if backend == 'nccl':
+            mine = mine.cuda()
+        dist.barrier()
+        t1 = time.perf_counter()
+        allh = pdist.gather_hits(mine, dst=0)
+        if backend == 'nccl':
+            torch.cuda.synchronize()
+        dist.barrier()
+        t_g = time.perf_counter() - t1
+        if rank == 0:
+            ids = allh[:, 2]
+            gather = {'ms': t_g * 1e3, 'records': int(allh.shape[0]), 'bytes': int(allh.shape[0]) * 32,
+                      'gb_per_s': allh.shape[0] * 32 / t_g / 1e9, 'backend': backend,
+                      'sorted_by_read_id': bool((ids[1:] >= ids[:-1]).all().item()) if allh.shape[0] > 1 else True}
 
     if rank == 0:
+        c = main_res['c']
         steps = args.steps
-        dom = max(kern, key=lambda n: kern[n])
-        avg_ms = kern[dom] / steps
-        c['n_kwalks_all'] = kwalks_all
-        c['n_hits_table'] = c['n_hits_off_path'] if c['n_locus_kmers'] and not c['n_loci_traversed'] else 0
-        abytes = algorithmic_bytes(dom, c, k, args.sa_rate, int(px.view.ftab_len))
-        # the same kernel priced with SURVEY 8(d)'s unmodified 2*k*64 B per seed (no interval table)
-        # (the k-mer table probe stands where K1 stood: SURVEY's price for the search it replaces)
-        survey_bytes = algorithmic_bytes('k_fm_search' if dom == 'k_kmer_probe' else dom, c, k, args.sa_rate, 0)
-        achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM-side traffic of the dominant kernel per launch, from a separate rocprofv3 --pmc run of
-        # this same command (tools/profile.sh -> profiles/*traffic.json); null when not collected
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', {'kmer-table': 'r01_k_traffic.json', 'locus-table': 'r01_l_traffic.json', 'traverse': 'r01_t_traffic.json'}.get(args.mode, 'none'))
-        if os.path.exists(tpath) and world == 1 and args.reads == 1_000_000 and k == 21 and step == 21 \
-                and args.paths == 1:
-            tj = json.load(open(tpath))
-            t = tj.get('per_launch', {}).get('k_fm_locate_direct' if dom == 'k_fm_locate' else dom) \
-                if tj.get('mode', 'traverse') == args.mode else None
-            if t:
-                traffic = t.get('fetch_size_bytes', 0.0) + t.get('write_size_bytes', 0.0)
         out = {
             'metric': 'seeds queried/sec (and hits located/sec), 150bp reads k=21, chr22 1000G graph',
-            'value': seeds_per_step * steps / elapsed,
+            'value': seeds_total / elapsed,
             'unit': 'seeds/s',
             'n_gpus': world,
             'steps': steps,
@@ -276,14 +394,16 @@ def main():
             'vs_baseline': None,
             'dtype': 'u64',
             'data': 'synthetic',
-            'hits_per_s': hits_per_step * steps / elapsed,
+            'value_definition': 'reads resident in HBM, hits left in HBM (bench contract); the SURVEY 8(d) rate '
+                                '(H2D + kernels + device sort-unique + D2H) is end_to_end.value',
+            'hits_per_s': hits_total / elapsed,
             'config': {
                 'workload': 'chr22-like synthetic stand-in (BASELINE.json configs[1]): %d bp backbone '
-                            'incl. %d bp leading N, %d bi-allelic SNV bubbles, nodes <= 32 bp; %d x %d bp '
-                            'error-free haplotype-walk reads per GPU, k=%d, seed distance %d, %d indexed '
-                            'path(s), SA sampling %d' % (args.backbone, args.nblock, args.snvs, args.reads,
+                            'incl. %d bp leading N, %d bi-allelic SNV bubbles, nodes <= 32 bp; %d batches of %d x %d bp '
+                            'error-free haplotype-walk reads per GPU alternating, k=%d, seed distance %d, %d indexed '
+                            'path(s), SA sampling %d' % (args.backbone, args.nblock, args.snvs, nb, args.reads,
                                                          args.read_len, k, step, args.paths, args.sa_rate),
-                'reads_per_gpu': args.reads, 'read_len': args.read_len, 'k': k, 'seed_step': step,
+                'reads_per_gpu': args.reads, 'read_len': args.read_len, 'k': k, 'seed_step': step, 'read_batches': nb,
                 'indexed_paths': args.paths, 'nodes': int(g.n_nodes), 'edges': int(g.n_edges),
                 'text_len': int(px.text_len), 'starting_loci': int(px.view.n_loci),
                 'ftab_len': int(px.view.ftab_len), 'sa_rate': int(px.view.sa_rate),
@@ -291,69 +411,125 @@ def main():
                 'seeds_per_step_per_gpu': int(c['n_seeds']), 'hits_per_step_per_gpu': int(c['n_hits']),
                 'hits_on_path': int(c['n_hits_on_path']), 'hits_off_path': int(c['n_hits_off_path']),
                 'query_mode': args.mode, 'locus_kmers': int(c['n_locus_kmers']), 'path_kmers': int(c['n_path_kmers']),
-                'table_build_ms': float(c['ms_locus_table_build']),
+                'table_build_ms': float(c['ms_locus_table_build']), 'prepare_wall_s': t_prep,
                 'loci_traversed_per_step': int(c['n_loci_traversed']),
-                'kwalks_from_loci': int(kwalks_all), 'kwalks_completed_per_step': int(c['n_kpaths']),
-                'lf_steps_per_step': int(c['n_lf_steps']), 'rows_verified_per_step': int(c['n_rows_verified']), 'parallelism': 'reads sharded x%d, index replicated' % world,
+                'kwalks_from_loci': int(c['n_kwalks_all']), 'kwalks_completed_per_step': int(c['n_kpaths']),
+                'lf_steps_per_step': int(c['n_lf_steps']), 'rows_verified_per_step': int(c['n_rows_verified']),
+                'parallelism': 'reads sharded x%d, index replicated' % world,
             },
-            'roofline': {
-                'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': abytes,
-                'survey_8d_bytes_per_launch': survey_bytes,
-                'traffic_gbs': (traffic / (avg_ms * 1e-3) / 1e9) if traffic and avg_ms > 0 else None,
-                'kernel_ms_per_step': {n: v / steps for n, v in kern.items()},
-                # secondary bound: divergent 16-byte loads per second against the rate
-                # tools/rand_sector2.hip measures on this part for a table of this size
-                # (profiles/r01_rand_sector_slot_loads.txt: 41.4 G/s on 8 GiB)
-                'random_loads_per_s': (c['n_seeds_valid'] / (avg_ms * 1e-3)) if dom == 'k_kmer_probe' and avg_ms > 0 else None,
-                'random_load_peak_per_s': 41.4e9,
-            },
+            'roofline': roofline_of(main_res, args.mode),
         }
-        if world == 1:
-            # PCIe-inclusive rate of the host-buffer entry point (never `value`)
-            finder.seeds_all((bases, off), step=step)
+        if gather:
+            out['gather_hits'] = gather
+    if world == 1 and not lean:
+        # ---- the same workload in the other query modes: the kernels north_star names --------------
+        by_mode = {args.mode: main_res}
+        for m in ('kmer-table', 'locus-table', 'traverse'):
+            if m in by_mode:
+                continue
+            f2 = psi_amd.SeedFinder(g, k, device=local_rank, mode=m)
+            f2.set_path_index(px)
+            f2.prepare()
+            by_mode[m] = time_mode(f2, 10, 3, m, False)
+            f2.close()
+        rbm = {}
+        for m, res in by_mode.items():
+            e = {'ms_per_step': res['elapsed'] / res['steps'] * 1e3, 'seeds_per_s': res['seeds'] / res['elapsed'],
+                 'hits_per_step': int(res['c']['n_hits']), 'dominant': roofline_of(res, m)}
+            if m != 'kmer-table':
+                e['k_fm_search'] = roofline_of(res, m, 'k_fm_search')
+                e['k_fm_locate'] = roofline_of(res, m, 'k_fm_locate')
+            if m == 'traverse':
+                e['k_traverse'] = roofline_of(res, m, 'k_traverse')
+            rbm[m] = e
+        out['roofline_by_mode'] = rbm
+
+        # ---- the host entry point, PCIe included ------------------------------------
+        hits = psi_amd.Hits()
+        pin = [(psi_amd.pinned_copy(b), psi_amd.pinned_copy(o)) for b, o in batches]
+
+        def host_entry(src, flags, reps):
+            calls = [(finder.ctx, psi_amd._ptr(b), psi_amd._ptr(o), args.reads, k, step, rec_offset, flags, C.byref(hits))
+                     for b, o in src]
+            n_h = 0
+            for i in range(2):                       # warm: pinned pool, slot buffers
+                if L.psigpu_find_seeds(*calls[i % nb]):
+                    raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
+                L.psigpu_free_hits(C.byref(hits))
             t1 = time.perf_counter()
-            finder.seeds_all((bases, off), step=step)
-            out['host_entry_ms_per_step'] = (time.perf_counter() - t1) * 1e3
-            # the same workload in the other query modes (same hit set), 5 timed steps each
-            other = {}
-            for m in ('kmer-table', 'locus-table', 'traverse'):
-                if m == args.mode:
-                    continue
-                f2 = psi_amd.SeedFinder(g, k, device=local_rank, mode=m)
-                f2.set_path_index(px)
-                for _ in range(2):
-                    f2.seeds_all_device(d_bases.data_ptr(), d_off.data_ptr(), args.reads, len(bases), step=step,
-                                        rec_offset=rec_offset, stream=stream)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(5):
-                    f2.seeds_all_device(d_bases.data_ptr(), d_off.data_ptr(), args.reads, len(bases), step=step,
-                                        rec_offset=rec_offset, stream=stream)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 5
-                c2 = f2.counters()
-                other[m] = {'ms_per_step': dt * 1e3, 'seeds_per_s': c2['n_seeds'] / dt, 'hits_per_step': int(c2['n_hits'])}
-                f2.close()
-            out['other_query_modes'] = other
-        if world == 1 and args.cpu_reads != 0:
+            for i in range(reps):
+                if L.psigpu_find_seeds(*calls[i % nb]):
+                    raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
+                n_h = hits.n
+                L.psigpu_free_hits(C.byref(hits))
+            return (time.perf_counter() - t1) / reps, n_h
+
+        pinned_src = [(p[0].array, p[1].array) for p in pin]
+        pageable_src = [(np.ascontiguousarray(b), np.ascontiguousarray(o.astype(np.uint64))) for b, o in batches]
+        t_su, n_su = host_entry(pinned_src, psi_amd.ALL | psi_amd.SORT_UNIQUE, 10)
+        t_raw, n_raw = host_entry(pinned_src, psi_amd.ALL, 10)
+        t_pg, _ = host_entry(pageable_src, psi_amd.ALL | psi_amd.SORT_UNIQUE, 6)
+        c_e = finder.counters()
+        bytes_in = float(len(batches[0][0]) + 8 * (args.reads + 1))
+        bytes_out = 32.0 * n_su
+        pcie_bound_ms = max(bytes_in, bytes_out) / (PCIE_PEAK_GBS * 1e9) * 1e3
+        out['end_to_end'] = {
+            'what': 'psigpu_find_seeds: H2D of the reads + kernels + sort-unique on the device + D2H of the hits '
+                    '(SURVEY 8(d) timed region), reads in pinned host memory, sub-batches pipelined over three streams',
+            'value': c_e['n_seeds'] / t_su, 'unit': 'seeds/s', 'ms_per_step': t_su * 1e3,
+            'hits_per_step_sort_unique': int(n_su), 'hits_per_s': n_su / t_su,
+            'raw_hits_ms_per_step': t_raw * 1e3, 'hits_per_step_raw': int(n_raw),
+            'pageable_reads_ms_per_step': t_pg * 1e3,
+            'device_ms_per_step': float(c_e['ms_total']), 'device_sort_ms_per_step': float(c_e['ms_sort']),
+            'roofline': {'bound': 'pcie', 'achieved': max(bytes_in, bytes_out) / t_su / 1e9, 'peak': PCIE_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': pcie_bound_ms / (t_su * 1e3), 'bytes_in': bytes_in, 'bytes_out': bytes_out,
+                         'note': 'full duplex: the bound is max(bytes in, bytes out) / one-direction rate'},
+        }
+        out['host_entry_ms_per_step'] = t_su * 1e3
+
+        # ---- second series: 1 % substitution errors ------------------------------------
+        eb, eo = synth.sim_reads_snv(sg, args.reads, args.read_len, seed=13 + rank, sub_rate=0.01)
+        d_eb, d_eo = torch.from_numpy(eb).cuda(), torch.from_numpy(eo.astype(np.int64)).cuda()
+        for _ in range(3):
+            finder.seeds_all_device(d_eb.data_ptr(), d_eo.data_ptr(), args.reads, len(eb), step=step, stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            finder.seeds_all_device(d_eb.data_ptr(), d_eo.data_ptr(), args.reads, len(eb), step=step, stream=stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 10
+        ce = finder.counters()
+        out['series_1pct_error'] = {'ms_per_step': dt * 1e3, 'seeds_per_s': ce['n_seeds'] / dt, 'hits_per_s': ce['n_hits'] / dt,
+                                    'hits_per_step': int(ce['n_hits'])}
+        del d_eb, d_eo
+
+        # ---- CPU baseline + parity gate -------------------------------------------------------------
+        if args.cpu_reads != 0:
             import oracle
             cores = oracle.lib().orc_max_threads()
             sample = args.cpu_reads if args.cpu_reads > 0 else min(args.reads, max(20_000, 125_000 * cores))
-            base, cpu_hits = cpu_baseline(sg, px, bases, off, k, step, sample)
+            og, pidx = oracle_objects(sg, px)
+            base, cpu_hits = cpu_baseline(og, pidx, px, batches[0][0], batches[0][1], k, step, sample)
             out['cpu_baseline'] = base
-            if args.check:
-                d_hits = np.zeros((n_hits, 4), np.uint64)
-                import ctypes
-                hip = ctypes.CDLL('libamdhip64.so')
-                hip.hipMemcpy(d_hits.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
-                              ctypes.c_size_t(n_hits * 32), 2)
-                got = psi_amd.sort_unique(d_hits)
-                got = got[got[:, 2] < sample]
+            if not args.no_check:
                 want = oracle.sort_unique(cpu_hits)
-                out['parity_vs_cpu_sample'] = bool(got.shape == want.shape and (got == want).all())
+                ptr, n = finder.seeds_all_device(dev[0][0].data_ptr(), dev[0][1].data_ptr(), args.reads, dev[0][2], step=step,
+                                                 rec_offset=0, stream=stream)
+                got = psi_amd.sort_unique(finder.copy_hits(ptr, n))
+                got = got[got[:, 2] < sample]
+                ok_dev = bool(got.shape == want.shape and (got == want).all())
+                # and the host entry point (pipeline + device sort-unique) returns the same set, in order
+                su = finder.seeds_all(pinned_src[0], step=step, sort_unique=True)
+                su = su[su[:, 2] < sample]
+                ordered = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
+                ok_host = bool(su.shape == ordered.shape and (su == ordered).all())
+                out['parity_vs_cpu_sample'] = ok_dev and ok_host
+                out['parity_detail'] = {'device_entry': ok_dev, 'host_entry_sorted': ok_host, 'reads_checked': int(sample),
+                                        'hits_checked': int(len(want))}
         else:
+            out['cpu_baseline'] = None
+    if rank == 0:
+        if 'cpu_baseline' not in out:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
     finder.close()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSIGPU_ABI_VERSION 2
+#define PSIGPU_ABI_VERSION 3
 #define PSIGPU_MAX_SEED_LEN 31u   /* seeds are 2-bit packed into one 64-bit word */
 
 /* Status codes */
@@ -232,32 +232,55 @@ int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr);
 #define PSIGPU_MODE_LOCUS_TABLE 2u
 int psigpu_set_query_mode(psigpu_ctx* ctx, uint32_t mode, uint32_t walk_cap);
 
+/* Builds the tables of the current query mode for seed length k now (index load time) instead of
+ * inside the first query: the k-walks of the starting loci enumerated by the traverser kernel, the
+ * path k-mers read off the suffix array, sorted and hashed.  Blocks until the device is idle (it
+ * allocates and frees gigabytes).  Without this call the first psigpu_find_seeds* call does the
+ * same.  No counterpart in the reference (it re-traverses every chunk); closest in role:
+ * SeedFinder::create_path_index / load_path_index (seed_finder.hpp:1330-1413). */
+int psigpu_prepare(psigpu_ctx* ctx, uint32_t k);
+
 /* flags for psigpu_find_seeds* */
 #define PSIGPU_ON_PATHS 1u      /* SeedFinder::seeds_on_paths  (seed_finder.hpp:1426-1457) */
 #define PSIGPU_OFF_PATHS 2u     /* SeedFinder::seeds_off_paths (seed_finder.hpp:1703-1722) */
 #define PSIGPU_ALL 3u           /* SeedFinder::seeds_all       (seed_finder.hpp:1724-1732) */
 #define PSIGPU_SORT_UNIQUE 4u   /* return sort-unique hits ordered by (read_id, read_offset,
-                                   node_id, node_offset) instead of the raw emission stream */
+                                   node_id, node_offset) instead of the raw emission stream;
+                                   sorted on the device (64-bit packed keys, radix sort) */
 
 /* One chunk of psikt's loop: get_seeds + index_reads + seeds_all (src/psikt.cpp:195-204).
  * `bases`/`read_off` are HOST buffers (read i = bases[read_off[i] .. read_off[i+1])),
  * `step` is psikt's -d (0 = k), `rec_offset` the number of reads consumed before this
- * chunk (sequence.hpp:1616).  Hits come back in library-owned pinned host memory. */
+ * chunk (sequence.hpp:1616).  Hits come back in library-owned pinned host memory.
+ * This is SURVEY 8(d)'s timed region (H2D of the reads + kernels + D2H of the hits): the chunk
+ * is cut into sub-batches that are pipelined over three streams, so the call costs about
+ * max(bytes in, bytes out) / PCIe rate.  Reads held in pinned memory (psigpu_host_alloc) are
+ * DMA'd in place; pageable reads are staged by a helper thread. */
 int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off,
                       uint64_t n_reads, uint32_t k, uint32_t step, uint64_t rec_offset,
                       uint32_t flags, psigpu_hits* out);
 void psigpu_free_hits(psigpu_hits* hits);
+
+/* Pinned (page-locked) host memory for read chunks: what the reference keeps in
+ * Records / seqan2::StringSet (sequence.hpp:1130-1294) the caller keeps here, and the copy
+ * engine reads it in place.  NULL when no GPU is present. */
+void* psigpu_host_alloc(uint64_t bytes);
+void psigpu_host_free(void* p);
 
 /* Same with the chunk already resident in HBM and the hits left there (n_bases must be the
  * total length of the reads, d_read_off[n_reads]): `d_bases` and
  * `d_read_off` are DEVICE pointers; `stream` is a hipStream_t (NULL = default stream).
  * On return *d_hits points at library-owned device memory holding *n_hits records, valid
  * until the next call on this context.  The call is asynchronous up to the final count
- * read-back (one stream synchronise). */
+ * read-back (one stream synchronise; one more with PSIGPU_SORT_UNIQUE). */
 int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off,
                              uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step,
                              uint64_t rec_offset, uint32_t flags, void* stream,
                              const psigpu_hit** d_hits, uint64_t* n_hits);
+
+/* Copies `n` records that psigpu_find_seeds_device left in HBM into host memory (blocking;
+ * through this library's HIP runtime, so that a binding never has to load one of its own). */
+int psigpu_copy_hits(psigpu_ctx* ctx, psigpu_hit* host_dst, const psigpu_hit* d_src, uint64_t n);
 
 /* SeedFinderStats / TraverserStats counters of the last call (seed_finder.hpp:111-494;
  * traverser_base.hpp:108-268) plus per-kernel device times from HIP events recorded on the

@@ -115,6 +115,10 @@ ABI = [
     ('psigpu_find_seeds_device', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_uint64, C.c_uint32, _P, C.POINTER(_P), _U64P]),
     ('psigpu_get_counters', C.c_int, [_P, C.POINTER(Counters)]),
+    ('psigpu_prepare', C.c_int, [_P, C.c_uint32]),
+    ('psigpu_copy_hits', C.c_int, [_P, _P, _P, C.c_uint64]),
+    ('psigpu_host_alloc', _P, [C.c_uint64]),
+    ('psigpu_host_free', None, [_P]),
 ]
 
 _lib = None
@@ -128,7 +132,7 @@ def lib():
         # (same SONAME as /opt/rocm's).  Two HSA runtimes cannot share the GPU inside one
         # process, so when torch is installed it is imported FIRST and libpsi_gpu.so then binds
         # to the runtime torch already loaded.  Set PSI_AMD_NO_TORCH=1 for torch-free processes.
-        if not os.environ.get('PSI_AMD_NO_TORCH'):
+        if os.environ.get('PSI_AMD_NO_TORCH', '0') in ('', '0'):
             try:
                 import torch  # noqa: F401
             except ImportError:
@@ -153,6 +157,35 @@ def _ptr(a):
 
 def _host_err() -> str:
     return lib().psigpu_host_last_error().decode()
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory from psigpu_host_alloc: a read chunk kept here is
+    DMA'd in place by psigpu_find_seeds (no staging copy).  Keep the object alive while the
+    array is in use; the memory is released with it."""
+
+    def __init__(self, n: int, dtype):
+        self.dtype = np.dtype(dtype)
+        self.n = int(n)
+        self.nbytes = max(1, self.n * self.dtype.itemsize)
+        self.ptr = lib().psigpu_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise PsiGpuError('psigpu_host_alloc(%d) failed (no GPU?)' % self.nbytes)
+        buf = (C.c_uint8 * self.nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=self.n)
+
+    def __del__(self):
+        if getattr(self, 'ptr', None) and _lib is not None:
+            self.array = None
+            _lib.psigpu_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_copy(a: np.ndarray) -> PinnedArray:
+    a = np.ascontiguousarray(a)
+    p = PinnedArray(a.size, a.dtype)
+    p.array[:] = a.ravel()
+    return p
 
 
 def pack_reads(reads: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
@@ -403,6 +436,10 @@ class SeedFinder:
         self.pindex = pindex
         self._chk(lib().psigpu_load_index(self.ctx, C.byref(pindex.view)))
 
+    def prepare(self) -> None:
+        """Build the query mode's tables now (index load time) instead of inside the first query."""
+        self._chk(lib().psigpu_prepare(self.ctx, self.seed_len))
+
     def load_path_index(self, prefix: str) -> bool:
         try:
             self.set_path_index(PathIndex.load(prefix))
@@ -449,13 +486,20 @@ class SeedFinder:
 
     def seeds_all_device(self, d_bases_ptr: int, d_read_off_ptr: int, n_reads: int, n_bases: int,
                          step: int = 0, rec_offset: int = 0, flags: int = ALL, stream: int = 0):
-        """Device-resident chunk in, device-resident hits out: returns (device pointer, n_hits)."""
+        """Device-resident chunk in, device-resident hits out: returns (device pointer, n_hits).
+        flags may include SORT_UNIQUE (sorted on the device)."""
         d_hits = C.c_void_p()
         n = C.c_uint64()
         self._chk(lib().psigpu_find_seeds_device(self.ctx, d_bases_ptr, d_read_off_ptr, n_reads, n_bases,
                                                  self.seed_len, step, rec_offset, flags, stream,
                                                  C.byref(d_hits), C.byref(n)))
         return d_hits.value, n.value
+
+    def copy_hits(self, d_ptr: int, n: int) -> np.ndarray:
+        """Device-resident hits (pointer from seeds_all_device) -> (n, 4) uint64 array."""
+        out = np.zeros((n, 4), np.uint64)
+        self._chk(lib().psigpu_copy_hits(self.ctx, _ptr(out), d_ptr, n))
+        return out
 
     def counters(self) -> dict:
         c = Counters()

@@ -18,13 +18,19 @@
 // Wavefronts are 64 lanes.  A "quad" is 4 adjacent lanes that fetch one 64-byte rank block
 // as 4 x 16 B (one coalesced sector) and combine partial popcounts with DPP quad permutes.
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -131,6 +137,7 @@ struct DevCounters {
   StripedCounter n_rows_verified; // SA rows K1 checked against the text
   PaddedCounter n_defer;         // seeds k_fm_search_direct left to the quad kernel
   PaddedCounter n_seeds_true;    // the scan's seed count (comes back to the host with the counters)
+  PaddedCounter max_read_len;    // longest read of the chunk (the hit sorter sizes its key fields with it)
   PaddedCounter dbg0, dbg1;      // diagnostics (builds with -DTRAV_STATS)
 };
 
@@ -265,6 +272,15 @@ __global__ void __launch_bounds__(256) k_fill3(FillJob a, FillJob b, FillJob c)
   for (uint64_t i = t0; i < c.n16; i += stride) c.p[i] = make_uint4(c.v, c.v, c.v, c.v);
 }
 
+// Counters / counts go back to the host through a kernel that stores into mapped pinned memory, not
+// through a copy-engine transfer: a 20-KB D2H queues behind whatever large copy the same SDMA
+// engine is busy with (the hits of the previous sub-batch in the host entry's pipeline), and the
+// compute stream would then wait for it.
+__global__ void __launch_bounds__(256) k_publish(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16)
+{
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------
 // K0: seeding
 // ------------------------------------------------------------------------------------
@@ -381,8 +397,18 @@ k_seed_scan_final(const uint64_t* __restrict__ read_off, uint64_t n, uint32_t k,
   if ((threadIdx.x & 63) == 0) shp[threadIdx.x >> 6] = before;
   uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
   uint32_t c[SCAN_ITEMS];
-  uint64_t s = 0;
-  for (int i = 0; i < SCAN_ITEMS; ++i) { c[i] = base + i < n ? seeds_of_read(read_off, base + i, k, step) : 0u; s += c[i]; }
+  uint64_t s = 0, longest = 0;
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    c[i] = 0;
+    if (base + i < n) {
+      const uint64_t len = read_off[base + i + 1] - read_off[base + i];
+      c[i] = len >= k ? (uint32_t)((len - k) / step + 1) : 0u;
+      longest = max(longest, len);
+    }
+    s += c[i];
+  }
+  for (int d = 32; d > 0; d >>= 1) longest = max(longest, (uint64_t)__shfl_down(longest, d));
+  if ((threadIdx.x & 63) == 0 && longest) atomicMax(&ctr->max_read_len.v, (unsigned long long)longest);
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int d = 1; d < SCAN_THREADS; d <<= 1) {
@@ -2153,11 +2179,35 @@ struct psigpu_ctx {
       w_chunks, w_chunk_fill, w_chunk_off, w_chunk_tiles, w_hits, w_spill_a, w_spill_b, w_ctr, w_total;
   uint64_t hits_cap_hint = 0, chunks_cap_hint = 0;
   uint64_t spill_cap = 1u << 22;   // traverser spill queue entries (grows when a chunk overflows it)
-  void* h_pinned = nullptr;        // pinned host mirror of the counters + seed count (async D2H without staging)
+  void* h_pinned = nullptr;        // pinned host mirror of the counters + counts, written by k_publish
+  void* h_pinned_dev = nullptr;    // the same memory as the device addresses it
   hipEvent_t ev[12];
   bool have_events = false;
   hipStream_t stream2 = nullptr;
   psigpu_counters last{};
+  uint64_t last_max_read_len = 0;  // longest read of the last run_pipeline call
+  // sort-unique on the device (PSIGPU_SORT_UNIQUE)
+  uint64_t max_node_len = 0;
+  DevBuf ids_sorted;               // node ids in increasing order (only when they are not rank + id_base)
+  HitSorter sorter;
+  DevBuf w_sorted[2], w_count;
+  // host entry point: sub-batches of a chunk pipelined through two slots (H2D | kernels | D2H)
+  struct Slot {
+    DevBuf bases, off;
+    void* h_stage = nullptr; size_t h_cap = 0;   // pinned staging: rebased read offsets, and the bases of pageable callers
+    void* h_stage_dev = nullptr;                 // the same memory as the device addresses it
+    hipEvent_t in_ready = nullptr, out_done = nullptr;
+  } slot[2];
+  DevBuf w_hits_alt;
+  hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+  // the pipeline's transfers, each direction on a copy engine of its own (see pipeline_init)
+  struct EngineCopy {
+    bool ok = false;
+    hsa_agent_t gpu{}, cpu{};
+    uint32_t eng_in = 0, eng_out = 0;            // hsa_amd_sdma_engine_id_t bits
+    hsa_signal_t sig_in[2]{}, sig_out[2]{};      // per slot: 1 while the slot's transfer is in flight
+  } ec;
+  double hits_per_read_hint = 0.0;
 };
 
 static thread_local std::string g_create_err;
@@ -2180,7 +2230,7 @@ struct PinnedPool {
       }
     void* p = nullptr;
     size_t want = bytes + bytes / 8 + 4096;
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocMapped) != hipSuccess) return nullptr;
     live.emplace_back(p, want);
     return p;
   }
@@ -2236,10 +2286,8 @@ psigpu_ctx* psigpu_create(int device)
   for (auto& ev : ctx->ev)
     if (hipEventCreate(&ev) != hipSuccess) { g_create_err = "hipEventCreate failed"; delete ctx; return nullptr; }
   ctx->have_events = true;
-  if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
-    g_create_err = "hipStreamCreate failed"; psigpu_destroy(ctx); return nullptr;
-  }
-  if (hipHostMalloc(&ctx->h_pinned, sizeof(DevCounters) + 64, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(&ctx->h_pinned, sizeof(DevCounters) + 64, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer(&ctx->h_pinned_dev, ctx->h_pinned, 0) != hipSuccess) {
     g_create_err = "hipHostMalloc failed"; psigpu_destroy(ctx); return nullptr;
   }
   return ctx;
@@ -2257,6 +2305,16 @@ void psigpu_destroy(psigpu_ctx* ctx)
                     &ctx->w_ctr, &ctx->w_total, &ctx->lkt_ht, &ctx->lkt_ent, &ctx->lkt_res, &ctx->w_seedout,
                     &ctx->w_iv_tiles_off, &ctx->w_defer, &ctx->sarec, &ctx->saloc, &ctx->kt_ht, &ctx->kt_ext, &ctx->seg_rank, &ctx->w_seedres };
   for (auto* b : all) b->release();
+  ctx->ids_sorted.release(); ctx->w_sorted[0].release(); ctx->w_sorted[1].release(); ctx->w_count.release();
+  ctx->w_hits_alt.release();
+  for (auto& sl : ctx->slot) {
+    sl.bases.release(); sl.off.release();
+    if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+    if (sl.in_ready) (void)hipEventDestroy(sl.in_ready);
+    if (sl.out_done) (void)hipEventDestroy(sl.out_done);
+  }
+  for (hipStream_t st : { ctx->s_in, ctx->s_comp, ctx->s_out }) if (st) (void)hipStreamDestroy(st);
+  if (ctx->ec.ok) for (int i = 0; i < 2; ++i) { (void)hsa_signal_destroy(ctx->ec.sig_in[i]); (void)hsa_signal_destroy(ctx->ec.sig_out[i]); }
   if (ctx->have_events) for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -2389,6 +2447,15 @@ int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
   ctx->id_base = n ? g->node_id[0] : 0;
   ctx->id_affine = true;
   for (uint64_t v = 0; v < n && ctx->id_affine; ++v) ctx->id_affine = g->node_id[v] == ctx->id_base + v;
+  ctx->max_node_len = 0;
+  for (uint64_t v = 0; v < n; ++v) ctx->max_node_len = std::max<uint64_t>(ctx->max_node_len, g->label_off[v + 1] - g->label_off[v]);
+  ctx->ids_sorted.release();
+  if (!ctx->id_affine) {
+    // the hit sorter orders by node id: keys hold a node's position among the sorted ids
+    std::vector<uint64_t> ids(g->node_id, g->node_id + n);
+    std::sort(ids.begin(), ids.end());
+    if ((st = upload(ctx, ctx->ids_sorted, ids.data(), n, 1))) return st;
+  }
   lkt_release(ctx);
   return PSIGPU_OK;
 }
@@ -2771,6 +2838,14 @@ static int ensure_lkt(psigpu_ctx* ctx, uint32_t k, const GraphView& gv)
   return PSIGPU_OK;
 }
 
+static GraphView graph_view(const psigpu_ctx* ctx)
+{
+  GraphView gv;
+  gv.nodes = ctx->nodes.as<NodeRec>(); gv.lite = ctx->lite.as<NodeLite>(); gv.lab2 = ctx->lab2.as<uint64_t>(); gv.labn = ctx->labn.as<uint64_t>();
+  gv.edge_to = ctx->edge_to.as<uint32_t>(); gv.node_id = ctx->node_id.as<uint64_t>();
+  return gv;
+}
+
 static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off,
                         uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t rec_offset,
                         uint32_t flags, hipStream_t stream, uint64_t* n_hits_out)
@@ -2811,9 +2886,11 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   // (every read of length L gives at most L / step + 1 seeds), so their reset can start now, on
   // the second stream, beside seeding -- it depends on nothing.
   static const bool serial = getenv("PSIGPU_SERIAL") != nullptr;   // profiling: no overlap
-  GraphView gv;
-  gv.nodes = ctx->nodes.as<NodeRec>(); gv.lite = ctx->lite.as<NodeLite>(); gv.lab2 = ctx->lab2.as<uint64_t>(); gv.labn = ctx->labn.as<uint64_t>();
-  gv.edge_to = ctx->edge_to.as<uint32_t>(); gv.node_id = ctx->node_id.as<uint64_t>();
+  // the second stream is made when a call first needs it (traverse mode): the runtime multiplexes
+  // streams onto four hardware queues, and two busy streams on one queue serialise
+  if (!ctx->stream2 && !serial && (flags & PSIGPU_OFF_PATHS) && ctx->n_loci)
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  const GraphView gv = graph_view(ctx);
   // Off-path hits: from the locus k-mer table (built on first use), the query-time traverser for
   // the loci the table leaves out -- or for all of them in PSIGPU_OFFPATH_TRAVERSE mode.
   const bool want_off = (flags & PSIGPU_OFF_PATHS) && ctx->n_loci && n_reads;
@@ -3078,7 +3155,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     }
     if (off_paths && !serial) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev[7], 0));   // join
     if (off_paths) {      // the traverser's spill count and chunk count are needed on the host
-      HIPCHK(ctx, hipMemcpyAsync(&h, ctr, sizeof h, hipMemcpyDeviceToHost, stream));
+      k_publish<<<1, 256, 0, stream>>>(reinterpret_cast<const uint4*>(ctr), reinterpret_cast<uint4*>(ctx->h_pinned_dev), (uint32_t)(sizeof(DevCounters) / 16));
       HIPCHK(ctx, hipStreamSynchronize(stream));
     }
     bool spill_overflow = false;
@@ -3107,7 +3184,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
             EnumOut{});
         ++pc.traverse_launches;
         std::swap(qin, qout);
-        HIPCHK(ctx, hipMemcpyAsync(&h, ctr, sizeof h, hipMemcpyDeviceToHost, stream));
+        k_publish<<<1, 256, 0, stream>>>(reinterpret_cast<const uint4*>(ctr), reinterpret_cast<uint4*>(ctx->h_pinned_dev), (uint32_t)(sizeof(DevCounters) / 16));
         HIPCHK(ctx, hipStreamSynchronize(stream));
         ns = h.n_spill.v;
       }
@@ -3131,9 +3208,10 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
       }
     }
     EVREC(8, stream);
-    HIPCHK(ctx, hipMemcpyAsync(&h, ctr, sizeof h, hipMemcpyDeviceToHost, stream));
+    k_publish<<<1, 256, 0, stream>>>(reinterpret_cast<const uint4*>(ctr), reinterpret_cast<uint4*>(ctx->h_pinned_dev), (uint32_t)(sizeof(DevCounters) / 16));
     HIPCHK(ctx, hipStreamSynchronize(stream));
     true_seeds = h.n_seeds_true.v;
+    ctx->last_max_read_len = h.max_read_len.v;
     if (true_seeds > n_seeds) { ctx->err = "n_bases does not cover the reads"; return PSIGPU_ERR_ARG; }
     total_hits = h.n_hits_tab.v + h.n_hits_off.v;
     if (total_hits > cap) { overflow = true; cap = total_hits + total_hits / 16 + 1024; }
@@ -3169,6 +3247,34 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   return PSIGPU_OK;
 }
 
+// PSIGPU_SORT_UNIQUE on the device: ctx->w_hits[0..n) -> dst[0..*n_out), on `stream`; one host
+// synchronisation for the count.  Returns PSIGPU_ERR_FORMAT (err untouched) when the records of this
+// chunk do not fit the sorter's 64-bit key: the caller falls back to the host sort.
+static int device_sort_unique(psigpu_ctx* ctx, uint64_t n, uint64_t n_reads, uint64_t rec_offset, DevBuf& dst,
+                              hipStream_t stream, uint64_t* n_out)
+{
+  *n_out = 0;
+  if (n == 0) return PSIGPU_OK;
+  if (!HitSorter::fits(n_reads, ctx->last_max_read_len, ctx->n_nodes, ctx->max_node_len)) return PSIGPU_ERR_FORMAT;
+  HIPCHK(ctx, dst.ensure((n + 1) * sizeof(psigpu_hit)));
+  HIPCHK(ctx, ctx->w_count.ensure(64));
+  EVREC(11, stream);
+  int st = ctx->sorter.run(ctx->w_hits.as<psigpu_hit>(), n, rec_offset, n_reads, ctx->last_max_read_len, ctx->n_nodes,
+                           ctx->max_node_len, ctx->id_affine, ctx->id_base, ctx->ids_sorted.as<uint64_t>(),
+                           dst.as<psigpu_hit>(), ctx->w_count.as<uint64_t>(), stream, &ctx->err);
+  if (st != PSIGPU_OK) return st;
+  EVREC(0, stream);                 // (event 0 is free again once run_pipeline has read its times)
+  uint64_t* h_n = reinterpret_cast<uint64_t*>((char*)ctx->h_pinned + sizeof(DevCounters) + 16);
+  k_publish<<<1, 256, 0, stream>>>(ctx->w_count.as<uint4>(), reinterpret_cast<uint4*>((char*)ctx->h_pinned_dev + sizeof(DevCounters) + 16), 1);
+  HIPCHK(ctx, hipStreamSynchronize(stream));
+  *n_out = *h_n;
+  float t = 0;
+  (void)hipEventElapsedTime(&t, ctx->ev[11], ctx->ev[0]);
+  ctx->last.ms_sort = t;
+  ctx->last.n_hits = *n_out;
+  return PSIGPU_OK;
+}
+
 int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off,
                              uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step,
                              uint64_t rec_offset, uint32_t flags, void* stream,
@@ -3176,17 +3282,183 @@ int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_
 {
   if (!ctx || !d_hits || !n_hits || (n_reads && (!d_read_off))) return PSIGPU_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (flags & PSIGPU_SORT_UNIQUE) { ctx->err = "PSIGPU_SORT_UNIQUE is only available on the host entry point"; return PSIGPU_ERR_ARG; }
   if ((flags & PSIGPU_ALL) == 0) flags |= PSIGPU_ALL;
   uint64_t n = 0;
-  int st = run_pipeline(ctx, d_bases, d_read_off, n_reads, n_bases, k, step, rec_offset, flags,
+  int st = run_pipeline(ctx, d_bases, d_read_off, n_reads, n_bases, k, step, rec_offset, flags & ~PSIGPU_SORT_UNIQUE,
                         (hipStream_t)stream, &n);
   if (st != PSIGPU_OK) return st;
   *d_hits = ctx->w_hits.as<psigpu_hit>();
   *n_hits = n;
+  if (flags & PSIGPU_SORT_UNIQUE) {
+    st = device_sort_unique(ctx, n, n_reads, rec_offset, ctx->w_sorted[0], (hipStream_t)stream, &n);
+    if (st == PSIGPU_ERR_FORMAT) { ctx->err = "hit records of this chunk do not fit the device sorter's 64-bit key"; return PSIGPU_ERR_ARG; }
+    if (st != PSIGPU_OK) return st;
+    *d_hits = n ? ctx->w_sorted[0].as<psigpu_hit>() : ctx->w_hits.as<psigpu_hit>();
+    *n_hits = n;
+  }
   return PSIGPU_OK;
 }
 
+int psigpu_copy_hits(psigpu_ctx* ctx, psigpu_hit* host_dst, const psigpu_hit* d_src, uint64_t n)
+{
+  if (!ctx || (n && (!host_dst || !d_src))) return PSIGPU_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (n) HIPCHK(ctx, hipMemcpy(host_dst, d_src, n * sizeof(psigpu_hit), hipMemcpyDeviceToHost));
+  return PSIGPU_OK;
+}
+
+int psigpu_prepare(psigpu_ctx* ctx, uint32_t k)
+{
+  if (!ctx) return PSIGPU_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..31)"; return PSIGPU_ERR_ARG; }
+  if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
+  if (ctx->query_mode == PSIGPU_MODE_TRAVERSE) return PSIGPU_OK;          // nothing is tabulated in this mode
+  if (ctx->index_k != k) return PSIGPU_OK;                                // tables exist for the index's seed length only
+  if (ctx->n_loci == 0 && !(ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->n_paths)) return PSIGPU_OK;
+  return ensure_lkt(ctx, k, graph_view(ctx));
+}
+
+void* psigpu_host_alloc(uint64_t bytes)
+{
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+
+void psigpu_host_free(void* p)
+{
+  if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"
+
+namespace {
+
+// is this host pointer pinned (hipHostMalloc / hipHostRegister), i.e. can the copy engine read it in place?
+bool host_ptr_is_pinned(const void* p)
+{
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+// pageable -> pinned staging copy with a few threads (one core moves ~10 GB/s, the link 55)
+void parallel_copy(char* dst, const char* src, size_t n)
+{
+  const size_t MIN_PART = 2u << 20;
+  unsigned parts = (unsigned)std::min<size_t>(4, std::max<size_t>(1, n / MIN_PART));
+  if (parts <= 1) { memcpy(dst, src, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n / parts + 63) & ~(size_t)63;
+  for (unsigned t = 1; t < parts; ++t) {
+    const size_t a = std::min(n, t * per), b = std::min(n, (t + 1) * per);
+    th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
+  }
+  memcpy(dst, src, std::min(n, per));
+  for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+// Streams and events of the host entry's pipeline, made on its first call.
+//
+// The two transfer directions get one SDMA engine each, by name.  hipMemcpyAsync leaves the choice
+// to the runtime ("the engine this stream used last if it is idle, else the first idle one"), and
+// in this pipeline both directions regularly end up on ONE engine and share its ~55 GB/s instead of
+// running full duplex (2 x 47 GB/s, tools/pcie_rate.hip) -- a chunk then costs 7 ms instead of 5.5.
+// ROCr's hsa_amd_memory_async_copy_on_engine takes the engine explicitly; completion is an HSA
+// signal the host waits on (the pipeline is host-synchronous at every stage boundary anyway).
+// When anything here is unavailable the transfers fall back to hipMemcpyAsync.
+static hsa_status_t find_agents_cb(hsa_agent_t a, void* data)
+{
+  auto* v = static_cast<std::vector<hsa_agent_t>*>(data);
+  v->push_back(a);
+  return HSA_STATUS_SUCCESS;
+}
+
+static void engine_copy_init(psigpu_ctx* ctx)
+{
+  psigpu_ctx::EngineCopy& ec = ctx->ec;
+  ec.ok = false;
+  if (getenv("PSIGPU_NO_ENGINE_COPY")) return;
+  if (hsa_init() != HSA_STATUS_SUCCESS) return;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return;
+  std::vector<hsa_agent_t> agents;
+  if (hsa_iterate_agents(find_agents_cb, &agents) != HSA_STATUS_SUCCESS) return;
+  bool have_gpu = false, have_cpu = false;
+  for (hsa_agent_t a : agents) {
+    hsa_device_type_t type;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS) continue;
+    if (type == HSA_DEVICE_TYPE_CPU && !have_cpu) { ec.cpu = a; have_cpu = true; }
+    if (type == HSA_DEVICE_TYPE_GPU && !have_gpu) {
+      uint32_t bdf = 0, domain = 0;
+      if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) continue;
+      (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+      const uint32_t want = ((uint32_t)prop.pciBusID << 8) | ((uint32_t)prop.pciDeviceID << 3);
+      if ((bdf & ~7u) == want && domain == (uint32_t)prop.pciDomainID) { ec.gpu = a; have_gpu = true; }
+    }
+  }
+  if (!have_gpu || !have_cpu) return;
+  uint32_t mask_in = 0, mask_out = 0;
+  if (hsa_amd_memory_copy_engine_status(ec.gpu, ec.cpu, &mask_in) != HSA_STATUS_SUCCESS) mask_in = 0;      // dst, src
+  if (hsa_amd_memory_copy_engine_status(ec.cpu, ec.gpu, &mask_out) != HSA_STATUS_SUCCESS) mask_out = 0;
+  if (mask_in == 0 || mask_out == 0) return;
+  ec.eng_in = mask_in & (~mask_in + 1);                       // lowest engine that can copy host -> device
+  uint32_t rest = mask_out & ~ec.eng_in;
+  if (rest == 0) return;                                      // a single engine: nothing to separate
+  ec.eng_out = rest & (~rest + 1);
+  for (int i = 0; i < 2; ++i)
+    if (hsa_signal_create(0, 0, nullptr, &ec.sig_in[i]) != HSA_STATUS_SUCCESS ||
+        hsa_signal_create(0, 0, nullptr, &ec.sig_out[i]) != HSA_STATUS_SUCCESS) return;
+  ec.ok = true;
+  if (getenv("PSIGPU_TRACE")) fprintf(stderr, "[psigpu] copy engines: in 0x%x of 0x%x, out 0x%x of 0x%x\n", ec.eng_in, mask_in, ec.eng_out, mask_out);
+}
+
+static int pipeline_init(psigpu_ctx* ctx)
+{
+  if (ctx->s_comp) return PSIGPU_OK;
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_comp, hipStreamNonBlocking));
+  engine_copy_init(ctx);
+  if (!ctx->ec.ok) {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking));
+  }
+  for (auto& sl : ctx->slot) {
+    HIPCHK(ctx, hipEventCreateWithFlags(&sl.in_ready, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming));
+  }
+  return PSIGPU_OK;
+}
+
+// one transfer of the pipeline: `slot_sig` goes 1 -> 0 when it is complete
+static bool engine_copy(psigpu_ctx* ctx, bool to_device, void* dst, const void* src, size_t bytes, hsa_signal_t slot_sig)
+{
+  const psigpu_ctx::EngineCopy& ec = ctx->ec;
+  hsa_signal_store_relaxed(slot_sig, 1);
+  hsa_status_t st = hsa_amd_memory_async_copy_on_engine(dst, to_device ? ec.gpu : ec.cpu, src, to_device ? ec.cpu : ec.gpu, bytes,
+                                                         0, nullptr, slot_sig,
+                                                         (hsa_amd_sdma_engine_id_t)(to_device ? ec.eng_in : ec.eng_out), true);
+  if (st != HSA_STATUS_SUCCESS) { hsa_signal_store_relaxed(slot_sig, 0); return false; }
+  return true;
+}
+
+static void engine_wait(hsa_signal_t sig)
+{
+  while (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) { }
+}
+
+// One chunk through the host entry point = SURVEY 8(d)'s timed region: H2D of the reads, kernels, D2H
+// of the hits.  The chunk is cut into sub-batches of contiguous reads that flow through two slots:
+// while sub-batch i is on the compute stream, the copy engines bring in i + 1 and take out i - 1
+// (PCIe is full duplex), so a chunk costs about max(bytes in, bytes out) / link rate.  Reads that
+// the caller keeps in pinned memory (psigpu_host_alloc) are copied in place; pageable reads are
+// staged through pinned buffers by a helper thread that runs ahead of the compute loop.  With
+// PSIGPU_SORT_UNIQUE every sub-batch is sorted on the device; sub-batches are contiguous read
+// ranges, so their concatenation is the sorted chunk.
 int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off, uint64_t n_reads,
                       uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, psigpu_hits* out)
 {
@@ -3194,27 +3466,247 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   out->n = 0; out->data = nullptr;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if ((flags & PSIGPU_ALL) == 0) flags |= PSIGPU_ALL;
-  uint64_t n_bases = n_reads ? read_off[n_reads] : 0;
+  const bool want_sort = (flags & PSIGPU_SORT_UNIQUE) != 0;
+  flags &= ~PSIGPU_SORT_UNIQUE;
+  const uint64_t n_bases = n_reads ? read_off[n_reads] : 0;
   if (n_reads && read_off[0] != 0) { ctx->err = "read_off[0] must be 0"; return PSIGPU_ERR_ARG; }
-  HIPCHK(ctx, ctx->w_bases.ensure(n_bases + 64));
-  HIPCHK(ctx, ctx->w_read_off.ensure((n_reads + 1) * 8));
-  if (n_bases) HIPCHK(ctx, hipMemcpy(ctx->w_bases.p, bases, n_bases, hipMemcpyHostToDevice));
-  if (n_reads) HIPCHK(ctx, hipMemcpy(ctx->w_read_off.p, read_off, (n_reads + 1) * 8, hipMemcpyHostToDevice));
-  uint64_t n = 0;
-  int st = run_pipeline(ctx, ctx->w_bases.as<char>(), ctx->w_read_off.as<uint64_t>(), n_reads, n_bases, k, step,
-                        rec_offset, flags & ~PSIGPU_SORT_UNIQUE, nullptr, &n);
-  if (st != PSIGPU_OK) return st;
-  if (n) {
-    void* hp = g_pinned.get(n * sizeof(psigpu_hit));
-    if (!hp) { ctx->err = "cannot allocate pinned host memory for the hits"; return PSIGPU_ERR_NOMEM; }
-    hipError_t e = hipMemcpy(hp, ctx->w_hits.p, n * sizeof(psigpu_hit), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { g_pinned.put(hp); ctx->err = hipGetErrorString(e); return PSIGPU_ERR_DEVICE; }
-    psigpu_hit* hh = (psigpu_hit*)hp;
-    if (flags & PSIGPU_SORT_UNIQUE) n = sort_unique_hits(hh, n);
-    out->data = hh;
-    out->n = n;
-    ctx->last.n_hits = n;
+  if (n_bases && !bases) return PSIGPU_ERR_ARG;
+  if (n_reads == 0) {                 // nothing to copy either way; the counters of the call are still set
+    uint64_t n = 0;
+    return run_pipeline(ctx, nullptr, nullptr, 0, 0, k, step, rec_offset, flags, nullptr, &n);
   }
+
+  // sub-batches: cut at read boundaries; the first ones are small and double up to SUB_BYTES of bases, so
+  // that the copy-out stream -- the longest stage -- starts early (what precedes its first transfer is
+  // the one part of the call nothing overlaps with)
+  // (PSIGPU_SUB_BYTES: tests force many sub-batches on small inputs)
+  const char* sub_env = getenv("PSIGPU_SUB_BYTES");
+  const uint64_t SUB_BYTES = sub_env ? std::max<uint64_t>(1, strtoull(sub_env, nullptr, 10)) : (16ull << 20);
+  std::vector<uint64_t> cut{ 0 };
+  {
+    uint64_t piece = std::max<uint64_t>(1, std::min<uint64_t>(SUB_BYTES, std::max<uint64_t>(SUB_BYTES / 8, 1)));
+    uint64_t target = 0;
+    while (cut.back() < n_reads) {
+      target += piece;
+      uint64_t r = target >= n_bases ? n_reads : (uint64_t)(std::lower_bound(read_off, read_off + n_reads, target) - read_off);
+      if (r <= cut.back()) r = cut.back() + 1;            // at least one read per sub-batch
+      if (n_bases - read_off[r] < piece / 4) r = n_reads; // no tiny tail
+      cut.push_back(r);
+      piece = std::min(SUB_BYTES, piece * 2);
+    }
+  }
+  const size_t n_sub = cut.size() - 1;
+  const bool pinned_in = n_bases == 0 || host_ptr_is_pinned(bases);
+  { int st = pipeline_init(ctx); if (st != PSIGPU_OK) return st; }
+
+  std::function<void(int)> trace_in;
+  // staging of sub-batch j into slot j % 2 and its H2D on the copy-in stream
+  auto stage_in = [&](size_t j) -> hipError_t {
+    psigpu_ctx::Slot& sl = ctx->slot[j & 1];
+    const uint64_t r0 = cut[j], r1 = cut[j + 1], nr = r1 - r0;
+    const uint64_t b0 = read_off[r0], nb = read_off[r1] - b0;
+    const size_t off_bytes = ((nr + 1) * 8 + 255) & ~(size_t)255;
+    const size_t need = off_bytes + (pinned_in ? 0 : nb);
+    if (need > sl.h_cap) {
+      if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+      sl.h_stage = nullptr; sl.h_cap = 0;
+      hipError_t e = hipHostMalloc(&sl.h_stage, need + need / 4 + 4096, hipHostMallocMapped);
+      if (e == hipSuccess) e = hipHostGetDevicePointer(&sl.h_stage_dev, sl.h_stage, 0);
+      if (e != hipSuccess) return e;
+      sl.h_cap = need + need / 4 + 4096;
+    }
+    hipError_t e = sl.bases.ensure(nb + 64);
+    if (e == hipSuccess) e = sl.off.ensure((nr + 1) * 8);
+    if (e != hipSuccess) return e;
+    uint64_t* ho = reinterpret_cast<uint64_t*>(sl.h_stage);
+    for (uint64_t r = 0; r <= nr; ++r) ho[r] = read_off[r0 + r] - b0;
+    const char* src = bases + b0;
+    if (!pinned_in && nb) { parallel_copy((char*)sl.h_stage + off_bytes, src, nb); src = (char*)sl.h_stage + off_bytes; }
+    // one transfer per sub-batch (the read offsets reach the device through k_publish from this
+    // mapped staging buffer)
+    if (trace_in) trace_in(0);
+    if (ctx->ec.ok) {
+      if (nb == 0) hsa_signal_store_relaxed(ctx->ec.sig_in[j & 1], 0);
+      else if (!engine_copy(ctx, true, sl.bases.p, src, nb, ctx->ec.sig_in[j & 1])) return hipErrorUnknown;
+    } else {
+      if (nb) e = hipMemcpyAsync(sl.bases.p, src, nb, hipMemcpyHostToDevice, ctx->s_in);
+      if (e == hipSuccess) e = hipEventRecord(sl.in_ready, ctx->s_in);
+    }
+    if (trace_in) trace_in(1);
+    return e;
+  };
+
+  // Pageable input: a helper thread stages ahead of the compute loop (its memcpy would otherwise sit
+  // between the kernels and the D2H of every sub-batch).  staged = sub-batches enqueued so far,
+  // consumed = sub-batches whose kernels have finished (their slot may be overwritten).
+  std::atomic<size_t> staged{ 0 }, consumed{ 0 };
+  std::atomic<int> stage_err{ (int)hipSuccess };
+  std::atomic<bool> stop{ false };
+  std::thread stager;
+  const bool use_thread = !pinned_in && n_sub > 1;
+  if (use_thread) {
+    stager = std::thread([&] {
+      if (hipSetDevice(ctx->device) != hipSuccess) { stage_err = (int)hipErrorInvalidDevice; return; }
+      for (size_t j = 0; j < n_sub && !stop; ++j) {
+        while (j >= consumed.load(std::memory_order_acquire) + 2 && !stop) std::this_thread::yield();
+        if (stop) break;
+        hipError_t e = stage_in(j);
+        if (e != hipSuccess) { stage_err = (int)e; return; }
+        staged.store(j + 1, std::memory_order_release);
+      }
+    });
+  }
+  struct Joiner {
+    std::thread& t; std::atomic<bool>& stop;
+    ~Joiner() { stop = true; if (t.joinable()) t.join(); }
+  } joiner{ stager, stop };
+
+  // output: pinned, sized from what earlier calls produced per read; regrown when a chunk has more
+  uint64_t out_cap = 0, done = 0;
+  psigpu_hit* hp = nullptr;
+  auto fail = [&](int st) {
+    if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }      // transfers into hp still in flight
+    else if (ctx->s_out) (void)hipStreamSynchronize(ctx->s_out);
+    if (hp) g_pinned.put(hp);
+    hp = nullptr;
+    return st;
+  };
+  auto out_reserve = [&](uint64_t want_records) -> int {
+    if (want_records <= out_cap) return PSIGPU_OK;
+    if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }
+    else HIPCHK(ctx, hipStreamSynchronize(ctx->s_out));
+    const uint64_t cap2 = want_records + want_records / 4 + 4096;
+    psigpu_hit* np = (psigpu_hit*)g_pinned.get(cap2 * sizeof(psigpu_hit));
+    if (!np) { ctx->err = "cannot allocate pinned host memory for the hits"; return PSIGPU_ERR_NOMEM; }
+    if (hp) { memcpy(np, hp, done * sizeof(psigpu_hit)); g_pinned.put(hp); }
+    hp = np; out_cap = cap2;
+    return PSIGPU_OK;
+  };
+  {
+    const double ratio = ctx->hits_per_read_hint > 0 ? ctx->hits_per_read_hint * 1.1 : 10.0;
+    int st = out_reserve((uint64_t)(ratio * (double)n_reads) + 1024);
+    if (st != PSIGPU_OK) return st;
+  }
+
+  psigpu_counters acc{};
+  const bool trace = getenv("PSIGPU_TRACE") != nullptr;        // per-sub-batch host timeline on stderr
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_call = now_ms();
+  std::vector<double> tr;
+  // device-side timeline (trace mode): events around every H2D, kernel phase and D2H
+  std::vector<hipEvent_t> tev;
+  hipEvent_t tev0 = nullptr;
+  auto tmark = [&](hipStream_t st_) { if (!trace || ctx->ec.ok) return; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st_); tev.push_back(e); };
+  std::vector<hipEvent_t> tin;
+  if (trace) {
+    (void)hipEventCreate(&tev0); (void)hipEventRecord(tev0, ctx->s_comp);
+    if (!ctx->ec.ok) trace_in = [&](int) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, ctx->s_in); tin.push_back(e); };
+  }
+  bool host_sort = false;            // some sub-batch did not fit the device sorter's key
+  hipStream_t sc = ctx->s_comp;
+  if (!use_thread) {
+    hipError_t e = stage_in(0);
+    if (e != hipSuccess) { ctx->err = std::string("staging the reads: ") + hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
+  }
+  for (size_t i = 0; i < n_sub; ++i) {
+    psigpu_ctx::Slot& sl = ctx->slot[i & 1];
+    if (use_thread) {
+      while (staged.load(std::memory_order_acquire) <= i && stage_err.load() == (int)hipSuccess) std::this_thread::yield();
+      if (stage_err.load() != (int)hipSuccess) {
+        ctx->err = std::string("staging the reads: ") + hipGetErrorString((hipError_t)stage_err.load());
+        return fail(PSIGPU_ERR_DEVICE);
+      }
+    } else if (i + 1 < n_sub) {
+      hipError_t e = stage_in(i + 1);           // slot (i + 1) & 1: its last user, sub-batch i - 1, has been synchronised
+      if (e != hipSuccess) { ctx->err = std::string("staging the reads: ") + hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
+    }
+    const uint64_t r0 = cut[i], nr = cut[i + 1] - r0, nb = read_off[cut[i + 1]] - read_off[r0];
+    if (ctx->ec.ok) {
+      engine_wait(ctx->ec.sig_in[i & 1]);
+      if (i >= 2) engine_wait(ctx->ec.sig_out[i & 1]);    // the hit buffer about to be written was the source of the D2H two sub-batches ago
+    } else {
+      if (hipStreamWaitEvent(sc, sl.in_ready, 0) != hipSuccess) { ctx->err = "hipStreamWaitEvent"; return fail(PSIGPU_ERR_DEVICE); }
+      if (i >= 2 && hipStreamWaitEvent(sc, sl.out_done, 0) != hipSuccess) { ctx->err = "hipStreamWaitEvent"; return fail(PSIGPU_ERR_DEVICE); }
+    }
+    uint64_t n = 0;
+    if (trace) { tr.push_back(now_ms() - t_call); tmark(sc); }
+    k_publish<<<64, 256, 0, sc>>>(reinterpret_cast<const uint4*>(sl.h_stage_dev), sl.off.as<uint4>(), (uint32_t)(((nr + 1) * 8 + 15) / 16));
+    int st = run_pipeline(ctx, sl.bases.as<char>(), sl.off.as<uint64_t>(), nr, nb, k, step, rec_offset + r0, flags, sc, &n);
+    if (st != PSIGPU_OK) return fail(st);
+    if (trace) tr.push_back(now_ms() - t_call);
+    consumed.store(i + 1, std::memory_order_release);
+    const psigpu_counters pc = ctx->last;
+    const psigpu_hit* src = ctx->w_hits.as<psigpu_hit>();
+    float ms_sort = 0.f;
+    if (want_sort && !host_sort && n) {
+      uint64_t nu = 0;
+      st = device_sort_unique(ctx, n, nr, rec_offset + r0, ctx->w_sorted[i & 1], sc, &nu);
+      if (st == PSIGPU_ERR_FORMAT) host_sort = true;
+      else if (st != PSIGPU_OK) return fail(st);
+      else { n = nu; src = ctx->w_sorted[i & 1].as<psigpu_hit>(); ms_sort = ctx->last.ms_sort; }
+    }
+    if (n) {
+      // extrapolate from the reads seen so far when the reservation turns out too small
+      if (done + n > out_cap) {
+        const double per_read = (double)(done + n) / (double)(cut[i + 1]);
+        st = out_reserve(std::max<uint64_t>(done + n, (uint64_t)(per_read * 1.1 * (double)n_reads) + 1024));
+        if (st != PSIGPU_OK) return fail(st);
+      }
+      if (trace) { tr.push_back(now_ms() - t_call); tmark(sc); tmark(ctx->s_out); }
+      hipError_t e = hipSuccess;
+      if (ctx->ec.ok) {
+        if (!engine_copy(ctx, false, hp + done, src, n * sizeof(psigpu_hit), ctx->ec.sig_out[i & 1])) e = hipErrorUnknown;
+      } else {
+        e = hipMemcpyAsync(hp + done, src, n * sizeof(psigpu_hit), hipMemcpyDeviceToHost, ctx->s_out);
+        if (e == hipSuccess) e = hipEventRecord(sl.out_done, ctx->s_out);
+      }
+      if (trace) { tr.push_back(now_ms() - t_call); tmark(ctx->s_out); }
+      if (e != hipSuccess) { ctx->err = std::string("copying the hits out: ") + hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
+      done += n;
+    } else if (ctx->ec.ok) hsa_signal_store_relaxed(ctx->ec.sig_out[i & 1], 0);
+    else if (hipEventRecord(sl.out_done, ctx->s_out) != hipSuccess) { ctx->err = "hipEventRecord"; return fail(PSIGPU_ERR_DEVICE); }
+    if (src == ctx->w_hits.as<psigpu_hit>()) std::swap(ctx->w_hits, ctx->w_hits_alt);    // the next sub-batch writes the other buffer
+    // counters of the chunk = sums over its sub-batches
+    acc.n_reads += pc.n_reads; acc.n_seeds += pc.n_seeds; acc.n_seeds_valid += pc.n_seeds_valid;
+    acc.n_seeds_on_path += pc.n_seeds_on_path; acc.n_hits_on_path += pc.n_hits_on_path;
+    acc.n_hits_off_path += pc.n_hits_off_path; acc.n_kpaths += pc.n_kpaths; acc.n_spilled += pc.n_spilled;
+    acc.n_lf_steps += pc.n_lf_steps; acc.n_rows_verified += pc.n_rows_verified;
+    acc.n_loci = pc.n_loci; acc.n_locus_kmers = pc.n_locus_kmers; acc.n_path_kmers = pc.n_path_kmers;
+    acc.n_loci_traversed = pc.n_loci_traversed; acc.ms_locus_table_build = pc.ms_locus_table_build;
+    acc.ms_pack += pc.ms_pack; acc.ms_table += pc.ms_table; acc.ms_search += pc.ms_search; acc.ms_locate += pc.ms_locate;
+    acc.ms_traverse += pc.ms_traverse; acc.ms_probe += pc.ms_probe; acc.ms_total += pc.ms_total + ms_sort; acc.ms_sort += ms_sort;
+    acc.search_launches += pc.search_launches; acc.traverse_launches += pc.traverse_launches;
+  }
+  if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }
+  else if (hipStreamSynchronize(ctx->s_out) != hipSuccess) { ctx->err = "hipStreamSynchronize (copy-out stream)"; return fail(PSIGPU_ERR_DEVICE); }
+  if (trace) {
+    fprintf(stderr, "[psigpu] host entry: %zu sub-batches, %.3f ms; per sub-batch (ms since call): pipeline begin, end, D2H enqueue begin, end\n", n_sub, now_ms() - t_call);
+    for (size_t j = 0; j + 3 < tr.size(); j += 4) fprintf(stderr, "[psigpu]   %.3f %.3f %.3f %.3f\n", tr[j], tr[j + 1], tr[j + 2], tr[j + 3]);
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "[psigpu] device timeline (ms since call): kernels begin, kernels end, D2H begin, D2H end\n");
+    for (size_t j = 0; j + 3 < tev.size(); j += 4) {
+      float a = 0, b = 0, c = 0, d = 0;
+      (void)hipEventElapsedTime(&a, tev0, tev[j]); (void)hipEventElapsedTime(&b, tev0, tev[j + 1]);
+      (void)hipEventElapsedTime(&c, tev0, tev[j + 2]); (void)hipEventElapsedTime(&d, tev0, tev[j + 3]);
+      fprintf(stderr, "[psigpu]   %.3f %.3f %.3f %.3f\n", a, b, c, d);
+    }
+    fprintf(stderr, "[psigpu] H2D (ms since call): begin, end\n");
+    for (size_t j = 0; j + 1 < tin.size(); j += 2) {
+      float a = 0, b = 0;
+      (void)hipEventElapsedTime(&a, tev0, tin[j]); (void)hipEventElapsedTime(&b, tev0, tin[j + 1]);
+      fprintf(stderr, "[psigpu]   %.3f %.3f\n", a, b);
+    }
+    for (auto e : tev) (void)hipEventDestroy(e);
+    for (auto e : tin) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(tev0);
+  }
+  if (want_sort && host_sort && done) done = sort_unique_hits(hp, done);      // records wider than the device key
+  if (n_reads) ctx->hits_per_read_hint = std::max(ctx->hits_per_read_hint * 0.9, (double)done / (double)n_reads);
+  acc.n_hits = done;
+  ctx->last = acc;
+  if (done == 0) { if (hp) g_pinned.put(hp); hp = nullptr; }
+  out->data = hp;
+  out->n = done;
   return PSIGPU_OK;
 }
 

@@ -76,8 +76,26 @@ int gpu_find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_
 int gpu_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, uint64_t n,
                        unsigned end_bit, std::string* err);
 
-// hits.cpp: parallel sort-unique of hit records by (read_id, read_offset, node_id, node_offset)
+// hits.cpp: parallel sort-unique of hit records by (read_id, read_offset, node_id, node_offset) on the
+// host: only for records that do not fit the device sorter's 64-bit key (HitSorter::fits)
 uint64_t sort_unique_hits(psigpu_hit* hits, uint64_t n);
+
+// hits_gpu.hip: the same on the device -- records packed into 64-bit keys, radix sort, unique, expand
+struct HitSorter {
+  void* keys_a = nullptr; void* keys_b = nullptr; void* tmp = nullptr;
+  uint64_t cap = 0; size_t tmp_cap = 0;
+  HitSorter() = default;
+  HitSorter(const HitSorter&) = delete;
+  HitSorter& operator=(const HitSorter&) = delete;
+  ~HitSorter();
+  // can a hit of this chunk / graph be packed into one 64-bit key?
+  static bool fits(uint64_t n_reads, uint64_t max_read_len, uint64_t n_nodes, uint64_t max_node_len);
+  // d_in[0..n) -> d_out[0..*d_count) sorted and unique; asynchronous on `stream` (a hipStream_t);
+  // d_count is a device pointer.  Read ids lie in [rec_offset, rec_offset + n_reads).
+  int run(const psigpu_hit* d_in, uint64_t n, uint64_t rec_offset, uint64_t n_reads, uint64_t max_read_len,
+          uint64_t n_nodes, uint64_t max_node_len, bool id_affine, uint64_t id_base, const uint64_t* d_ids_sorted,
+          psigpu_hit* d_out, uint64_t* d_count, void* stream, std::string* err);
+};
 Index* load_index(const std::string& prefix, int* status);
 
 }  // namespace psigpu

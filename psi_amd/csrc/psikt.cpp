@@ -5,15 +5,18 @@
 // psi::SeedFinder shim (psi_amd/include/psi/seed_finder.hpp) and, through it, the HIP kernels.
 // Argument parsing, logging and I/O are plain C++; SeqAn's ArgumentParser / spdlog are not used.
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
-#include <unordered_set>
+#include <thread>
 #include <vector>
 
 #include <psi/seed_finder.hpp>
@@ -174,6 +177,64 @@ Options parse_args( int argc, char** argv )
   return o;
 }
 
+/* Writes hit arrays in the order they are pushed, on its own thread; owns them until written. */
+class HitWriter {
+public:
+  explicit HitWriter( FILE* f ) : out_( f ), th_( [ this ] { loop(); } ) {}
+  ~HitWriter() { finish(); }
+  void push( psigpu_hits h )
+  {
+    std::unique_lock< std::mutex > lk( mu_ );
+    cv_.wait( lk, [ this ] { return q_.size() < 2; } );      /* at most two chunks of hits in flight */
+    q_.push_back( h );
+    cv_.notify_all();
+  }
+  bool finish()
+  {
+    {
+      std::lock_guard< std::mutex > lk( mu_ );
+      if ( done_ ) return ok_;
+      done_ = true;
+      cv_.notify_all();
+    }
+    th_.join();
+    return ok_;
+  }
+private:
+  void loop()
+  {
+    while ( true ) {
+      psigpu_hits h;
+      {
+        std::unique_lock< std::mutex > lk( mu_ );
+        cv_.wait( lk, [ this ] { return !q_.empty() || done_; } );
+        if ( q_.empty() ) return;
+        h = q_.front();
+      }
+      if ( h.n && fwrite( h.data, sizeof( psigpu_hit ), h.n, out_ ) != h.n ) ok_ = false;
+      psigpu_free_hits( &h );
+      std::lock_guard< std::mutex > lk( mu_ );
+      q_.pop_front();
+      cv_.notify_all();
+    }
+  }
+  FILE* out_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque< psigpu_hits > q_;
+  bool done_ = false, ok_ = true;
+  std::thread th_;
+};
+
+/* distinct read ids in an array sorted by read id */
+unsigned long long count_covered_reads( psigpu_hits const& h )
+{
+  unsigned long long n = h.n ? 1 : 0;
+#pragma omp parallel for reduction( + : n ) schedule( static )
+  for ( long long i = 1; i < (long long)h.n; ++i ) n += h.data[ i ].read_id != h.data[ i - 1 ].read_id;
+  return n;
+}
+
 double seconds_since( std::chrono::steady_clock::time_point t0 )
 {
   return std::chrono::duration< double >( std::chrono::steady_clock::now() - t0 ).count();
@@ -223,14 +284,12 @@ int run( Options const& o, Logger& log )
     return 0;
   }
 
-  unsigned long long found = 0;
-  std::unordered_set< std::uint64_t > covered_reads;
-  finder_type::callback_type write_callback = [ & ]( finder_type::output_type const& hit ) {
-    ++found;                                           // 4 x native-endian u64 (src/psikt.cpp:176-179)
-    std::uint64_t rec[ 4 ] = { hit.node_id, hit.node_offset, hit.read_id, hit.read_offset };
-    fwrite( rec, sizeof rec, 1, out );
-    covered_reads.insert( hit.read_id );
-  };
+  /* The reference's write_callback (src/psikt.cpp:172-181) appends one 32-byte record per hit:
+   * 4 x native-endian u64 = the layout of psigpu_hit, so a chunk's hits are ONE fwrite.  It runs on
+   * a writer thread while the device answers the next chunk.  Hits arrive sorted by read id, so
+   * the reads covered are the changes of read id along the array. */
+  unsigned long long found = 0, covered = 0;
+  HitWriter writer( out );
 
   auto chunk = finder.create_readrecord();
   SeedsRecord seeds;
@@ -247,17 +306,21 @@ int run( Options const& o, Logger& log )
     finder.get_seeds( seeds, chunk, o.distance );
     auto seeds_index = finder.index_reads( seeds );
     log.info( "Finding all seeds..." );
-    finder.seeds_all( seeds, seeds_index, traverser, write_callback );
+    psigpu_hits hits = finder.seeds_all_hits( seeds, seeds_index, traverser );
+    found += hits.n;
+    covered += count_covered_reads( hits );
+    writer.push( hits );                               // takes ownership, frees after writing
     auto st = finder.get_stats();
     t_device += st.ms_total * 1e-3;
     log.info( "Found seeds on paths: " + std::to_string( st.n_hits_on_path ) + ", off paths: " +
               std::to_string( st.n_hits_off_path ) + " (raw), device time " + std::to_string( st.ms_total ) + " ms." );
   }
+  if ( !writer.finish() ) throw std::runtime_error( "cannot write to '" + o.output_path + "'" );
   fclose( out );
   log.info( "Found seed in " + std::to_string( seconds_since( t_all ) ) + " s (" + std::to_string( t_device ) +
             " s on the device)." );
   log.info( "Total number of seeds found: " + std::to_string( found ) );            // src/psikt.cpp:59-80
-  log.info( "Number of reads covered: " + std::to_string( covered_reads.size() ) );
+  log.info( "Number of reads covered: " + std::to_string( covered ) );
   return 0;
 }
 

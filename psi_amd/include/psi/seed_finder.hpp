@@ -153,6 +153,15 @@ namespace psi {
       run( seeds, PSIGPU_ALL, callback );
     }
 
+    /** seeds_all without the per-hit callback: the chunk's sort-unique hits as one array of 32-byte
+     *  records in library-owned pinned memory (release with psigpu_free_hits).  No counterpart in
+     *  the reference; psikt uses it to write a chunk with one fwrite. */
+    psigpu_hits seeds_all_hits( SeedsRecord const& seeds, readsindex_type& index, traverser_type& traverser ) const
+    {
+      setup_traverser( traverser, seeds, index );
+      return find( seeds, PSIGPU_ALL );
+    }
+
     /** seeds_all with one callback per phase (reference :1734-1743). */
     void seeds_all( SeedsRecord const& seeds, readsindex_type& index, traverser_type& traverser,
                     callback_type callback1, callback_type callback2 ) const
@@ -194,13 +203,19 @@ namespace psi {
     void check( int st ) const
     { if ( st != PSIGPU_OK ) throw std::runtime_error( psigpu_last_error( ctx ) ); }
 
-    void run( SeedsRecord const& seeds, unsigned int flags, callback_type const& callback ) const
+    psigpu_hits find( SeedsRecord const& seeds, unsigned int flags ) const
     {
       if ( seeds.chunk == nullptr ) throw std::runtime_error( "get_seeds() has not been called" );
       Records const& c = *seeds.chunk;
       psigpu_hits hits{};
       check( psigpu_find_seeds( ctx, c.bases.data(), c.offsets.data(), c.size(), seeds.seed_len,
                                 seeds.distance, c.get_record_offset(), flags | PSIGPU_SORT_UNIQUE, &hits ) );
+      return hits;
+    }
+
+    void run( SeedsRecord const& seeds, unsigned int flags, callback_type const& callback ) const
+    {
+      psigpu_hits hits = find( seeds, flags );
       output_type h{};
       h.match_len = seeds.seed_len;
       h.gocc = 0;

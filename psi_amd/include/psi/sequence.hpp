@@ -2,22 +2,75 @@
 // Mirrors the parts of reference include/psi/sequence.hpp the seed-finding loop touches:
 // Records (name/str, record offset :1130-1294), readRecords (:1590-1624).  FASTQ (optionally
 // gzip'd) or one-sequence-per-line text; kseq++ / SeqAn are not used.
+//
+// The bases of a chunk live in page-locked memory (psigpu_host_alloc): the copy engine of the GPU
+// reads them in place, psigpu_find_seeds does not stage them.
 #ifndef PSI_AMD_SEQUENCE_HPP__
 #define PSI_AMD_SEQUENCE_HPP__
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "psi_gpu.h"
+
 namespace psi {
+  /** Grow-only byte buffer in pinned host memory (plain malloc when there is no GPU runtime:
+   *  the finder itself still refuses to run without one). */
+  class PinnedChars {
+  public:
+    PinnedChars() = default;
+    PinnedChars( PinnedChars const& ) = delete;
+    PinnedChars& operator=( PinnedChars const& ) = delete;
+    ~PinnedChars() { release(); }
+    char const* data() const { return p_; }
+    char* data() { return p_; }
+    std::size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    void clear() { n_ = 0; }
+    void append( char const* s, std::size_t len )
+    {
+      if ( n_ + len > cap_ ) grow( n_ + len );
+      std::memcpy( p_ + n_, s, len );
+      n_ += len;
+    }
+    PinnedChars& operator+=( std::string const& s ) { append( s.data(), s.size() ); return *this; }
+    std::string substr( std::size_t pos, std::size_t len ) const { return std::string( p_ + pos, len ); }
+  private:
+    void grow( std::size_t want )
+    {
+      std::size_t cap = cap_ ? cap_ : ( 1u << 20 );
+      while ( cap < want ) cap *= 2;
+      bool pinned = true;
+      char* q = static_cast< char* >( psigpu_host_alloc( cap ) );
+      if ( q == nullptr ) { q = static_cast< char* >( std::malloc( cap ) ); pinned = false; }
+      if ( q == nullptr ) throw std::bad_alloc();
+      if ( n_ ) std::memcpy( q, p_, n_ );
+      release();
+      p_ = q; cap_ = cap; pinned_ = pinned;
+    }
+    void release()
+    {
+      if ( p_ == nullptr ) return;
+      if ( pinned_ ) psigpu_host_free( p_ ); else std::free( p_ );
+      p_ = nullptr; cap_ = 0;
+    }
+    char* p_ = nullptr;
+    std::size_t n_ = 0, cap_ = 0;
+    bool pinned_ = false;
+  };
+
   /** A set of reads stored back to back (what the device consumes) plus their names. */
   class Records {
   public:
     std::vector< std::string > name;
-    std::string bases;                       /**< concatenated sequences */
+    PinnedChars bases;                         /**< concatenated sequences */
     std::vector< std::uint64_t > offsets{ 0 }; /**< size()+1 offsets into bases */
 
     std::size_t size() const { return offsets.size() - 1; }
@@ -31,16 +84,23 @@ namespace psi {
       bases += s;
       offsets.push_back( bases.size() );
     }
+    void push_back( char const* n, std::size_t nlen, char const* s, std::size_t slen )
+    {
+      name.emplace_back( n, nlen );
+      bases.append( s, slen );
+      offsets.push_back( bases.size() );
+    }
     std::string operator[]( std::size_t i ) const
     { return bases.substr( offsets[ i ], offsets[ i + 1 ] - offsets[ i ] ); }
   private:
     std::uint64_t rec_offset = 0;
   };
 
-  /** Sequence input stream: counts the records handed out so far (kseq++'s `counts()`). */
+  /** Sequence input stream: counts the records handed out so far (kseq++'s `counts()`).
+   *  The file is inflated in 4-MiB blocks and lines are cut in place. */
   class SeqStreamIn {
   public:
-    explicit SeqStreamIn( std::string const& path )
+    explicit SeqStreamIn( std::string const& path ) : buf_( BLOCK + 1 )
     {
       gz_ = gzopen( path.c_str(), "rb" );
       if ( gz_ == nullptr ) throw std::runtime_error( "cannot open file '" + path + "'" );
@@ -53,44 +113,87 @@ namespace psi {
     /** Next record; false at end of input. */
     bool next( std::string& name, std::string& seq )
     {
-      std::string line;
-      while ( getline( line ) ) {
-        if ( line.empty() ) continue;
-        if ( line[0] == '@' ) {                 /* FASTQ */
-          name = line.substr( 1, line.find_first_of( " \t" ) - 1 );
-          std::string plus, qual;
-          if ( !getline( seq ) ) throw std::runtime_error( "truncated FASTQ record" );
-          if ( !getline( plus ) || !getline( qual ) ) throw std::runtime_error( "truncated FASTQ record" );
-        } else if ( line[0] == '>' ) {          /* FASTA, single-line records */
-          name = line.substr( 1, line.find_first_of( " \t" ) - 1 );
-          if ( !getline( seq ) ) throw std::runtime_error( "truncated FASTA record" );
-        } else {                                /* plain text */
-          name = std::to_string( count_ );
-          seq = line;
+      char const *n, *s; std::size_t nl, sl;
+      if ( !next_view( n, nl, s, sl ) ) return false;
+      name.assign( n, nl ); seq.assign( s, sl );
+      return true;
+    }
+
+    /** Next record appended to `records` without intermediate strings. */
+    bool next_into( Records& records )
+    {
+      char const *n, *s; std::size_t nl, sl;
+      if ( !next_view( n, nl, s, sl ) ) return false;
+      records.push_back( n, nl, s, sl );
+      return true;
+    }
+  private:
+    static constexpr std::size_t BLOCK = 4u << 20;
+
+    /* Views stay valid until the next call.  `keep` is where the current record starts in the
+     * block buffer: line() preserves everything from there on when it refills, and positions
+     * inside the record are held relative to it. */
+    bool next_view( char const*& name, std::size_t& nlen, char const*& seq, std::size_t& slen )
+    {
+      while ( true ) {
+        std::size_t keep = pos_, lo, ll;
+        if ( !line( lo, ll, keep ) ) return false;
+        if ( ll == 0 ) continue;
+        char const first = buf_[ lo ];
+        if ( first == '@' || first == '>' ) {
+          bool const fq = first == '@';
+          std::size_t name_len = 0;
+          while ( 1 + name_len < ll && buf_[ lo + 1 + name_len ] != ' ' && buf_[ lo + 1 + name_len ] != '\t' ) ++name_len;
+          std::size_t const name_rel = lo + 1 - keep;
+          std::size_t so, sl, to, tl;
+          if ( !line( so, sl, keep ) ) throw std::runtime_error( fq ? "truncated FASTQ record" : "truncated FASTA record" );
+          std::size_t const seq_rel = so - keep;
+          if ( fq && ( !line( to, tl, keep ) || !line( to, tl, keep ) ) ) throw std::runtime_error( "truncated FASTQ record" );
+          name = buf_.data() + keep + name_rel; nlen = name_len;
+          seq = buf_.data() + keep + seq_rel; slen = sl;
+        } else {                                    /* plain text: one sequence per line */
+          tmp_name_ = std::to_string( count_ );
+          name = tmp_name_.data(); nlen = tmp_name_.size();
+          seq = buf_.data() + lo; slen = ll;
         }
         ++count_;
         return true;
       }
-      return false;
     }
-  private:
-    bool getline( std::string& out )
+
+    /* Offset and length of the next line (terminator stripped).  Refilling moves [keep, end) to
+     * the front of the buffer and sets keep to 0. */
+    bool line( std::size_t& off, std::size_t& len, std::size_t& keep )
     {
-      out.clear();
-      char buf[ 4096 ];
-      bool any = false;
-      while ( gzgets( gz_, buf, sizeof buf ) != nullptr ) {
-        any = true;
-        out += buf;
-        if ( !out.empty() && out.back() == '\n' ) {
-          out.pop_back();
-          if ( !out.empty() && out.back() == '\r' ) out.pop_back();
+      while ( true ) {
+        char* base = buf_.data();
+        char* nl = end_ > pos_ ? static_cast< char* >( std::memchr( base + pos_, '\n', end_ - pos_ ) ) : nullptr;
+        if ( nl != nullptr || ( eof_ && pos_ < end_ ) ) {
+          std::size_t const stop = nl ? static_cast< std::size_t >( nl - base ) : end_;
+          off = pos_;
+          len = stop - pos_;
+          pos_ = nl ? stop + 1 : end_;
+          if ( len && base[ off + len - 1 ] == '\r' ) --len;
           return true;
         }
+        if ( eof_ ) return false;
+        if ( keep ) {
+          std::memmove( base, base + keep, end_ - keep );
+          pos_ -= keep; end_ -= keep; keep = 0;
+        }
+        if ( buf_.size() - end_ < BLOCK / 2 ) { buf_.resize( buf_.size() * 2 ); base = buf_.data(); }
+        int got = gzread( gz_, base + end_, static_cast< unsigned >( std::min< std::size_t >( buf_.size() - end_, 1u << 30 ) ) );
+        if ( got < 0 ) throw std::runtime_error( "read error" );
+        if ( got == 0 ) eof_ = true;
+        end_ += static_cast< std::size_t >( got );
       }
-      return any;
     }
+
     gzFile gz_ = nullptr;
+    std::vector< char > buf_;
+    std::size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+    std::string tmp_name_;
     std::uint64_t count_ = 0;
   };
 
@@ -104,9 +207,7 @@ namespace psi {
   {
     records.clear();
     records.set_record_offset( iss.counts() );
-    std::string name, seq;
-    while ( ( num == 0 || records.size() < num ) && iss.next( name, seq ) )
-      records.push_back( name, seq );
+    while ( ( num == 0 || records.size() < num ) && iss.next_into( records ) ) { }
     return records.size() != 0;
   }
 }  /* --- end of namespace psi --- */

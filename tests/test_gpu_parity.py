@@ -417,12 +417,7 @@ def test_device_resident_entry_matches_host_entry():
                                 step=k, rec_offset=77, stream=stream)
     c = f.counters()
     assert n == c['n_hits'] and c['ms_total'] > 0
-    import ctypes
-    out = np.zeros((n, 4), np.uint64)
-    hip = ctypes.CDLL('libamdhip64.so')
-    assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr),
-                         ctypes.c_size_t(n * 32), 2) == 0
-    assert _eq(psi_amd.sort_unique(out), host)
+    assert _eq(psi_amd.sort_unique(f.copy_hits(ptr, n)), host)
     f.close()
 
 
@@ -635,3 +630,88 @@ def test_regression_all_t_31mer_with_an_ext_record(query_mode):
         got = psi_amd.sort_unique(f.seeds_all(reads, step=step))
         assert _eq(got, want), cap
         f.close()
+
+
+# ---------------------------------------------------------------------------------------
+# host entry point: sub-batch pipeline (H2D | kernels | D2H), pinned and pageable reads,
+# sort-unique on the device
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('sub_bytes', [64, 1000, 30_000])
+@pytest.mark.parametrize('pinned', [False, True])
+def test_host_entry_pipeline_equals_one_batch(monkeypatch, sub_bytes, pinned):
+    """A chunk cut into many sub-batches (ragged reads, reads with N, empty reads) gives the hits of
+    the chunk answered in one piece; read ids stay global; the sorted result is the sorted chunk."""
+    g, reads = _x_case()
+    k, step = 21, 5
+    ragged = []
+    for i, r in enumerate(reads[:400]):
+        ragged += [r, r[:k + (i % 7)], '', r[:40] + 'N' + r[41:]] if i % 5 == 0 else [r]
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(2, rng_seed=3)
+    monkeypatch.setenv('PSIGPU_SUB_BYTES', str(1 << 30))
+    want_raw = f.seeds_all(ragged, step=step, rec_offset=1000)
+    want = psi_amd.sort_unique(want_raw)
+    want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
+    bases, off = psi_amd.pack_reads(ragged)
+    keep = []
+    if pinned:
+        keep = [psi_amd.pinned_copy(bases), psi_amd.pinned_copy(off)]
+        bases, off = keep[0].array, keep[1].array
+    monkeypatch.setenv('PSIGPU_SUB_BYTES', str(sub_bytes))
+    raw = f.seeds_all((bases, off), step=step, rec_offset=1000)
+    assert len(raw) == len(want_raw) and _eq(psi_amd.sort_unique(raw), psi_amd.sort_unique(want_raw))
+    c = f.counters()
+    assert c['n_reads'] == len(ragged) and c['n_hits'] == len(raw)
+    su = f.seeds_all((bases, off), step=step, rec_offset=1000, sort_unique=True)
+    assert _eq(su, want)
+    assert f.counters()['n_hits'] == len(su)
+    f.close()
+
+
+def test_sort_unique_with_unordered_node_ids():
+    """Node ids that are not rank + constant: the device sorter orders by id, not by rank."""
+    g, reads = _random_graph(77)
+    rng = np.random.default_rng(23)
+    n = len(g.ids)
+    new_ids = rng.permutation(np.arange(100, 100 + 3 * n, 3)).astype(np.uint64)
+    rank = {v: i for i, v in enumerate(g.ids)}
+    label_off = np.cumsum([0] + [len(g.seq[v]) for v in g.ids])
+    labels = ''.join(g.seq[v] for v in g.ids).encode()
+    edge_off = np.cumsum([0] + [len(g.out[v]) for v in g.ids])
+    edge_to = [rank[t] for v in g.ids for t in g.out[v]]
+    pg = psi_amd.Graph.from_csr(new_ids, label_off, labels, edge_off, edge_to,
+                                paths=[[rank[v] for v in g.paths[0][1]]])
+    k = 8
+    f = psi_amd.SeedFinder(pg, k)
+    f.create_path_index(1)
+    raw = f.seeds_all(reads, step=2)
+    assert len(raw)
+    want = psi_amd.sort_unique(raw)
+    want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
+    su = f.seeds_all(reads, step=2, sort_unique=True)
+    assert _eq(su, want)
+    assert set(np.unique(su[:, 0]).tolist()) <= set(new_ids.tolist())
+    f.close()
+
+
+def test_device_entry_sort_unique_and_prepare():
+    """psigpu_find_seeds_device with PSIGPU_SORT_UNIQUE (device buffers in and out), after an explicit
+    psigpu_prepare: the first query then builds nothing."""
+    import torch
+    g, reads = _x_case()
+    k, step = 12, 4
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(1)
+    f.prepare()
+    bases, off = psi_amd.pack_reads(reads[:500])
+    d_bases = torch.from_numpy(bases).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    raw = f.seeds_all((bases, off), step=step, rec_offset=7)
+    want = psi_amd.sort_unique(raw)
+    want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
+    ptr, n = f.seeds_all_device(d_bases.data_ptr(), d_off.data_ptr(), 500, len(bases), step=step, rec_offset=7,
+                                flags=psi_amd.ALL | psi_amd.SORT_UNIQUE,
+                                stream=torch.cuda.current_stream().cuda_stream)
+    assert n == len(want) == f.counters()['n_hits']
+    assert _eq(f.copy_hits(ptr, n), want)
+    f.close()

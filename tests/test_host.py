@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(L, name), name + ' is declared in include/psi_gpu.h but not exported'
     bound = {n for n, _, _ in psi_amd.ABI}
     assert declared == bound
-    assert L.psigpu_abi_version() == 2
+    assert L.psigpu_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure(ref_data):
@@ -276,3 +276,55 @@ def test_index_argument_checks(ref_data):
     g2 = psi_amd.Graph.from_csr([1], [0, 4], b'ACGT', [0, 0], [])
     with pytest.raises(psi_amd.PsiGpuError):
         psi_amd.PathIndex.build(g2, 3, 1)              # "no reference path found in the input graph"
+
+
+# ---------------------------------------------------------------------------------------
+# psi::Records / readRecords (psi_amd/include/psi/sequence.hpp; reference sequence.hpp:1590-1624)
+# ---------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def records_dump(tmp_path_factory):
+    import subprocess
+    out = str(tmp_path_factory.mktemp('bin') / 'records_dump')
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-I' + os.path.join(ROOT, 'include'),
+                           '-I' + os.path.join(ROOT, 'psi_amd', 'include'),
+                           os.path.join(ROOT, 'tests', 'cpp', 'records_dump.cpp'), '-o', out,
+                           '-L' + os.path.join(ROOT, 'psi_amd'), '-lpsi_gpu', '-lz',
+                           '-Wl,-rpath,' + os.path.join(ROOT, 'psi_amd')])
+    return out
+
+
+@pytest.mark.parametrize('fmt', ['fastq', 'fastq.gz', 'fasta', 'text', 'crlf'])
+@pytest.mark.parametrize('chunk', [0, 1, 7])
+def test_read_records_formats_and_chunks(records_dump, tmp_path, fmt, chunk):
+    """Every format the CLI accepts, read ids global across chunks, records longer than the reader's
+    block and an unterminated last line."""
+    import gzip
+    import subprocess
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b'ACGTN', np.uint8)
+    reads = [alpha[rng.integers(0, 5, size=int(n))].tobytes().decode() for n in
+             list(rng.integers(1, 200, size=40)) + [9_000_000, 3, 5_000_000]]
+    names = ['r%d' % i for i in range(len(reads))]
+    if fmt.startswith('fastq') or fmt == 'crlf':
+        eol = '\r\n' if fmt == 'crlf' else '\n'
+        text = ''.join('@%s some comment%s%s%s+%s%s%s' % (n, eol, r, eol, eol, 'I' * len(r), eol) for n, r in zip(names, reads))
+        text = text[:-len(eol)]                   # no terminator on the last line
+    elif fmt == 'fasta':
+        text = ''.join('>%s desc\n%s\n' % (n, r) for n, r in zip(names, reads))
+    else:
+        text = '\n'.join(reads) + '\n\n'
+        names = [str(i) for i in range(len(reads))]
+    path = str(tmp_path / ('reads.' + fmt))
+    if fmt.endswith('.gz'):
+        with gzip.open(path, 'wt') as f:
+            f.write(text)
+    else:
+        with open(path, 'w', newline='') as f:
+            f.write(text)
+    out = subprocess.check_output([records_dump, path, str(chunk)]).decode().split('\n')
+    recs = [l.split('\t') for l in out if l and not l.startswith('#')]
+    chunks = [l.split() for l in out if l.startswith('#chunk')]
+    assert [(int(a), b, c) for a, b, c in recs] == [(i, n, r) for i, (n, r) in enumerate(zip(names, reads))]
+    want_chunks = 1 if chunk == 0 else -(-len(reads) // chunk)
+    assert len(chunks) == want_chunks
+    assert [int(c[1]) for c in chunks] == [i * chunk for i in range(want_chunks)]
