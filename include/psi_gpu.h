@@ -161,20 +161,33 @@ typedef struct psigpu_index_opts {
   uint64_t rng_seed;       /* tie-breaking in path selection */
   uint32_t build_on_device; /* 0: suffix sorting and FM arrays on the host (SA-IS); d + 1: on GPU d
                               (prefix doubling); both give the identical index */
+  uint32_t context;        /* psikt -t: patching context; 0 with `patched` = seed_len
+                              (SeedFinder::set_context, seed_finder.hpp:1772-1787) */
+  uint32_t patched;        /* psikt's default (no -P): index the first walk of a region whole and of every
+                              further walk only the stretches no earlier walk covers (psigpu_index_build only) */
   uint32_t reserved1;
 } psigpu_index_opts;
 
-/* SeedFinder::create_path_index(n, patched=false, context=0, step_size, ...) restricted to
- * full paths (seed_finder.hpp:1330-1355): pick `n_per_region` paths per embedded path
- * (the first is the embedded path itself, the rest greedy least-covered walks seeded by
- * `rng_seed`), index them, detect the uncovered loci for seed length k and locus step
- * (psikt -e).  n_per_region == 0: no path index, every locus is a starting locus
+/* SeedFinder::create_path_index(n, patched, context, step_size, ...) (seed_finder.hpp:1330-1355):
+ * draw `n_per_region` walks per embedded path with the Haplotyper rules (graph_iter.hpp:537-731:
+ * first out-edges for the first walk, then the out-edge that takes the walk where no earlier one
+ * went; ties by an RNG seeded with `rng_seed`), index them whole or -- `patched` -- the first one
+ * whole and of the others the patches no earlier walk covers (pathindex.hpp:496-560), then detect
+ * the uncovered loci for seed length k and locus step (psikt -e; :1481-1541).
+ * n_per_region == 0: no path index, every locus is a starting locus
  * (src/psikt.cpp:121-123; seed_finder.hpp:1543-1585). */
 psigpu_index* psigpu_index_build(const psigpu_graph* g, const psigpu_index_opts* opts, int* status);
-/* Same, over caller-chosen paths (node ranks); opts->n_per_region is ignored. */
+/* Same, over caller-chosen paths (node ranks); opts->n_per_region and opts->patched are ignored. */
 psigpu_index* psigpu_index_build_paths(const psigpu_graph* g, const psigpu_index_opts* opts,
                                        uint64_t n_paths, const uint64_t* path_off,
                                        const uint32_t* path_nodes, int* status);
+/* Same with trimmed paths -- what PathIndex::add_path takes (pathindex.hpp:153-161): path i covers
+ * its first node from base head_off[i] on and of its last node the first tail_len[i] bases (0 = all
+ * of it); Path::left / right (path_base.hpp:113-114, :240-246).  Either array may be NULL. */
+psigpu_index* psigpu_index_build_patches(const psigpu_graph* g, const psigpu_index_opts* opts,
+                                         uint64_t n_paths, const uint64_t* path_off,
+                                         const uint32_t* path_nodes, const uint32_t* head_off,
+                                         const uint32_t* tail_len, int* status);
 void psigpu_index_free(psigpu_index* x);
 int psigpu_index_view_get(const psigpu_index* x, psigpu_index_view* out);
 /* SeedFinder::serialize_path_index / load_path_index (seed_finder.hpp:1372-1413); own
@@ -185,6 +198,11 @@ psigpu_index* psigpu_index_load(const char* prefix, int* status);
  * 2..5 = ACGT) and its full suffix array are kept only when opts->keep_text_sa was set. */
 uint64_t psigpu_index_path_count(const psigpu_index* x);
 uint64_t psigpu_index_path(const psigpu_index* x, uint64_t i, uint32_t* out, uint64_t cap);
+int psigpu_index_path_trim(const psigpu_index* x, uint64_t i, uint32_t* head_off, uint32_t* tail_len);
+/* Was this index made for this graph, seed length and locus step?  (load_path_index recomputes the
+ * starting loci when its loci file does not match: seed_finder.hpp:1396-1413, utils.hpp:521-566;
+ * here a mismatch means "no valid index": the caller builds a new one.)  1 = yes. */
+int psigpu_index_matches(const psigpu_index* x, const psigpu_graph* g, uint32_t seed_len, uint32_t locus_step);
 const uint8_t* psigpu_index_text(const psigpu_index* x);      /* NULL unless kept */
 const int32_t* psigpu_index_sa(const psigpu_index* x);        /* NULL unless kept */
 /* Host helper: suffix array of a 0-terminated symbol string (own SA-IS). */

@@ -263,24 +263,42 @@ def hit_set(g: Graph, reads: Sequence[str], k: int, step: int,
     return sorted(hits)
 
 
-def uncovered_loci(g: Graph, paths: Iterable[Sequence[int]], k: int) -> List[Tuple[int, int]]:
-    """Loci with at least one k-walk whose node sequence is not a contiguous run of some
-    indexed (full, un-trimmed) path -- the intent of SeedFinder::add_uncovered_loci
-    (reference include/psi/seed_finder.hpp:1481-1541) for step 1.  With no paths every
-    locus that has a k-walk qualifies (cf. add_all_loci, :1543-1585, which adds all)."""
-    runs = set()
+def uncovered_loci(g: Graph, paths: Iterable[Sequence[int]], k: int,
+                   trims: Sequence[Tuple[int, int]] = ()) -> List[Tuple[int, int]]:
+    """Loci with at least one k-walk that is not a contiguous run of some indexed path -- the intent
+    of SeedFinder::add_uncovered_loci (reference include/psi/seed_finder.hpp:1481-1541) for step 1.
+    With no paths every locus that has a k-walk qualifies (cf. add_all_loci, :1543-1585, which adds
+    all).  `trims[i]` = (head offset, tail length) of path i, for patched paths
+    (pathindex.hpp:496-560; Path::left / right, path_base.hpp:113-114): the path covers its first node
+    from base `head` on and of its last node the first `tail` bases (0 = all); a walk is covered only
+    if the path spells all of its bases."""
     paths = [tuple(p) for p in paths]
-    maxlen = 0
-    walks = list(all_kwalks(g, k))
-    for _, _, _, nodes in walks:
-        maxlen = max(maxlen, len(nodes))
+    trims = list(trims) + [(0, 0)] * (len(paths) - len(trims))
+    where: List[Dict[int, List[int]]] = []          # per path: node -> its positions
     for p in paths:
-        for L in range(1, maxlen + 1):
-            for i in range(0, len(p) - L + 1):
-                runs.add(p[i:i + L])
+        d: Dict[int, List[int]] = {}
+        for i, u in enumerate(p):
+            d.setdefault(u, []).append(i)
+        where.append(d)
     out = set()
-    for _, v, o, nodes in walks:
-        if nodes not in runs:
+    for _, v, o, nodes in all_kwalks(g, k):
+        m = len(nodes)
+        # bases of the walk inside its last node
+        used = k if m == 1 else k - (len(g.seq[v]) - o) - sum(len(g.seq[u]) for u in nodes[1:-1])
+        covered = False
+        for p, (head, tail), d in zip(paths, trims, where):
+            for i in d.get(v, ()):
+                if p[i:i + m] != nodes:
+                    continue
+                if i == 0 and o < head:
+                    continue
+                if i + m == len(p) and tail and (o + used if m == 1 else used) > tail:
+                    continue
+                covered = True
+                break
+            if covered:
+                break
+        if not covered:
             out.add((v, o))
     rank = {v: i for i, v in enumerate(g.ids)}
     return sorted(out, key=lambda t: (rank[t[0]], t[1]))

@@ -53,7 +53,8 @@ class IndexView(C.Structure):
 class IndexOpts(C.Structure):
     _fields_ = [('seed_len', C.c_uint32), ('n_per_region', C.c_uint32), ('locus_step', C.c_uint32),
                 ('sa_rate', C.c_uint32), ('ftab_len', C.c_uint32), ('keep_text_sa', C.c_uint32),
-                ('rng_seed', C.c_uint64), ('build_on_device', C.c_uint32), ('reserved1', C.c_uint32)]
+                ('rng_seed', C.c_uint64), ('build_on_device', C.c_uint32), ('context', C.c_uint32),
+                ('patched', C.c_uint32), ('reserved1', C.c_uint32)]
 
 
 MODE_KMER_TABLE, MODE_TRAVERSE, MODE_LOCUS_TABLE = 0, 1, 2
@@ -93,6 +94,9 @@ ABI = [
     ('psigpu_graph_path', C.c_uint64, [_P, C.c_uint64, _P, C.c_uint64]),
     ('psigpu_index_build', _P, [_P, C.POINTER(IndexOpts), _INTP]),
     ('psigpu_index_build_paths', _P, [_P, C.POINTER(IndexOpts), C.c_uint64, _P, _P, _INTP]),
+    ('psigpu_index_build_patches', _P, [_P, C.POINTER(IndexOpts), C.c_uint64, _P, _P, _P, _P, _INTP]),
+    ('psigpu_index_path_trim', C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ('psigpu_index_matches', C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
     ('psigpu_index_free', None, [_P]),
     ('psigpu_index_view_get', C.c_int, [_P, C.POINTER(IndexView)]),
     ('psigpu_index_save', C.c_int, [_P, C.c_char_p]),
@@ -292,11 +296,13 @@ class PathIndex:
 
     @classmethod
     def build(cls, g: Graph, k: int, n_paths: int, step: int = 1, sa_rate: int = 0,
-              rng_seed: int = 0, ftab_len: int = 0, keep: bool = False, device: Optional[int] = None) -> 'PathIndex':
-        """`device`: GPU ordinal to build the suffix array / FM arrays on (None = host SA-IS)."""
+              rng_seed: int = 0, ftab_len: int = 0, keep: bool = False, device: Optional[int] = None,
+              patched: bool = False, context: int = 0) -> 'PathIndex':
+        """`device`: GPU ordinal to build the suffix array / FM arrays on (None = host SA-IS);
+        `patched` / `context`: psikt's default indexing mode (no -P) and its -t."""
         st = C.c_int(0)
         opts = IndexOpts(k, n_paths, step, sa_rate, ftab_len, int(keep), rng_seed,
-                         0 if device is None else device + 1, 0)
+                         0 if device is None else device + 1, context, int(patched), 0)
         h = lib().psigpu_index_build(g.h, C.byref(opts), C.byref(st))
         if not h:
             raise PsiGpuError('index build failed (%d): %s' % (st.value, _host_err()))
@@ -305,7 +311,10 @@ class PathIndex:
     @classmethod
     def build_paths(cls, g: Graph, k: int, paths: Sequence[Sequence[int]], step: int = 1,
                     sa_rate: int = 0, keep: bool = False, ftab_len: int = 0,
-                    device: Optional[int] = None) -> 'PathIndex':
+                    device: Optional[int] = None, head: Optional[Sequence[int]] = None,
+                    tail: Optional[Sequence[int]] = None, context: int = 0) -> 'PathIndex':
+        """`head` / `tail`: per path, the offset of its first indexed base in its first node and the
+        number of indexed bases of its last node (0 = all): a patch (Path::left / right)."""
         poff = np.zeros(len(paths) + 1, dtype=np.uint64)
         if len(paths):
             poff[1:] = np.cumsum([len(p) for p in paths], dtype=np.uint64)
@@ -313,9 +322,11 @@ class PathIndex:
         else:
             pnodes = np.zeros(0, np.uint32)
         st = C.c_int(0)
-        opts = IndexOpts(k, 0, step, sa_rate, ftab_len, int(keep), 0, 0 if device is None else device + 1, 0)
-        h = lib().psigpu_index_build_paths(g.h, C.byref(opts), len(paths), _ptr(poff), _ptr(pnodes),
-                                           C.byref(st))
+        opts = IndexOpts(k, 0, step, sa_rate, ftab_len, int(keep), 0, 0 if device is None else device + 1, context, 0, 0)
+        hd = None if head is None else np.ascontiguousarray(head, dtype=np.uint32)
+        tl = None if tail is None else np.ascontiguousarray(tail, dtype=np.uint32)
+        h = lib().psigpu_index_build_patches(g.h, C.byref(opts), len(paths), _ptr(poff), _ptr(pnodes),
+                                             _ptr(hd), _ptr(tl), C.byref(st))
         if not h:
             raise PsiGpuError('index build failed (%d): %s' % (st.value, _host_err()))
         return cls(h)
@@ -366,6 +377,18 @@ class PathIndex:
             lib().psigpu_index_path(self.h, i, _ptr(a), n)
             out.append(a)
         return out
+
+    def trims(self) -> List[Tuple[int, int]]:
+        """(head offset, tail length) of every indexed path; (0, 0) = a full path."""
+        out = []
+        for i in range(lib().psigpu_index_path_count(self.h)):
+            a, b = C.c_uint32(), C.c_uint32()
+            lib().psigpu_index_path_trim(self.h, i, C.byref(a), C.byref(b))
+            out.append((a.value, b.value))
+        return out
+
+    def matches(self, g: Graph, k: int, step: int = 1) -> bool:
+        return bool(lib().psigpu_index_matches(self.h, g.h, k, step))
 
     def __del__(self):
         if getattr(self, 'h', None) and _lib is not None:
@@ -427,10 +450,9 @@ class SeedFinder:
     def create_path_index(self, n: int, patched: bool = False, context: int = 0, step_size: int = 1,
                           sa_rate: int = 0, rng_seed: int = 0, ftab_len: int = 0,
                           build_on_device: bool = False) -> None:
-        if patched or context:
-            raise PsiGpuError('patched / context paths are not supported: full paths only (psikt -P)')
         self.set_path_index(PathIndex.build(self.graph, self.seed_len, n, step_size, sa_rate, rng_seed,
-                                            ftab_len, device=self.device if build_on_device else None))
+                                            ftab_len, device=self.device if build_on_device else None,
+                                            patched=patched, context=context))
 
     def set_path_index(self, pindex: PathIndex) -> None:
         self.pindex = pindex
@@ -440,11 +462,16 @@ class SeedFinder:
         """Build the query mode's tables now (index load time) instead of inside the first query."""
         self._chk(lib().psigpu_prepare(self.ctx, self.seed_len))
 
-    def load_path_index(self, prefix: str) -> bool:
+    def load_path_index(self, prefix: str, step_size: int = 1) -> bool:
+        """False (the caller then builds a new index) when the file is missing, unreadable, or was made
+        for another graph / seed length / locus step."""
         try:
-            self.set_path_index(PathIndex.load(prefix))
+            px = PathIndex.load(prefix)
         except PsiGpuError:
             return False
+        if not px.matches(self.graph, self.seed_len, step_size):
+            return False
+        self.set_path_index(px)
         return True
 
     def serialize_path_index(self, prefix: str) -> bool:

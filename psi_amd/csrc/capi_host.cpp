@@ -121,16 +121,30 @@ psigpu_index* psigpu_index_build(const psigpu_graph* g, const psigpu_index_opts*
     if (status) *status = PSIGPU_ERR_ARG;
     return nullptr;
   }
+  // SeedFinder::set_context (seed_finder.hpp:1772-1787): no context without patching; patching with
+  // context 0 means context = seed length
+  psigpu_index_opts o = *opts;
+  if (!o.patched) o.context = 0;
+  else if (o.context == 0) o.context = o.seed_len;
   std::vector<std::vector<uint32_t>> paths;
-  pick_paths(g->g, opts->n_per_region, opts->rng_seed, paths);
+  std::vector<uint32_t> head, tail;
+  pick_paths(g->g, o.n_per_region, o.patched != 0, o.context, o.rng_seed, paths, head, tail);
   int st; std::string err;
-  Index* x = build_index(g->g, *opts, paths, &st, &err);
+  Index* x = build_index(g->g, o, paths, head, tail, &st, &err);
   return wrap_index(x, st, err, status);
 }
 
 psigpu_index* psigpu_index_build_paths(const psigpu_graph* g, const psigpu_index_opts* opts,
                                        uint64_t n_paths, const uint64_t* path_off,
                                        const uint32_t* path_nodes, int* status)
+{
+  return psigpu_index_build_patches(g, opts, n_paths, path_off, path_nodes, nullptr, nullptr, status);
+}
+
+psigpu_index* psigpu_index_build_patches(const psigpu_graph* g, const psigpu_index_opts* opts,
+                                         uint64_t n_paths, const uint64_t* path_off,
+                                         const uint32_t* path_nodes, const uint32_t* head_off,
+                                         const uint32_t* tail_len, int* status)
 {
   if (!g || !opts || (n_paths && (!path_off || !path_nodes))) { if (status) *status = PSIGPU_ERR_ARG; return nullptr; }
   std::vector<std::vector<uint32_t>> paths;
@@ -144,8 +158,11 @@ psigpu_index* psigpu_index_build_paths(const psigpu_graph* g, const psigpu_index
       }
     paths.push_back(std::move(nodes));
   }
+  std::vector<uint32_t> head, tail;
+  if (head_off) head.assign(head_off, head_off + n_paths);
+  if (tail_len) tail.assign(tail_len, tail_len + n_paths);
   int st; std::string err;
-  Index* x = build_index(g->g, *opts, paths, &st, &err);
+  Index* x = build_index(g->g, *opts, paths, head, tail, &st, &err);
   return wrap_index(x, st, err, status);
 }
 
@@ -194,6 +211,21 @@ uint64_t psigpu_index_path(const psigpu_index* h, uint64_t i, uint32_t* out, uin
   uint64_t n = p.size() < cap ? p.size() : cap;
   if (out && n) memcpy(out, p.data(), n * 4);
   return p.size();
+}
+
+int psigpu_index_path_trim(const psigpu_index* h, uint64_t i, uint32_t* head_off, uint32_t* tail_len)
+{
+  if (!h || i >= h->x.paths.size()) return PSIGPU_ERR_ARG;
+  if (head_off) *head_off = i < h->x.path_head.size() ? h->x.path_head[i] : 0;
+  if (tail_len) *tail_len = i < h->x.path_tail.size() ? h->x.path_tail[i] : 0;
+  return PSIGPU_OK;
+}
+
+int psigpu_index_matches(const psigpu_index* h, const psigpu_graph* g, uint32_t seed_len, uint32_t locus_step)
+{
+  if (!h || !g) return 0;
+  if (locus_step == 0) locus_step = 1;
+  return h->x.k == seed_len && h->x.locus_step == locus_step && h->x.graph_fp == graph_fingerprint(g->g);
 }
 
 const uint8_t* psigpu_index_text(const psigpu_index* x)

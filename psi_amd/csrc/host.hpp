@@ -40,6 +40,10 @@ struct Graph {
 struct Index {
   uint32_t k = 0, sa_rate = 0, context = 0;
   std::vector<std::vector<uint32_t>> paths;    // indexed paths (node ranks)
+  std::vector<uint32_t> path_head, path_tail;  // per path: offset of its first indexed base in its first node; indexed
+                                               // bases of its last node (0 = all) -- Path::left / right of a patch
+  uint32_t locus_step = 1;                     // psikt -e the starting loci were sampled with
+  uint64_t graph_fp = 0;                       // fingerprint of the graph the index was made for
   uint64_t n = 0;                              // text length
   std::vector<RankBlock> blocks;
   uint64_t C[4] = { 0, 0, 0, 0 };
@@ -57,11 +61,16 @@ struct Index {
 Graph* load_graph_file(const std::string& path, int* status, std::string* err);
 
 // pathsel.cpp / index.cpp
-void pick_paths(const Graph& g, uint32_t n_per_region, uint64_t rng_seed,
-                std::vector<std::vector<uint32_t>>& out);
+// pathsel.cpp: Haplotyper walks and patches
+void pick_paths(const Graph& g, uint32_t n_per_region, bool patched, uint32_t context, uint64_t rng_seed,
+                std::vector<std::vector<uint32_t>>& out, std::vector<uint32_t>& head, std::vector<uint32_t>& tail);
+// index.cpp
+uint64_t graph_fingerprint(const Graph& g);
 Index* build_index(const Graph& g, const psigpu_index_opts& opts,
-                   const std::vector<std::vector<uint32_t>>& paths, int* status, std::string* err);
+                   const std::vector<std::vector<uint32_t>>& paths, const std::vector<uint32_t>& head,
+                   const std::vector<uint32_t>& tail, int* status, std::string* err);
 void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>& paths,
+                        const std::vector<uint32_t>& path_head, const std::vector<uint32_t>& path_tail,
                         uint32_t k, uint32_t step, std::vector<uint32_t>& loci_node,
                         std::vector<uint32_t>& loci_off);
 int save_index(const Index& x, const std::string& prefix);

@@ -20,92 +20,70 @@
 namespace psigpu {
 
 // ------------------------------------------------------------------------------------
-// Path selection.  The reference draws `n` haplotype-like walks per embedded path with a
-// Haplotyper iterator that prefers the least-covered out-edge (include/psi/graph.hpp:216-287)
-// and breaks ties at random.  Here walk 1 of every region is the embedded path itself and
-// walks 2..n are least-covered walks from its first node, ties broken by a seeded RNG; any
-// choice of paths yields the same hit set (the uncovered loci make up the difference).
-// ------------------------------------------------------------------------------------
-void pick_paths(const Graph& g, uint32_t n_per_region, uint64_t rng_seed,
-                std::vector<std::vector<uint32_t>>& out)
-{
-  out.clear();
-  if (n_per_region == 0) return;
-  std::vector<uint32_t> cover(g.n_nodes(), 0);
-  std::mt19937_64 rng(rng_seed);
-  for (size_t r = 0; r < g.paths.size(); ++r) {
-    const auto& ref = g.paths[r];
-    if (ref.empty()) continue;
-    out.push_back(ref);
-    for (uint32_t v : ref) ++cover[v];
-    for (uint32_t i = 1; i < n_per_region; ++i) {
-      std::vector<uint32_t> walk;
-      for (int attempt = 0; attempt < 4; ++attempt) {
-        walk.clear();
-        uint32_t v = ref[0];
-        while (true) {
-          walk.push_back(v);
-          uint64_t e0 = g.edge_off[v], e1 = g.edge_off[v + 1];
-          if (e0 == e1) break;
-          uint32_t best = 0xFFFFFFFFu, nbest = 0, pick = 0;
-          for (uint64_t e = e0; e < e1; ++e) {
-            uint32_t c = cover[g.edge_to[e]];
-            if (c < best) { best = c; nbest = 1; pick = g.edge_to[e]; }
-            else if (c == best) { ++nbest; if (rng() % nbest == 0) pick = g.edge_to[e]; }
-          }
-          v = pick;
-          if (walk.size() > g.n_nodes()) break;   // cyclic graph guard
-        }
-        bool dup = false;
-        for (auto& p : out) if (p == walk) { dup = true; break; }
-        if (!dup) break;
-      }
-      for (uint32_t v : walk) ++cover[v];
-      out.push_back(std::move(walk));
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// Starting loci: a locus (v, o) is a starting locus iff at least one k-walk from it is not
-// a contiguous run of an indexed path (seed_finder.hpp:1481-1541, step 1).  Coverage is
-// tracked with one bit per path on nodes and edges: for a path that visits no node twice, a
-// walk is a contiguous run of it iff every node and edge of the walk carries its bit.  Paths
-// that repeat a node, and paths beyond the first 64, get no bit (they are still indexed;
-// the loci set only grows, which costs duplicates, never sensitivity).
+// Starting loci: a locus (v, o) is a starting locus iff at least one k-walk from it is not spelled
+// by a contiguous run of an indexed path (seed_finder.hpp:1481-1541, step 1) -- "spelled" in the
+// indexed TEXT: a patched path (pathindex.hpp:496-560) covers its first node only from its head
+// offset on and its last node only up to its tail length, so a walk that needs the bases cut away
+// is not covered by it.  (The reference asks covered_by() about node ids alone and relies on the
+// patching rules for the bases; the definition here is the one that keeps the hit set complete.)
+//
+// Coverage is tracked with path STEPS: the paths' node lists are concatenated, a step is an index
+// into that array.  A walk w0 .. wm is covered iff some step s has node[s .. s+m] = w0 .. wm inside
+// one path, the walk's first base is at or behind that step's first indexed base and its last base
+// in front of step s+m's end.  The set of candidate steps only shrinks while a walk is extended and
+// holds at most as many steps as paths pass through the node, whatever the number of paths:
+// thousands of patches cost no more than the haplotypes they were cut from.
 // ------------------------------------------------------------------------------------
 namespace {
 
 struct LociCtx {
   const Graph& g;
   uint32_t k;
-  std::vector<uint64_t> node_mask, edge_mask;
+  std::vector<uint32_t> step_node;              // concatenated path node lists
+  std::vector<uint32_t> step_lo, step_hi;       // indexed bases [lo, hi) of the step's node
+  std::vector<uint8_t> step_last;               // last step of its path
+  std::vector<uint64_t> at_off;                 // CSR: steps at every node
+  std::vector<uint32_t> at;
   std::vector<uint32_t> reach;      // max bases spelled by a walk starting at node start, capped at k
   std::vector<uint32_t> child;      // max reach over the out-neighbours (0 for sinks)
 };
 
-// marks in `unc` (bit i = need i) the extension lengths for which an uncovered walk exists
-void explore(const LociCtx& c, uint32_t u, uint64_t e_in, uint32_t S, uint64_t mask, uint64_t* unc,
-             uint32_t depth = 0)
+inline void mark(uint64_t* unc, uint32_t lo, uint32_t hi)      // bits lo .. hi (need lengths, < 64)
+{
+  for (uint32_t i = lo; i <= hi && i < 64; ++i) *unc |= 1ull << i;
+}
+
+// The walk has spelled S bases behind its first node and now enters u; `state` = the steps the walk is
+// still a run of, standing on the node before u.  Marks in `unc` (bit i = need i) every extension
+// length for which an uncovered walk exists.
+void explore(const LociCtx& c, uint32_t u, uint32_t S, const std::vector<uint32_t>& state, uint64_t* unc, uint32_t depth)
 {
   if (depth > 4 * c.k) return;      // guards cycles of empty nodes
-  uint64_t m = mask & c.edge_mask[e_in] & c.node_mask[u];
-  if (m == 0) {
-    // entering u makes the walk uncovered: any need in [S+1, S+reach(u)] completes inside/after u
-    uint32_t lo = S + 1, hi = S + c.reach[u];
-    if (hi > c.k - 1) hi = c.k - 1;
-    for (uint32_t i = lo; i <= hi; ++i) *unc |= 1ull << i;
+  const uint32_t len = (uint32_t)c.g.node_len(u);
+  std::vector<uint32_t> next;
+  uint32_t hi_max = 0;              // most bases of u any candidate path still spells
+  for (uint32_t s : state) {
+    const uint32_t t = s + 1;       // (s is never the last step of its path)
+    if (c.step_node[t] != u) continue;
+    hi_max = std::max(hi_max, c.step_hi[t]);
+    if (!c.step_last[t]) next.push_back(t);
+  }
+  const uint32_t kmax = c.k - 1;    // needs are 1 .. k-1
+  // needs that end inside u: covered while some candidate spells that many of u's bases
+  if (len && S + hi_max < kmax && hi_max < len) mark(unc, S + hi_max + 1, std::min(kmax, S + len));
+  const uint32_t S2 = S + len;
+  if (S2 >= kmax) return;
+  if (next.empty()) {               // every longer walk through u is uncovered
+    if (c.child[u]) mark(unc, S2 + 1, std::min(kmax, S2 + c.child[u]));
     return;
   }
-  uint32_t S2 = S + (uint32_t)c.g.node_len(u);
-  if (S2 >= c.k - 1) return;
-  for (uint64_t e = c.g.edge_off[u]; e < c.g.edge_off[u + 1]; ++e)
-    explore(c, c.g.edge_to[e], e, S2, m, unc, depth + 1);
+  for (uint64_t e = c.g.edge_off[u]; e < c.g.edge_off[u + 1]; ++e) explore(c, c.g.edge_to[e], S2, next, unc, depth + 1);
 }
 
 }  // namespace
 
 void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>& paths,
+                        const std::vector<uint32_t>& path_head, const std::vector<uint32_t>& path_tail,
                         uint32_t k, uint32_t step, std::vector<uint32_t>& loci_node,
                         std::vector<uint32_t>& loci_off)
 {
@@ -113,9 +91,7 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
   loci_off.clear();
   if (step == 0) step = 1;
   const uint64_t n = g.n_nodes();
-  LociCtx c{ g, k, {}, {}, {}, {} };
-  c.node_mask.assign(n, 0);
-  c.edge_mask.assign(g.edge_to.size(), 0);
+  LociCtx c{ g, k, {}, {}, {}, {}, {}, {}, {}, {} };
   c.reach.assign(n, 0);
   c.child.assign(n, 0);
   // reach: fixed point of reach(u) = min(k, len(u) + max_child reach(child)); len 0 nodes allowed
@@ -132,27 +108,28 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
       if (r > c.reach[v]) { c.reach[v] = r; changed = true; }
     }
   }
-  // coverage bits
+  // path steps and the steps at every node
   {
-    std::vector<uint32_t> seen(n, 0xFFFFFFFFu);
-    uint32_t bit = 0;
-    for (size_t p = 0; p < paths.size() && bit < 64; ++p) {
+    uint64_t total = 0;
+    for (auto& P : paths) total += P.size();
+    c.step_node.reserve(total + 1); c.step_lo.reserve(total + 1); c.step_hi.reserve(total + 1); c.step_last.reserve(total + 1);
+    c.at_off.assign(n + 1, 0);
+    for (size_t p = 0; p < paths.size(); ++p) {
       const auto& P = paths[p];
-      bool simple = true;
-      for (uint32_t v : P) {
-        if (seen[v] == (uint32_t)p) { simple = false; break; }
-        seen[v] = (uint32_t)p;
-      }
-      if (!simple) continue;
-      uint64_t b = 1ull << bit++;
       for (size_t i = 0; i < P.size(); ++i) {
-        c.node_mask[P[i]] |= b;
-        if (i + 1 < P.size()) {
-          for (uint64_t e = g.edge_off[P[i]]; e < g.edge_off[P[i] + 1]; ++e)
-            if (g.edge_to[e] == P[i + 1]) { c.edge_mask[e] |= b; break; }
-        }
+        const uint32_t len = (uint32_t)g.node_len(P[i]);
+        uint32_t lo = 0, hi = len;
+        if (i == 0 && p < path_head.size()) lo = std::min(len, path_head[p]);
+        if (i + 1 == P.size() && p < path_tail.size() && path_tail[p]) hi = std::min(len, path_tail[p]);
+        c.step_node.push_back(P[i]); c.step_lo.push_back(lo); c.step_hi.push_back(hi);
+        c.step_last.push_back(i + 1 == P.size());
+        ++c.at_off[P[i] + 1];
       }
     }
+    for (uint64_t v = 0; v < n; ++v) c.at_off[v + 1] += c.at_off[v];
+    c.at.resize(c.step_node.size());
+    std::vector<uint64_t> fill(c.at_off.begin(), c.at_off.end() - 1);
+    for (uint32_t s = 0; s < c.step_node.size(); ++s) c.at[fill[c.step_node[s]]++] = s;
   }
   // Nodes are independent: blocks of nodes in parallel (OpenMP), each block's loci in node order,
   // blocks concatenated in order.
@@ -163,28 +140,53 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
   for (int64_t b = 0; b < (int64_t)n_blk; ++b) {
     std::vector<uint32_t>& out_n = bn[b];
     std::vector<uint32_t>& out_o = bo[b];
+    std::vector<uint32_t> state, heads;
+    std::vector<uint64_t> unc_of;
     const uint64_t v1 = std::min<uint64_t>(n, (uint64_t)(b + 1) * BLK);
     for (uint64_t v = (uint64_t)b * BLK; v < v1; ++v) {
-      uint64_t len = g.node_len((uint32_t)v);
+      const uint32_t len = (uint32_t)g.node_len((uint32_t)v);
       if (len == 0) continue;
-      uint64_t unc = 0;              // bit `need` (1..k-1): uncovered extension exists
-      bool node_unc = c.node_mask[v] == 0;
-      if (!node_unc)
-        for (uint64_t e = g.edge_off[v]; e < g.edge_off[v + 1]; ++e)
-          explore(c, g.edge_to[e], e, 0, c.node_mask[v], &unc);
+      const uint32_t* sv = c.at.data() + c.at_off[v];
+      const uint32_t nsv = (uint32_t)(c.at_off[v + 1] - c.at_off[v]);
+      // The steps a walk from offset o can be a run of are those whose first indexed base is at or
+      // before o: the distinct head offsets cut the node into ranges with one candidate set each.
+      heads.clear();
+      for (uint32_t i = 0; i < nsv; ++i) heads.push_back(c.step_lo[sv[i]]);
+      std::sort(heads.begin(), heads.end());
+      heads.erase(std::unique(heads.begin(), heads.end()), heads.end());
+      unc_of.assign(heads.size(), 0);
+      for (size_t h = 0; h < heads.size(); ++h) {
+        // walks that leave v: candidates spell v to its end and go on
+        state.clear();
+        for (uint32_t i = 0; i < nsv; ++i) {
+          const uint32_t s = sv[i];
+          if (c.step_lo[s] <= heads[h] && c.step_hi[s] == len && !c.step_last[s]) state.push_back(s);
+        }
+        uint64_t unc = 0;
+        if (state.empty()) { if (c.child[v]) mark(&unc, 1, std::min(k - 1, c.child[v])); }
+        else
+          for (uint64_t e = g.edge_off[v]; e < g.edge_off[v + 1]; ++e) explore(c, g.edge_to[e], 0, state, &unc, 0);
+        unc_of[h] = unc;
+      }
       uint32_t since = 0;            // locus subsampling (psikt -e): every step-th starting locus per node
-      for (uint64_t o = 0; o < len; ++o) {
-        if (len - o + c.child[v] < k) continue;      // no k-walk starts here
+      for (uint32_t o = 0; o < len; ++o) {
+        if ((uint64_t)len - o + c.child[v] < k) continue;      // no k-walk starts here
         bool take;
-        if (node_unc) take = true;
-        else {
-          int64_t need = (int64_t)k - (int64_t)(len - o);
-          take = need > 0 && ((unc >> need) & 1);
+        const int64_t need = (int64_t)k - (int64_t)(len - o);
+        if (need <= 0) {
+          // the k-walk lies inside v: covered iff one step spells [o, o + k)
+          take = true;
+          for (uint32_t i = 0; i < nsv && take; ++i)
+            if (c.step_lo[sv[i]] <= o && c.step_hi[sv[i]] >= o + k) take = false;
+        } else {
+          // the range of o: the last head offset <= o (none: no candidate at all)
+          size_t h = std::upper_bound(heads.begin(), heads.end(), o) - heads.begin();
+          take = h == 0 ? true : ((unc_of[h - 1] >> need) & 1) != 0;
         }
         if (!take) continue;
         if (since % step == 0) {
           out_n.push_back((uint32_t)v);
-          out_o.push_back((uint32_t)o);
+          out_o.push_back(o);
         }
         ++since;
       }
@@ -216,8 +218,22 @@ static inline int base_sym(char ch)
   }
 }
 
+uint64_t graph_fingerprint(const Graph& g)
+{
+  // node count, total label length, edge count and the node ids: enough to tell that an index file
+  // was made for another graph (load_path_index then rebuilds, as the reference does when its loci
+  // file does not match: seed_finder.hpp:1396-1413)
+  uint64_t h = 0xcbf29ce484222325ull;
+  auto mix = [&](uint64_t x) { h ^= x; h *= 0x100000001b3ull; h ^= h >> 29; };
+  mix(g.n_nodes()); mix(g.labels.size()); mix(g.edge_to.size());
+  for (uint64_t id : g.node_id) mix(id);
+  for (uint64_t v = 0; v < g.n_nodes(); v += 97) mix(g.label_off[v + 1]);
+  return h;
+}
+
 Index* build_index(const Graph& g, const psigpu_index_opts& opts,
-                   const std::vector<std::vector<uint32_t>>& paths, int* status, std::string* err)
+                   const std::vector<std::vector<uint32_t>>& paths, const std::vector<uint32_t>& head,
+                   const std::vector<uint32_t>& tail, int* status, std::string* err)
 {
   const uint32_t k = opts.seed_len, step = opts.locus_step;
   uint32_t sa_rate = opts.sa_rate;
@@ -232,9 +248,26 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
         if (g.edge_to[e] == P[i + 1]) { found = true; break; }
       if (!found) { *status = PSIGPU_ERR_ARG; *err = "path step without an edge"; return nullptr; }
     }
+  if ((!head.empty() && head.size() != paths.size()) || (!tail.empty() && tail.size() != paths.size())) {
+    *status = PSIGPU_ERR_ARG; *err = "head / tail arrays must have one entry per path"; return nullptr;
+  }
+  bool trimmed = false;
+  for (size_t p = 0; p < paths.size(); ++p) {
+    if (paths[p].empty()) continue;
+    const uint64_t l0 = g.node_len(paths[p].front()), l1 = g.node_len(paths[p].back());
+    const uint32_t h = head.empty() ? 0 : head[p], t = tail.empty() ? 0 : tail[p];
+    if (h > l0 || t > l1 || (paths[p].size() == 1 && t && h >= t)) {
+      *status = PSIGPU_ERR_ARG; *err = "path head offset / tail length out of range"; return nullptr;
+    }
+    trimmed = trimmed || h || (t && t < l1);
+  }
   Index* x = new Index;
-  x->k = k; x->sa_rate = sa_rate; x->context = 0;
+  x->k = k; x->sa_rate = sa_rate; x->context = opts.context;
   x->paths = paths;
+  x->path_head = head.empty() ? std::vector<uint32_t>(paths.size(), 0) : head;
+  x->path_tail = tail.empty() ? std::vector<uint32_t>(paths.size(), 0) : tail;
+  x->locus_step = step ? step : 1;
+  x->graph_fp = graph_fingerprint(g);
 
   // ---- text + segments -----------------------------------------------------------
   std::vector<uint8_t> T;
@@ -251,16 +284,21 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
   T.reserve(est);
   auto& ss = x->seg_start; auto& sn = x->seg_node; auto& so = x->seg_noff;
   bool first_path = true;
-  for (auto& P : paths) {
+  for (size_t pi = 0; pi < paths.size(); ++pi) {
+    const auto& P = paths[pi];
     if (P.empty()) continue;
     if (!first_path) T.push_back(SYM_SEP);
     first_path = false;
     bool in_gap = false;           // last emitted symbol was a separator for an N run
-    for (uint32_t v : P) {
+    for (size_t si = 0; si < P.size(); ++si) {
+      const uint32_t v = P[si];
       const char* lab = g.labels.data() + g.label_off[v];
-      uint64_t len = g.node_len(v);
+      // a patched path starts at its head offset and ends after its tail length
+      // (Path::left / right, path_base.hpp:113-114, :240-246)
+      const uint64_t o_begin = si == 0 ? x->path_head[pi] : 0;
+      const uint64_t len = (si + 1 == P.size() && x->path_tail[pi]) ? x->path_tail[pi] : g.node_len(v);
       bool open = false;           // a segment of this node is open
-      for (uint64_t o = 0; o < len; ++o) {
+      for (uint64_t o = o_begin; o < len; ++o) {
         int s = base_sym(lab[o]);
         if (s < 0) {
           if (!in_gap) { T.push_back(SYM_SEP); in_gap = true; }
@@ -394,11 +432,21 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
 
   }
 
-  if (opts.build_on_device) {
+  // the device routine tracks coverage with one bit per path: full, simple (no node twice) paths, at most 64
+  bool bits_suffice = !trimmed && paths.size() <= 64;
+  if (bits_suffice && opts.build_on_device) {
+    std::vector<uint32_t> seen(g.n_nodes(), 0xFFFFFFFFu);
+    for (size_t p = 0; p < paths.size() && bits_suffice; ++p)
+      for (uint32_t v : paths[p]) {
+        if (seen[v] == (uint32_t)p) { bits_suffice = false; break; }
+        seen[v] = (uint32_t)p;
+      }
+  }
+  if (opts.build_on_device && bits_suffice) {
     int st = gpu_find_starting_loci(g, paths, k, step, (int)opts.build_on_device - 1, x->loci_node, x->loci_off, err);
     if (st != PSIGPU_OK) { *status = st; delete x; return nullptr; }
   } else {
-    find_starting_loci(g, paths, k, step, x->loci_node, x->loci_off);
+    find_starting_loci(g, paths, x->path_head, x->path_tail, k, step, x->loci_node, x->loci_off);
   }
   if (keep) { x->text = std::move(T); x->sa = std::move(SA); }
   *status = PSIGPU_OK;
@@ -409,7 +457,7 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
 // Serialisation: one little-endian container `<prefix>.psigpu`.
 // ------------------------------------------------------------------------------------
 namespace {
-const char MAGIC[8] = { 'P', 'S', 'I', 'G', 'P', 'U', '0', '4' };
+const char MAGIC[8] = { 'P', 'S', 'I', 'G', 'P', 'U', '0', '5' };
 
 template <typename T> bool wr(FILE* f, const std::vector<T>& v)
 {
@@ -437,6 +485,8 @@ int save_index(const Index& x, const std::string& prefix)
   uint64_t np = x.paths.size();
   ok = ok && fwrite(&np, 8, 1, f) == 1;
   for (auto& p : x.paths) ok = ok && wr(f, p);
+  uint64_t extra[2] = { x.locus_step, x.graph_fp };
+  ok = ok && fwrite(extra, 8, 2, f) == 2 && wr(f, x.path_head) && wr(f, x.path_tail);
   ok = ok && wr(f, x.blocks) && wr(f, x.samples) && wr(f, x.exc_row) && wr(f, x.exc_sa) &&
        wr(f, x.seg_start) && wr(f, x.seg_node) && wr(f, x.seg_noff) && wr(f, x.seg_dir) &&
        wr(f, x.loci_node) && wr(f, x.loci_off) && wr(f, x.ftab) && wr(f, x.text4);
@@ -459,11 +509,29 @@ Index* load_index(const std::string& prefix, int* status)
     for (int i = 0; i < 4; ++i) x->C[i] = hdr[4 + i];
     x->paths.resize(np);
     for (auto& p : x->paths) ok = ok && rd(f, p);
+    uint64_t extra[2] = { 0, 0 };
+    ok = ok && fread(extra, 8, 2, f) == 2 && rd(f, x->path_head) && rd(f, x->path_tail);
+    x->locus_step = (uint32_t)extra[0]; x->graph_fp = extra[1];
     ok = ok && rd(f, x->blocks) && rd(f, x->samples) && rd(f, x->exc_row) && rd(f, x->exc_sa) &&
          rd(f, x->seg_start) && rd(f, x->seg_node) && rd(f, x->seg_noff) && rd(f, x->seg_dir) &&
          rd(f, x->loci_node) && rd(f, x->loci_off) && rd(f, x->ftab) && rd(f, x->text4);
   }
   fclose(f);
+  // a corrupt or truncated file must not reach the device: every array length follows from the header
+  if (ok) {
+    const uint64_t n = x->n;
+    ok = x->k >= 1 && x->k <= PSIGPU_MAX_SEED_LEN && x->sa_rate && !(x->sa_rate & (x->sa_rate - 1)) && n >= 1 &&
+         n < 0xFFFFFFF0ull && x->blocks.size() == n / BLOCK_SYMS + 1 && x->samples.size() == (n + x->sa_rate - 1) / x->sa_rate &&
+         x->exc_row.size() == x->exc_sa.size() && x->seg_start.size() == x->seg_node.size() + 1 &&
+         x->seg_noff.size() == x->seg_node.size() && x->seg_dir.size() == (n >> DIR_SHIFT) + 1 &&
+         x->loci_node.size() == x->loci_off.size() && x->ftab_len <= 16 &&
+         (x->ftab.empty() ? x->ftab_len == 0 : x->ftab.size() == (2ull << (2 * x->ftab_len))) &&
+         (x->text4.empty() || x->text4.size() == n / 16 + 2) && x->path_head.size() == x->paths.size() &&
+         x->path_tail.size() == x->paths.size();
+    for (uint32_t d : x->seg_dir) ok = ok && d < x->seg_node.size();
+    for (size_t i = 0; ok && i + 1 < x->seg_start.size(); ++i) ok = x->seg_start[i] <= x->seg_start[i + 1];
+    ok = ok && (x->seg_start.empty() || x->seg_start.back() == n);
+  }
   if (!ok) { delete x; *status = PSIGPU_ERR_FORMAT; return nullptr; }
   *status = PSIGPU_OK;
   return x;

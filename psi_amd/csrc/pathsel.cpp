@@ -1,0 +1,269 @@
+// Path selection for the path index: SeedFinder::pick_paths (reference
+// include/psi/seed_finder.hpp:1138-1167) -- `n` haplotype-like walks per embedded path, drawn by the
+// Haplotyper graph iterator, as full paths or cut into patches.
+//
+//   Haplotyper (include/psi/graph_iter.hpp:537-731)        ->  class Haplotyper below: the same
+//       choice of the next node, rule for rule (first out-edge at level 0; at level s > 0 the
+//       first out-edge whose "setback" path -- the last nodes of the walk, kept short by the
+//       entropy rule -- no earlier walk contains; else the out-edge whose setback path the fewest
+//       earlier walks contain; else a uniformly random out-edge).  The reference draws that last
+//       case from a randomly seeded generator; here the generator is seeded by the caller.
+//   get_uniq_full_haplotype (pathindex.hpp:455-496)        ->  full_walk()
+//   get_uniq_patches (pathindex.hpp:498-560)               ->  cut_patches(): own formulation of the
+//       same idea.  A walk drawn after the first one is mostly a repetition of earlier walks; only
+//       its windows of `context` bases whose NODE sequence no earlier walk contains are new.  The
+//       patches are the maximal runs of such windows, trimmed to the base: a patch starts at the
+//       first base of its first uncovered window (head offset in its first node, Path::left) and ends
+//       with the last base of its last one (tail length in its last node, Path::right).  The
+//       reference slides a frontier path along the walk and trims with ltrim/rtrim_front_by_len;
+//       its patches can differ from these by the context carried at their ends.  Which bases the
+//       index holds does not change the hit set: every k-walk the indexed text does not spell
+//       makes its first base a starting locus (find_starting_loci, index.cpp).
+#include <algorithm>
+#include <deque>
+#include <random>
+#include <unordered_map>
+
+#include "host.hpp"
+
+namespace psigpu {
+namespace {
+
+constexpr uint32_t END = 0xFFFFFFFFu;
+
+// An earlier walk, kept the way Path<Graph, Haplotype> keeps it: the set of its node ranks.
+// contains(q) (path_base.hpp:1256-1280): q's ranks strictly increase, all lie on the walk, and the walk
+// has no other node between q's first and last rank -- q is a contiguous run of the walk.
+struct Walk {
+  std::vector<uint32_t> sorted;       // node ranks, increasing
+  bool contains(const uint32_t* q, size_t n) const
+  {
+    if (n == 0) return false;
+    const uint32_t b = q[0], e = q[n - 1];
+    if (e < b) return false;
+    auto lo = std::lower_bound(sorted.begin(), sorted.end(), b);
+    auto hi = std::upper_bound(sorted.begin(), sorted.end(), e);
+    if (lo == sorted.end() || *lo != b || (size_t)(hi - lo) != n) return false;
+    for (size_t i = 0; i < n; ++i)
+      if (lo[i] != q[i]) return false;      // (strictly increasing and on the walk, both at once)
+    return true;
+  }
+};
+
+class Haplotyper {
+public:
+  Haplotyper(const Graph& g, uint64_t seed) : g_(g), rng_((uint32_t)(seed ^ (seed >> 32)) + 5489u) {}
+
+  void reset(uint32_t start)                       // GraphIter::reset (:706-718)
+  {
+    start_ = value_ = start;
+    visiting_.clear(); visited_.clear();
+    current_.assign(1, start);
+    setback_ = 0; entropy_ = 1;
+  }
+  uint32_t value() const { return value_; }
+  size_t level() const { return visited_.size(); } // :720-724
+  const std::vector<uint32_t>& current() const { return current_; }
+
+  bool covered(const uint32_t* q, size_t n) const  // operator[] (:693-700): covered_by( path, visited )
+  {
+    for (const Walk& w : visited_) if (w.contains(q, n)) return true;
+    return false;
+  }
+
+  void next()                                      // operator++ (:590-657)
+  {
+    const uint64_t e0 = g_.edge_off[value_], e1 = g_.edge_off[value_ + 1];
+    if (e0 == e1) { value_ = END; return; }
+    if (setback_ > 1) {
+      while (!visiting_.empty() && entropy_ > setback_) {
+        entropy_ /= outdeg(visiting_.front());
+        visiting_.pop_front();
+      }
+    }
+    uint32_t candidate = END;
+    if (setback_ == 0 || e1 - e0 == 1) candidate = g_.edge_to[e0];
+    else {
+      // a forward node such that the setback path is in none of the earlier walks
+      bool again;
+      do {
+        again = false;
+        for (uint64_t e = e0; e < e1; ++e) {
+          visiting_.push_back(g_.edge_to[e]);
+          const bool seen = covered_visiting();
+          visiting_.pop_back();
+          if (!seen) { candidate = g_.edge_to[e]; break; }
+        }
+        if (setback_ == 1 && candidate == END && visiting_.empty()) { visiting_.push_back(value_); again = true; }
+      } while (again);
+      if (setback_ == 1 && !visiting_.empty()) visiting_.pop_back();
+    }
+    if (candidate == END) candidate = least_covered_adjacent();       // graph.hpp:250-284
+    if (candidate == END) {                                           // graph.hpp:162-203
+      std::uniform_int_distribution<uint64_t> dis(0, e1 - e0 - 1);
+      candidate = g_.edge_to[e0 + dis(rng_)];
+    }
+    value_ = candidate;
+    if (setback_ > 1) { visiting_.push_back(value_); entropy_ *= std::max<uint64_t>(1, outdeg(value_)); }
+    current_.push_back(value_);
+  }
+
+  void discard() { rewind(); }                     // operator--(int) (:659-671)
+  void save()                                      // operator--() (:673-680)
+  {
+    Walk w;
+    w.sorted = current_;
+    std::sort(w.sorted.begin(), w.sorted.end());
+    w.sorted.erase(std::unique(w.sorted.begin(), w.sorted.end()), w.sorted.end());
+    visited_.push_back(std::move(w));
+    setback_ = (unsigned)visited_.size();
+    rewind();
+  }
+
+private:
+  uint64_t outdeg(uint32_t v) const { return g_.edge_off[v + 1] - g_.edge_off[v]; }
+  bool covered_visiting() const
+  {
+    tmp_.assign(visiting_.begin(), visiting_.end());
+    return covered(tmp_.data(), tmp_.size());
+  }
+  void rewind()
+  {
+    value_ = start_;
+    visiting_.clear();
+    entropy_ = 1;
+    if (setback_ > 1) { visiting_.push_back(value_); entropy_ *= std::max<uint64_t>(1, outdeg(value_)); }
+    current_.assign(1, value_);
+  }
+  uint32_t least_covered_adjacent()
+  {
+    if (visiting_.empty()) return END;
+    const uint32_t back = visiting_.back();
+    uint32_t lc = END;
+    uint64_t lc_value = ~0ull;
+    bool equal = true;
+    for (uint64_t e = g_.edge_off[back]; e < g_.edge_off[back + 1]; ++e) {
+      visiting_.push_back(g_.edge_to[e]);
+      tmp_.assign(visiting_.begin(), visiting_.end());
+      visiting_.pop_back();
+      uint64_t cov = 0;
+      for (const Walk& w : visited_) cov += w.contains(tmp_.data(), tmp_.size());
+      if (equal && lc_value != ~0ull && lc_value != cov) equal = false;
+      if (cov < lc_value) { lc = g_.edge_to[e]; lc_value = cov; }
+    }
+    return equal ? END : lc;
+  }
+
+  const Graph& g_;
+  std::mt19937 rng_;
+  uint32_t start_ = 0, value_ = 0;
+  std::deque<uint32_t> visiting_;
+  std::vector<Walk> visited_;
+  std::vector<uint32_t> current_;
+  mutable std::vector<uint32_t> tmp_;
+  unsigned setback_ = 0;
+  uint64_t entropy_ = 1;
+};
+
+// get_uniq_full_haplotype with tries = 0: walk to a sink, keep the walk
+std::vector<uint32_t> full_walk(const Graph& g, Haplotyper& hp)
+{
+  std::vector<uint32_t> walk;
+  const uint64_t cap = 4 * g.n_nodes() + 16;       // a cyclic graph has no sink to stop at
+  while (hp.value() != END && walk.size() < cap) {
+    walk.push_back(hp.value());
+    hp.next();
+  }
+  return walk;
+}
+
+struct Patch { size_t first, last; uint32_t head, tail; };      // nodes walk[first..last], trimmed
+
+// maximal runs of `context`-base windows of `walk` whose node sequence none of `earlier` contains
+std::vector<Patch> cut_patches(const Graph& g, const std::vector<uint32_t>& walk,
+                               const std::vector<std::vector<uint32_t>>& earlier, uint32_t context)
+{
+  const size_t m = walk.size();
+  std::vector<Patch> out;
+  if (m == 0) return out;
+  std::vector<uint64_t> pos(m + 1, 0);             // first base of walk[i] in the walk's sequence
+  for (size_t i = 0; i < m; ++i) pos[i + 1] = pos[i] + g.node_len(walk[i]);
+  const uint64_t L = pos[m];
+  if (L == 0) return out;
+  // run[i]: the longest j - i + 1 such that walk[i..j] is a contiguous run of some earlier walk
+  std::vector<uint32_t> run(m, 0), cur(m, 0);
+  for (const auto& V : earlier) {
+    std::unordered_map<uint32_t, uint32_t> at;      // node -> its (first) position in V
+    at.reserve(V.size() * 2);
+    for (uint32_t q = 0; q < V.size(); ++q) at.emplace(V[q], q);
+    for (size_t i = m; i-- > 0;) {
+      auto it = at.find(walk[i]);
+      if (it == at.end()) { cur[i] = 0; continue; }
+      const uint32_t q = it->second;
+      cur[i] = (i + 1 < m && q + 1 < V.size() && V[q + 1] == walk[i + 1] && cur[i + 1]) ? cur[i + 1] + 1 : 1;
+      run[i] = std::max(run[i], cur[i]);
+    }
+  }
+  // Windows start at x in [0, x_max]; the one starting in node i at x ends in the node holding base
+  // x + c - 1, and is uncovered iff that node lies behind walk[i + run[i] - 1]
+  const uint64_t c = std::min<uint64_t>(context, L);
+  const uint64_t x_max = L - c;
+  uint64_t open_s = 0, open_t = 0;                 // the run of uncovered windows being collected: bases [s, t)
+  bool open = false;
+  auto close = [&]() {
+    if (!open) return;
+    size_t a = std::upper_bound(pos.begin(), pos.end(), open_s) - pos.begin() - 1;
+    size_t b = std::upper_bound(pos.begin(), pos.end(), open_t - 1) - pos.begin() - 1;
+    while (a < b && g.node_len(walk[a]) == 0) ++a;
+    Patch p{ a, b, (uint32_t)(open_s - pos[a]), (uint32_t)(open_t - pos[b]) };
+    if (p.tail == g.node_len(walk[b])) p.tail = 0;
+    out.push_back(p);
+    open = false;
+  };
+  for (size_t i = 0; i < m; ++i) {
+    if (pos[i] > x_max) break;
+    if (pos[i + 1] == pos[i]) continue;
+    const uint64_t covered_to = run[i] ? pos[i + run[i]] : pos[i];     // first base behind the covered run
+    // uncovered windows starting in this node: x + c - 1 >= covered_to
+    uint64_t lo = covered_to >= c ? covered_to - c + 1 : 0;
+    lo = std::max<uint64_t>(lo, pos[i]);
+    const uint64_t hi = std::min<uint64_t>(pos[i + 1] - 1, x_max);      // last window start in this node
+    if (lo > hi) continue;
+    if (open && lo > open_t) close();             // a gap of covered bases: the run ended
+    if (!open) { open = true; open_s = lo; }
+    open_t = hi + c;
+  }
+  close();
+  return out;
+}
+
+}  // namespace
+
+void pick_paths(const Graph& g, uint32_t n_per_region, bool patched, uint32_t context, uint64_t rng_seed,
+                std::vector<std::vector<uint32_t>>& out, std::vector<uint32_t>& head, std::vector<uint32_t>& tail)
+{
+  out.clear(); head.clear(); tail.clear();
+  if (n_per_region == 0) return;
+  Haplotyper hp(g, rng_seed);
+  for (size_t r = 0; r < g.paths.size(); ++r) {
+    if (g.paths[r].empty()) continue;
+    hp.reset(g.paths[r][0]);                       // the region's walks start where its embedded path starts (:1159-1160)
+    std::vector<std::vector<uint32_t>> walks;      // this region's walks so far (whole, also when patches are kept)
+    for (uint32_t i = 0; i < n_per_region; ++i) {
+      std::vector<uint32_t> walk = full_walk(g, hp);
+      hp.save();
+      if (walk.empty()) continue;
+      if (!patched || walks.empty()) {             // get_uniq_patched_haplotype: level 0 gives a full haplotype (:568-571)
+        out.push_back(walk); head.push_back(0); tail.push_back(0);
+      } else {
+        for (const Patch& p : cut_patches(g, walk, walks, context)) {
+          out.emplace_back(walk.begin() + p.first, walk.begin() + p.last + 1);
+          head.push_back(p.head); tail.push_back(p.tail);
+        }
+      }
+      walks.push_back(std::move(walk));
+    }
+  }
+}
+
+}  // namespace psigpu

@@ -262,11 +262,13 @@ int run( Options const& o, Logger& log )
   } else {
     if ( o.path_num == 0 ) log.info( "No path has been specified. Skipping path indexing..." );
     else log.info( "No valid path index found. Creating the path index..." );
-    if ( o.path_num != 0 && o.patched )
-      throw std::runtime_error( "patched paths are not supported by this build: add -P/--no-patched" );
+    if ( o.step_size > 1 )
+      log.warn( "-e " + std::to_string( o.step_size ) + ": every e-th uncovered locus of a node is kept; the reference steps "
+                "along its backtracked k-paths (seed_finder.hpp:1520-1524). Neither is fully sensitive, and the two hit "
+                "sets differ; only -e 1 is covered by the parity claim." );
     auto info_cb = [ &log ]( std::string const& m ) { log.info( m ); };
     auto warn_cb = [ &log ]( std::string const& m ) { log.warn( m ); };
-    finder.create_path_index( o.path_num, false, 0, o.step_size, o.dindex_min_ris, o.dindex_max_ris,
+    finder.create_path_index( o.path_num, o.patched, o.context, o.step_size, o.dindex_min_ris, o.dindex_max_ris,
                               PerComponent{}, info_cb, warn_cb );
     log.info( "Created path index in " + std::to_string( seconds_since( t0 ) ) + " s." );
     if ( o.path_num != 0 ) {

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "psi_gpu.h"
@@ -49,6 +50,22 @@ namespace psi {
     std::uint64_t get_edge_count() const { return psigpu_graph_edge_count( h_ ); }
     std::uint64_t get_path_count() const { return psigpu_graph_path_count( h_ ); }
     id_type rank_to_id( rank_type rank ) const { return view_.node_id[ rank - 1 ]; }   /* ranks are 1-based as in gum */
+    /** gum's id_to_rank: 0 when there is no such node. */
+    rank_type id_to_rank( id_type id ) const
+    {
+      std::uint64_t n = view_.n_nodes;
+      if ( n == 0 ) return 0;
+      /* ids of vg / GFA files are almost always first id + rank */
+      std::uint64_t guess = id - view_.node_id[ 0 ];
+      if ( id >= view_.node_id[ 0 ] && guess < n && view_.node_id[ guess ] == id ) return guess + 1;
+      if ( id_rank_.empty() ) {
+        id_rank_.reserve( n * 2 );
+        for ( std::uint64_t r = 0; r < n; ++r ) id_rank_.emplace( view_.node_id[ r ], r + 1 );
+      }
+      auto it = id_rank_.find( id );
+      return it == id_rank_.end() ? 0 : it->second;
+    }
+    bool has_node( id_type id ) const { return id_to_rank( id ) != 0; }
     offset_type node_length( rank_type rank ) const
     { return view_.label_off[ rank ] - view_.label_off[ rank - 1 ]; }
     std::string node_sequence( rank_type rank ) const
@@ -59,6 +76,7 @@ namespace psi {
   private:
     psigpu_graph* h_ = nullptr;
     psigpu_graph_view view_{};
+    mutable std::unordered_map< id_type, rank_type > id_rank_;
   };
 }  /* --- end of namespace psi --- */
 

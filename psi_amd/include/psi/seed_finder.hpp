@@ -9,8 +9,9 @@
 //    ignored so that `SeedFinder< NoStats, Traits >` in caller code still compiles;
 //  * get_seeds()/index_reads() only describe the chunk (k, distance): seeding and the seeds
 //    index are built on the device inside seeds_all();
-//  * paths are full paths: create_path_index( n, patched = true, ... ) throws, as patched
-//    (context-trimmed) paths are an index-size optimisation that does not change the hit set.
+//  * path selection, indexing and the starting loci are made together by the library
+//    (psigpu_index_build): pick_paths() does all three, index_paths() / add_uncovered_loci() are kept
+//    for callers that spell the steps out (reference test/src/test_seedfinder.cpp:98-163).
 #ifndef PSI_AMD_SEED_FINDER_HPP__
 #define PSI_AMD_SEED_FINDER_HPP__
 
@@ -61,8 +62,8 @@ namespace psi {
 
     /** SeedFinder( graph, seed_len, gocc_threshold, max_mem ) (reference :930-942). */
     SeedFinder( graph_type const& g, unsigned int len, unsigned int gocc_thr = 0,
-                unsigned int /* mxmem: MEM mode is not on the k-mer path */ = 0, int device = 0 )
-      : graph_ptr( &g ), seed_len( len ), gocc_threshold( gocc_thr ), device_( device )
+                unsigned int mxmem = 0, int device = 0 )
+      : graph_ptr( &g ), seed_len( len ), gocc_threshold( gocc_thr ), max_mem( mxmem ), device_( device ), pindex( g )
     {
       if ( len == 0 || len > PSIGPU_MAX_SEED_LEN )
         throw std::runtime_error( "seed length out of range (1.." + std::to_string( PSIGPU_MAX_SEED_LEN ) + ")" );
@@ -83,6 +84,28 @@ namespace psi {
     ~SeedFinder() { psigpu_destroy( ctx ); }
 
     /* ---- index ------------------------------------------------------------------------ */
+    /** pick_paths( n, patched, context, callback, info, warn ) (reference :1138-1167): `n` walks per
+     *  embedded path drawn with the Haplotyper rules, whole or patched.  The library indexes them and
+     *  detects the uncovered loci in the same call. */
+    void pick_paths( unsigned int n, bool patched = true, unsigned int context = 0,
+                     std::function< void( std::string const&, int ) > callback = nullptr,
+                     std::function< void( std::string const& ) > info = nullptr,
+                     std::function< void( std::string const& ) > warn = nullptr )
+    {
+      (void)callback; (void)info;
+      if ( n != 0 && graph_ptr->get_path_count() == 0 )
+        throw std::runtime_error( "no reference path found in the input graph" );      /* reference :1145-1147 */
+      if ( patched && context == 0 && warn )                                             /* set_context, :1772-1787 */
+        warn( "The context size cannot be zero for patching. Assuming the seed length as the context size..." );
+      pick_n = n; pick_patched = patched; pick_context = context;
+      build( 1 );
+    }
+    /** index_paths() (reference :1169-1176): done by pick_paths. */
+    void index_paths() {}
+    /** add_uncovered_loci( step ) (reference :1481-1541): the loci for step 1 exist after pick_paths;
+     *  another step rebuilds. */
+    void add_uncovered_loci( unsigned int step = 1 ) { if ( step != built_step ) build( step ); }
+
     /** create_path_index( n, patched, context, step_size, dmin, dmax, mode, info, warn )
      *  (reference :1330-1355). */
     template< typename TMode = PerComponent >
@@ -91,24 +114,32 @@ namespace psi {
                             TMode = {}, std::function< void( std::string const& ) > info = nullptr,
                             std::function< void( std::string const& ) > warn = nullptr )
     {
-      if ( patched || context != 0 )
-        throw std::runtime_error( "patched paths are not supported: pass --no-patched (full paths)" );
       if ( ( dmin || dmax ) && warn ) warn( "the distance index is not part of the seed-finding path; ignored" );
-      if ( info ) info( "Selecting and indexing " + std::to_string( n ) + " path(s) per region..." );
-      psigpu_index_opts o{};
-      o.seed_len = seed_len; o.n_per_region = n; o.locus_step = step_size;
-      o.build_on_device = (unsigned int)device_ + 1;      /* suffix sorting on the GPU the finder runs on */
-      pindex.create( *graph_ptr, o );
-      check( psigpu_load_index( ctx, &pindex.view() ) );
+      if ( n != 0 && graph_ptr->get_path_count() == 0 )
+        throw std::runtime_error( "no reference path found in the input graph" );
+      if ( patched && context == 0 && n != 0 && warn )
+        warn( "The context size cannot be zero for patching. Assuming the seed length as the context size..." );
+      if ( info ) info( "Selecting and indexing " + std::to_string( n ) + ( patched ? " patched" : "" ) +
+                        " path(s) per region..." );
+      pick_n = n; pick_patched = patched; pick_context = context;
+      if ( info ) info( "Detecting uncovered loci..." );
+      build( step_size );
     }
 
-    /** load_path_index( prefix, context, step, dmin, dmax ) -> bool (reference :1396-1413). */
+    /** load_path_index( prefix, context, step, dmin, dmax ) -> bool (reference :1396-1413).  A file made
+     *  for another graph, seed length or locus step is not a valid index for this finder (the reference
+     *  keys its loci file on seed length and step and recomputes on a mismatch, utils.hpp:521-566). */
     bool load_path_index( std::string const& prefix, unsigned int /*context*/ = 0,
-                          unsigned int /*step_size*/ = 1, unsigned int = 0, unsigned int = 0 )
+                          unsigned int step_size = 1, unsigned int = 0, unsigned int = 0 )
     {
       if ( !pindex.load( prefix ) ) return false;
-      if ( pindex.view().seed_len != seed_len ) { pindex.clear(); return false; }
+      if ( !psigpu_index_matches( pindex.handle(), graph_ptr->handle(), seed_len, step_size ) ) {
+        pindex.clear();
+        return false;
+      }
       check( psigpu_load_index( ctx, &pindex.view() ) );
+      check( psigpu_prepare( ctx, seed_len ) );
+      built_step = step_size;
       return true;
     }
 
@@ -203,6 +234,18 @@ namespace psi {
     void check( int st ) const
     { if ( st != PSIGPU_OK ) throw std::runtime_error( psigpu_last_error( ctx ) ); }
 
+    void build( unsigned int step_size )
+    {
+      psigpu_index_opts o{};
+      o.seed_len = seed_len; o.n_per_region = pick_n; o.locus_step = step_size;
+      o.patched = pick_patched ? 1u : 0u; o.context = pick_context;
+      o.build_on_device = (unsigned int)device_ + 1;      /* suffix sorting on the GPU the finder runs on */
+      pindex.create( *graph_ptr, o );
+      check( psigpu_load_index( ctx, &pindex.view() ) );
+      check( psigpu_prepare( ctx, seed_len ) );           /* the query mode's tables: index time, not query time */
+      built_step = step_size;
+    }
+
     psigpu_hits find( SeedsRecord const& seeds, unsigned int flags ) const
     {
       if ( seeds.chunk == nullptr ) throw std::runtime_error( "get_seeds() has not been called" );
@@ -232,6 +275,9 @@ namespace psi {
     graph_type const* graph_ptr;
     unsigned int seed_len;
     unsigned int gocc_threshold;
+    unsigned int max_mem = 0;
+    unsigned int pick_n = 0, pick_context = 0, built_step = 0;
+    bool pick_patched = true;
     int device_ = 0;
     pathindex_type pindex;
     psigpu_ctx* ctx = nullptr;

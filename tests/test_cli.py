@@ -70,9 +70,28 @@ def test_output_bytes_match_golden(tmp_path):
     assert os.path.exists(prefix + '.psigpu')
     log = open(str(tmp_path / 'psi.log')).read()
     assert 'Total number of seeds found: 10' in log and 'Number of reads covered: 10' in log
-    # patched paths are refused, not silently replaced
-    p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '1', '-o', str(tmp_path / 'o2'), '-Q')
-    assert p.returncode == 1 and 'no-patched' in p.stderr
+    # the reference's DEFAULT indexing mode -- patched paths, src/psikt.cpp:456 -- with and without -t
+    for extra in (['-n', '2', '-t', '10'], ['-n', '3'], ['-n', '2', '-t', '14', '--query-mode', 'traverse'],
+                  ['-n', '4', '-t', '12', '--query-mode', 'locus-table', '-c', '4']):
+        out = str(tmp_path / 'outp.gam')
+        p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-o', out, '-Q', *extra)
+        assert p.returncode == 0, p.stderr
+        got = _records(out)
+        got = got[np.lexsort((got[:, 1], got[:, 0], got[:, 3], got[:, 2]))]
+        assert got.shape == want.shape and (got == want).all()
+    # context shorter than the seed: the reference's runtime error (seed_finder.hpp:1434-1437)
+    p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '2', '-t', '6', '-o', str(tmp_path / 'o2'), '-Q')
+    assert p.returncode == 1 and 'seed length should not be larger than context size' in p.stderr
+    # an index file made with another locus step (-e) is not reused
+    pre2 = str(tmp_path / 'stale')
+    p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '1', '-e', '3', '-I', pre2, '-o', str(tmp_path / 'o4'), '-Q')
+    assert p.returncode == 0, p.stderr
+    out = str(tmp_path / 'o5')
+    p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '1', '-I', pre2, '-o', out, '-L', str(tmp_path / 'psi2.log'))
+    assert p.returncode == 0, p.stderr
+    assert 'No valid path index found' in open(str(tmp_path / 'psi2.log')).read()
+    got = _records(out)
+    assert got.shape == want.shape and (got == want).all()
     p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '0', '--query-mode', 'nope', '-o', str(tmp_path / 'o3'), '-Q')
     assert p.returncode == 1 and 'query mode' in p.stderr
 

@@ -48,14 +48,17 @@ def _graph(name):
 # committed golden vectors (brute-force definition on the reference's own fixtures)
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize('fname', _golden_files())
-@pytest.mark.parametrize('npaths', [0, 1, 3])
+@pytest.mark.parametrize('npaths', [0, 1, 3, -4])
 def test_golden(fname, npaths):
+    """npaths < 0: that many PATCHED paths (psikt's default indexing mode), context = k or k + 5."""
     z = np.load(os.path.join(GOLDEN, fname))
     reads = [str(r) for r in z['reads']]
     k, step = int(z['k']), int(z['step'])
     g = _graph(str(z['graph']))
     f = psi_amd.SeedFinder(g, k)
-    f.create_path_index(npaths, sa_rate=[1, 4, 32][npaths % 3], rng_seed=npaths,
+    patched, npaths = npaths < 0, abs(npaths)
+    f.create_path_index(npaths, sa_rate=[1, 4, 32][npaths % 3], rng_seed=npaths, patched=patched,
+                        context=(k + 5) * (k % 2) if patched else 0,
                         ftab_len=[0, psi_amd.NO_FTAB, 5, 12][(npaths + k) % 4])
     raw = f.seeds_all(reads, step=step)
     assert _eq(psi_amd.sort_unique(raw), z['hits'])
@@ -158,22 +161,30 @@ def _oracle_hits(graph_arrays, finder, bases, off, k, step, gocc=0, threads=2):
     node_id, label_off, labels, edge_off, edge_to = graph_arrays
     og = oracle.OracleGraph(node_id, label_off, bytes(labels), edge_off, edge_to.astype(np.uint64))
     paths = [p.tolist() for p in finder.pindex.paths()]
-    pidx = oracle.OraclePathIndex(og, paths) if paths else None
+    # (head offset, tail length) -> the reference's Path::left / right: lengths of the first / last
+    # node that belong to the path, 0 = all
+    lo64 = np.asarray(label_off, dtype=np.int64)
+    left = [int(lo64[p[0] + 1] - lo64[p[0]]) - h if h else 0 for p, (h, _) in zip(paths, finder.pindex.trims())]
+    right = [t for _, t in finder.pindex.trims()]
+    pidx = oracle.OraclePathIndex(og, paths, left=left, right=right) if paths else None
     ln, lo = finder.get_starting_loci()
     h = oracle.seeds_all(og, pidx, bytes(bases), off, k, step, ln, lo, gocc_thr=gocc, threads=threads)
     return oracle.sort_unique(h)
 
 
 @pytest.mark.parametrize('k,step,npaths,err', [(21, 21, 1, 0.0), (21, 1, 2, 0.01), (31, 31, 4, 0.0),
-                                               (11, 11, 1, 0.0), (16, 5, 0, 0.0)])
+                                               (11, 11, 1, 0.0), (16, 5, 0, 0.0), (21, 21, -3, 0.0), (25, 7, -6, 0.01)])
 def test_snv_graph_vs_oracle(k, step, npaths, err):
+    """npaths < 0: patched paths -- the oracle indexes the same trimmed paths (head offsets and all)."""
     sg = synth.snv_graph(300_000, 9_000, n_block=20_000, seed=k)
     g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to,
                                paths=[sg.ref_path])
     n_reads = 3000 if npaths else 400
     bases, off = synth.sim_reads_snv(sg, n_reads, 150, seed=k + 1, sub_rate=err)
     f = psi_amd.SeedFinder(g, k)
-    f.create_path_index(npaths, rng_seed=2)
+    f.create_path_index(abs(npaths), rng_seed=2, patched=npaths < 0, context=k + 3 if npaths < 0 else 0)
+    if npaths < 0:
+        assert len(f.pindex.paths()) > -npaths and any(h for h, _ in f.pindex.trims())
     got = psi_amd.sort_unique(f.seeds_all((bases, off), step=step))
     want = _oracle_hits((sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to), f, bases, off,
                         k, step)

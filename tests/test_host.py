@@ -134,7 +134,15 @@ def test_index_layout_answers_path_queries(name, k, npaths, sa_rate, ref_data):
                                  ftab_len=[0, psi_amd.NO_FTAB, 3, 7][sa_rate % 4 if sa_rate < 32 else 3])
     paths = [[b.ids[r] for r in p] for p in px.paths()]
     assert len(paths) == npaths * len(b.paths)
-    assert paths[0] == b.paths[0][1]
+    # the first walk of a region follows first out-edges from where its embedded path starts
+    # (Haplotyper at level 0, reference graph_iter.hpp:609-617)
+    first, v = [], b.paths[0][1][0]
+    while True:
+        first.append(v)
+        if not b.out[v]:
+            break
+        v = b.out[v][0]
+    assert paths[0] == first
     emu = IndexEmu(px, g)
     occ = _path_occurrences(b, paths, k)
     # every k-mer of the paths is found exactly where it occurs ...
@@ -201,6 +209,103 @@ def test_starting_loci_equal_brute_force(name, k, npaths, ref_data):
     assert got == brute.uncovered_loci(b, paths, k)
 
 
+# ---------------------------------------------------------------------------------------
+# Path picking and patched paths (reference include/psi/seed_finder.hpp:1138-1167,
+# graph_iter.hpp:537-731, pathindex.hpp:455-560)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('fn', ['tiny.gfa', 'tiny.vg'])
+def test_pick_paths_reference_golden(fn, ref_data):
+    """test/src/test_seedfinder.cpp:46-83: four full paths on the tiny graph -- the first two are the
+    ones the reference asserts, all four are different."""
+    b = brute.parse_gfa(os.path.join(ref_data, 'tiny.gfa'))
+    g = psi_amd.Graph.load(os.path.join(ref_data, fn))
+    for seed in range(5):                          # the RNG only breaks ties the rules leave
+        px = psi_amd.PathIndex.build(g, 30, 4, rng_seed=seed)
+        seqs = [''.join(b.seq[b.ids[r]] for r in p) for p in px.paths()]
+        assert seqs[0] == 'CAAATAAGATTTGAAAATTTTCTGGAGTTCTATAATATACCAACTCTCTG'
+        assert seqs[1] == 'CAAATAAGGCTTGGAAATTTTCTGGAGTTCTATTATATTCCAACTCTCTG'
+        assert len(set(seqs)) == 4
+        assert px.trims() == [(0, 0)] * 4
+
+
+@pytest.mark.parametrize('fn', ['tiny.gfa', 'tiny.vg'])
+def test_patched_paths_starting_loci_reference_golden(fn, ref_data):
+    """test/src/test_seedfinder.cpp:98-163: k = 12, four PATCHED paths with context 12 leave exactly
+    the loci (1,2) .. (1,7), (2,0), (3,0); eight patched paths leave none; 32 full paths leave none."""
+    b = brute.parse_gfa(os.path.join(ref_data, 'tiny.gfa'))
+    g = psi_amd.Graph.load(os.path.join(ref_data, fn))
+    truth = [(1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7), (2, 0), (3, 0)]
+    for seed in range(5):
+        px = psi_amd.PathIndex.build(g, 12, 4, rng_seed=seed, patched=True, context=12)
+        ln, lo = px.loci
+        assert [(b.ids[v], int(o)) for v, o in zip(ln.tolist(), lo.tolist())] == truth
+        assert px.view.context == 12
+        assert any(t != (0, 0) for t in px.trims())          # some paths really are patches
+        # the same loci by the brute-force definition over the trimmed paths
+        paths = [[b.ids[r] for r in p] for p in px.paths()]
+        assert brute.uncovered_loci(b, paths, 12, px.trims()) == truth
+    assert len(psi_amd.PathIndex.build(g, 12, 8, patched=True, context=12).loci[0]) == 0
+    px = psi_amd.PathIndex.build(g, 31, 32)                  # (the reference uses k = 45; 31 is this build's limit)
+    assert len(px.loci[0]) == 0 and len({tuple(p.tolist()) for p in px.paths()}) == 32
+
+
+@pytest.mark.parametrize('name,k,npaths,context', [
+    ('tiny', 10, 3, 0), ('tiny', 12, 5, 14), ('x', 10, 2, 0), ('x', 20, 4, 25), ('x', 12, 6, 12),
+    ('multi', 21, 3, 0), ('multi', 12, 4, 16),
+])
+def test_patched_index_loci_and_text(name, k, npaths, context, ref_data):
+    """Patched indexing on the reference's graphs: loci = brute-force definition over the trimmed
+    paths; the indexed text is exactly the patches' bases; every k-walk of the graph is either spelled by
+    the text at its position or starts at a locus."""
+    b, g = _setup(ref_data, name)
+    px = psi_amd.PathIndex.build(g, k, npaths, rng_seed=5, patched=True, context=context, keep=True)
+    assert px.view.context == (context or k)
+    paths = [[b.ids[r] for r in p] for p in px.paths()]
+    trims = px.trims()
+    ln, lo = px.loci
+    got = [(b.ids[v], int(o)) for v, o in zip(ln.tolist(), lo.tolist())]
+    assert got == brute.uncovered_loci(b, paths, k, trims)
+    # text = patches joined by separators (N runs collapse to one separator too)
+    sym = {0: '#', 1: '$', 2: 'A', 3: 'C', 4: 'G', 5: 'T'}
+    txt = ''.join(sym[int(c)] for c in px.text())
+    want = []
+    for p, (head, tail) in zip(paths, trims):
+        seqs = [b.seq[v] for v in p]
+        if tail:
+            seqs[-1] = seqs[-1][:tail]
+        seqs[0] = seqs[0][head:]
+        want.append(re.sub('[^ACGT]+', '$', ''.join(seqs)))
+    assert txt == '$'.join(want) + '#'
+    # fewer indexed bases than the same walks indexed whole
+    full = psi_amd.PathIndex.build(g, k, npaths, rng_seed=5)
+    assert px.text_len <= full.text_len
+    emu = IndexEmu(px, g)
+    loci = set(got)
+    rng = np.random.default_rng(3)
+    walks = list(brute.all_kwalks(b, k))
+    for i in rng.choice(len(walks), size=min(80, len(walks)), replace=False):
+        km, v, o, _ = walks[i]
+        if 'N' in km:
+            continue
+        l, r = emu.search(km)
+        on_path = (v, o) in {emu.map(emu.locate(j)) for j in range(l, r)}
+        assert on_path or (v, o) in loci
+
+
+def test_build_patches_argument_checks(ref_data):
+    b, g = _setup(ref_data, 'tiny')
+    # single-node path with head >= tail, head beyond the node, wrong array length
+    with pytest.raises(psi_amd.PsiGpuError):
+        psi_amd.PathIndex.build_paths(g, 4, [[0]], head=[5], tail=[3])
+    with pytest.raises(psi_amd.PsiGpuError):
+        psi_amd.PathIndex.build_paths(g, 4, [[0, 1]], head=[100], tail=[0])
+    px = psi_amd.PathIndex.build_paths(g, 4, [[0, 1, 3], [0]], head=[3, 2], tail=[0, 6], keep=True)
+    sym = {0: '#', 1: '$', 2: 'A', 3: 'C', 4: 'G', 5: 'T'}
+    s0 = b.seq[b.ids[0]]
+    assert ''.join(sym[int(c)] for c in px.text()) == s0[3:] + b.seq[b.ids[1]] + b.seq[b.ids[3]] + '$' + s0[2:6] + '#'
+    assert px.trims() == [(3, 0), (2, 6)]
+
+
 def test_starting_loci_step(ref_data):
     b, g = _setup(ref_data, 'x')
     full = psi_amd.PathIndex.build(g, 12, 0, step=1).loci
@@ -237,6 +342,30 @@ def test_layout_plus_loci_reproduce_golden(fname, npaths, golden_dir, ref_data):
                 hits.add((b.ids[v], int(o), r, i))
     want = {tuple(h) for h in z['hits'].tolist()}
     assert hits == want
+
+
+def test_index_file_is_tied_to_graph_seed_length_and_step(tmp_path, ref_data):
+    """load_path_index must not reuse loci computed for another -e / -l / graph
+    (reference seed_finder.hpp:1396-1413 recomputes them; here the file is declared invalid)."""
+    _, g = _setup(ref_data, 'x')
+    _, g2 = _setup(ref_data, 'multi')
+    px = psi_amd.PathIndex.build(g, 12, 2, step=3, patched=True, context=15)
+    prefix = str(tmp_path / 'ix')
+    px.save(prefix)
+    py = psi_amd.PathIndex.load(prefix)
+    assert py.trims() == px.trims() and py.view.context == 15
+    assert py.matches(g, 12, 3)
+    assert not py.matches(g, 12, 1) and not py.matches(g, 13, 3) and not py.matches(g2, 12, 3)
+    # a truncated / corrupted file is rejected, not uploaded
+    raw = open(prefix + '.psigpu', 'rb').read()
+    open(prefix + '.psigpu', 'wb').write(raw[:len(raw) // 2])
+    with pytest.raises(psi_amd.PsiGpuError):
+        psi_amd.PathIndex.load(prefix)
+    bad = bytearray(raw)
+    bad[8 + 24:8 + 32] = (10 ** 9).to_bytes(8, 'little')       # text length in the header
+    open(prefix + '.psigpu', 'wb').write(bytes(bad))
+    with pytest.raises(psi_amd.PsiGpuError):
+        psi_amd.PathIndex.load(prefix)
 
 
 def test_index_save_load_roundtrip(tmp_path, ref_data):
@@ -328,3 +457,32 @@ def test_read_records_formats_and_chunks(records_dump, tmp_path, fmt, chunk):
     want_chunks = 1 if chunk == 0 else -(-len(reads) // chunk)
     assert len(chunks) == want_chunks
     assert [int(c[1]) for c in chunks] == [i * chunk for i in range(want_chunks)]
+
+
+# ---------------------------------------------------------------------------------------
+# psi::Path / psi::PathIndex shim (psi_amd/include/psi/pathindex.hpp) against the reference's own
+# numbers (test/src/test_pathindex.cpp:94-288)
+# ---------------------------------------------------------------------------------------
+def test_pathindex_shim_reference_golden(tmp_path, ref_data):
+    import subprocess
+    exe = str(tmp_path / 'pathindex_api')
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-I' + os.path.join(ROOT, 'include'),
+                           '-I' + os.path.join(ROOT, 'psi_amd', 'include'),
+                           os.path.join(ROOT, 'tests', 'cpp', 'pathindex_api.cpp'), '-o', exe,
+                           '-L' + os.path.join(ROOT, 'psi_amd'), '-lpsi_gpu', '-lz',
+                           '-Wl,-rpath,' + os.path.join(ROOT, 'psi_amd')])
+    out = subprocess.check_output([exe, os.path.join(ref_data, 'x.gfa'), str(tmp_path / 'px')]).decode().split('\n')
+    kv = [l.split(' ', 1) for l in out if l]
+    get = lambda key: [v for k_, v in kv if k_ == key]
+    assert get('seqlen') == ['54'] and get('length') == ['4'] and get('plen') == ['1']          # :108-109
+    assert get('fwd') == ['0 205 0', '14 205 14', '26 205 26', '27 207 0', '30 207 3', '51 207 24',
+                          '52 209 0', '53 210 0']                                                  # :118-133
+    trimmed = ['GTTTCCTGTACTAAGGACAAAGGTGCGGGGAGATAA', 'CAAGGGCTTTTAA', 'CATTTGTCTTATTGTCCAGGA']       # :166-168
+    assert get('text') == ['$'.join(trimmed) + '#']
+    assert get('pathseq') == trimmed
+    assert get('context') == ['10']
+    assert get('fwd2') == ['10 171 0', '11 172 0', '12 174 0', '20 174 8']                         # :236-243
+    assert get('rev0') == ['0 210 0', '1 209 0', '2 207 24', '20 207 6', '26 207 0', '27 205 26',
+                           '29 205 24', '35 205 18']                                               # :266-281
+    assert get('covered') == ['1 0 1']
+    assert get('loaded') == ['3 ' + ' '.join(trimmed)]
