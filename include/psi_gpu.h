@@ -203,6 +203,15 @@ int psigpu_index_path_trim(const psigpu_index* x, uint64_t i, uint32_t* head_off
  * starting loci when its loci file does not match: seed_finder.hpp:1396-1413, utils.hpp:521-566;
  * here a mismatch means "no valid index": the caller builds a new one.)  1 = yes. */
 int psigpu_index_matches(const psigpu_index* x, const psigpu_graph* g, uint32_t seed_len, uint32_t locus_step);
+uint32_t psigpu_index_locus_step(const psigpu_index* x);
+/* The reference's own starting-loci file `<prefix>_loci_e<E>l<K>` (SeedFinder::save_starts /
+ * open_starts, seed_finder.hpp:1640-1679; container serialisation utils.hpp:521-588): u64 count, then
+ * raw psi::Position<> records { node id (external), offset } -- 8 + 8 bytes each, gum's id and offset
+ * types (gum is not in the reference tree; a file that does not have this size is rejected).
+ * save writes the index's loci for its (k, locus step); load replaces the index's loci by the file
+ * made for (index k, locus_step) -- e.g. one written by the reference for the same paths. */
+int psigpu_loci_save(const psigpu_index* x, const psigpu_graph* g, const char* prefix);
+int psigpu_loci_load(psigpu_index* x, const psigpu_graph* g, const char* prefix, uint32_t locus_step);
 const uint8_t* psigpu_index_text(const psigpu_index* x);      /* NULL unless kept */
 const int32_t* psigpu_index_sa(const psigpu_index* x);        /* NULL unless kept */
 /* Host helper: suffix array of a 0-terminated symbol string (own SA-IS). */
@@ -278,6 +287,26 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
                       uint64_t n_reads, uint32_t k, uint32_t step, uint64_t rec_offset,
                       uint32_t flags, psigpu_hits* out);
 void psigpu_free_hits(psigpu_hits* hits);
+
+/* MEM mode -- SeedFinder::seeds_on_paths( sequence, callback ) -> find_mems
+ * (seed_finder.hpp:1459-1479, index_iter.hpp:854-906): per read, from `start` the pattern grows
+ * base by base while it still occurs on the indexed paths; once it is at least `minlen` long and has
+ * at most gocc_threshold occurrences (psigpu_set_gocc_threshold), every occurrence is reported
+ * (read_offset = start, match_len = pattern length, gocc = number of occurrences) and the search
+ * restarts one base behind the pattern's end; a base that cannot be appended, or an N, restarts it
+ * one base behind that base; `max_mem` (psikt -E, 0 = unlimited) ends a read once that many records
+ * are out.  Records are the reference's psi::Seed<> (seed.hpp:32-46), ordered by (read_id,
+ * read_offset, node_id, node_offset).  Needs an index with sa_rate 1 (the default). */
+typedef struct psigpu_mem_hit {
+  uint64_t node_id, node_offset, read_id, read_offset, match_len, gocc;
+} psigpu_mem_hit;
+typedef struct psigpu_mems {
+  uint64_t n;
+  psigpu_mem_hit* data;   /* library-owned pinned host memory; release with psigpu_free_mems */
+} psigpu_mems;
+int psigpu_find_mems(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off, uint64_t n_reads,
+                     uint32_t minlen, uint32_t max_mem, uint64_t rec_offset, psigpu_mems* out);
+void psigpu_free_mems(psigpu_mems* mems);
 
 /* Pinned (page-locked) host memory for read chunks: what the reference keeps in
  * Records / seqan2::StringSet (sequence.hpp:1130-1294) the caller keeps here, and the copy

@@ -302,3 +302,74 @@ def uncovered_loci(g: Graph, paths: Iterable[Sequence[int]], k: int,
             out.add((v, o))
     rank = {v: i for i, v in enumerate(g.ids)}
     return sorted(out, key=lambda t: (rank[t[0]], t[1]))
+
+
+def path_texts(g: Graph, paths: Iterable[Sequence[int]], trims: Sequence[Tuple[int, int]] = ()):
+    """The indexed (forward) text of every path with the graph position of each base:
+    [(text, [(node, offset) per base])].  Trimmed as Path::left / right trim a patch
+    (reference include/psi/path_base.hpp:113-114, :240-246)."""
+    paths = [list(p) for p in paths]
+    trims = list(trims) + [(0, 0)] * (len(paths) - len(trims))
+    out = []
+    for p, (head, tail) in zip(paths, trims):
+        txt, pos = [], []
+        for i, v in enumerate(p):
+            s = g.seq[v]
+            b = head if i == 0 else 0
+            e = tail if (i + 1 == len(p) and tail) else len(s)
+            for o in range(b, e):
+                txt.append(s[o])
+                pos.append((v, o))
+        out.append((''.join(txt), pos))
+    return out
+
+
+def find_mems(g: Graph, paths: Iterable[Sequence[int]], reads: Sequence[str], minlen: int,
+              trims: Sequence[Tuple[int, int]] = (), gocc_thr: int = 0, max_mem: int = 0,
+              rec_offset: int = 0) -> List[Tuple[int, int, int, int, int, int]]:
+    """find_mems of the reference (include/psi/index_iter.hpp:854-906) as driven by
+    SeedFinder::seeds_on_paths( sequence, callback ) (seed_finder.hpp:1459-1479), with naive
+    substring search standing in for the index iterator: go_down( c ) succeeds iff pattern + c
+    occurs in a path text; count_occurrences = number of occurrences over all paths.
+    Returns sorted (node_id, node_offset, read_id, read_offset, match_len, gocc)."""
+    texts = path_texts(g, paths, trims)
+    gocc_thr = gocc_thr or (1 << 62)
+    max_mem = max_mem or (1 << 62)
+
+    def occurrences(pat: str):
+        occ = []
+        for txt, pos in texts:
+            i = txt.find(pat)
+            while i >= 0:
+                occ.append(pos[i])
+                i = txt.find(pat, i + 1)
+        return occ
+
+    n_total = sum(len(t) for t, _ in texts)
+    out = []
+    for rid, pattern in enumerate(reads):
+        pattern = pattern.upper()
+        start = plen = 0
+        has_hit = False
+        nof = 0
+        occ = None                      # occurrences of pattern[start:start+plen]; None = root (everything)
+        while start + plen < len(pattern):
+            cnt = n_total if occ is None else len(occ)
+            if plen >= minlen and cnt <= gocc_thr:
+                has_hit = True
+                for v, o in occ:
+                    out.append((v, o, rid + rec_offset, start, plen, len(occ)))
+                nof += len(occ)
+                if nof >= max_mem:
+                    break
+            c = pattern[start + plen]
+            nxt = None
+            if not has_hit and c in 'ACGT':
+                nxt = occurrences(pattern[start:start + plen + 1])
+            if not nxt:
+                occ = None
+                start, plen, has_hit = start + plen + 1, 0, False
+                continue
+            occ = nxt
+            plen += 1
+    return sorted(out, key=lambda t: (t[2], t[3], t[0], t[1]))

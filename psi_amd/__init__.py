@@ -33,6 +33,15 @@ class Hits(C.Structure):
     _fields_ = [('n', C.c_uint64), ('data', C.POINTER(Hit))]
 
 
+class MemHit(C.Structure):
+    _fields_ = [('node_id', C.c_uint64), ('node_offset', C.c_uint64), ('read_id', C.c_uint64),
+                ('read_offset', C.c_uint64), ('match_len', C.c_uint64), ('gocc', C.c_uint64)]
+
+
+class Mems(C.Structure):
+    _fields_ = [('n', C.c_uint64), ('data', C.POINTER(MemHit))]
+
+
 class GraphView(C.Structure):
     _fields_ = [('n_nodes', C.c_uint64), ('node_id', C.c_void_p), ('label_off', C.c_void_p),
                 ('labels', C.c_void_p), ('edge_off', C.c_void_p), ('edge_to', C.c_void_p)]
@@ -97,6 +106,9 @@ ABI = [
     ('psigpu_index_build_patches', _P, [_P, C.POINTER(IndexOpts), C.c_uint64, _P, _P, _P, _P, _INTP]),
     ('psigpu_index_path_trim', C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ('psigpu_index_matches', C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
+    ('psigpu_index_locus_step', C.c_uint32, [_P]),
+    ('psigpu_loci_save', C.c_int, [_P, _P, C.c_char_p]),
+    ('psigpu_loci_load', C.c_int, [_P, _P, C.c_char_p, C.c_uint32]),
     ('psigpu_index_free', None, [_P]),
     ('psigpu_index_view_get', C.c_int, [_P, C.POINTER(IndexView)]),
     ('psigpu_index_save', C.c_int, [_P, C.c_char_p]),
@@ -119,6 +131,8 @@ ABI = [
     ('psigpu_find_seeds_device', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_uint64, C.c_uint32, _P, C.POINTER(_P), _U64P]),
     ('psigpu_get_counters', C.c_int, [_P, C.POINTER(Counters)]),
+    ('psigpu_find_mems', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Mems)]),
+    ('psigpu_free_mems', None, [C.POINTER(Mems)]),
     ('psigpu_prepare', C.c_int, [_P, C.c_uint32]),
     ('psigpu_copy_hits', C.c_int, [_P, _P, _P, C.c_uint64]),
     ('psigpu_host_alloc', _P, [C.c_uint64]),
@@ -387,6 +401,18 @@ class PathIndex:
             out.append((a.value, b.value))
         return out
 
+    def save_loci(self, g: Graph, prefix: str) -> None:
+        """`<prefix>_loci_e<E>l<K>` in the reference's format (SeedFinder::save_starts)."""
+        if lib().psigpu_loci_save(self.h, g.h, prefix.encode()):
+            raise PsiGpuError('cannot write the loci file')
+
+    def load_loci(self, g: Graph, prefix: str, step: int = 1) -> None:
+        """Replace the starting loci by those of `<prefix>_loci_e<step>l<K>` (SeedFinder::open_starts)."""
+        st = lib().psigpu_loci_load(self.h, g.h, prefix.encode(), step)
+        if st:
+            raise PsiGpuError('cannot read the loci file (%d): %s' % (st, _host_err()))
+        lib().psigpu_index_view_get(self.h, C.byref(self.view))
+
     def matches(self, g: Graph, k: int, step: int = 1) -> bool:
         return bool(lib().psigpu_index_matches(self.h, g.h, k, step))
 
@@ -510,6 +536,27 @@ class SeedFinder:
 
     def seeds_off_paths(self, reads, step: int = 0, rec_offset: int = 0):
         return self._find(reads, step, rec_offset, OFF_PATHS)
+
+    def find_mems(self, reads, max_mem: int = 0, rec_offset: int = 0) -> np.ndarray:
+        """SeedFinder::seeds_on_paths( sequence, callback ) for every read (reference
+        seed_finder.hpp:1459-1479 -> find_mems, index_iter.hpp:854-906), minimum length = seed length.
+        Returns an (n, 6) uint64 array: node_id, node_offset, read_id, read_offset, match_len, gocc."""
+        if isinstance(reads, tuple):
+            bases, off = reads
+        else:
+            bases, off = pack_reads(reads)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        out = Mems()
+        self._chk(lib().psigpu_find_mems(self.ctx, _ptr(bases), _ptr(off), len(off) - 1, self.seed_len, max_mem,
+                                         rec_offset, C.byref(out)))
+        if out.n:
+            buf = (C.c_uint64 * (6 * out.n)).from_address(C.addressof(out.data.contents))
+            arr = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 6).copy()
+        else:
+            arr = np.zeros((0, 6), np.uint64)
+        lib().psigpu_free_mems(C.byref(out))
+        return arr
 
     def seeds_all_device(self, d_bases_ptr: int, d_read_off_ptr: int, n_reads: int, n_bases: int,
                          step: int = 0, rec_offset: int = 0, flags: int = ALL, stream: int = 0):

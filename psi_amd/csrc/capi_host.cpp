@@ -1,7 +1,11 @@
 // C entry points of the host side (graph loading, index construction); see
 // include/psi_gpu.h for what each one replaces in the reference.
+#include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
+#include <vector>
 
 #include "host.hpp"
 #include "sais.hpp"
@@ -226,6 +230,76 @@ int psigpu_index_matches(const psigpu_index* h, const psigpu_graph* g, uint32_t 
   if (!h || !g) return 0;
   if (locus_step == 0) locus_step = 1;
   return h->x.k == seed_len && h->x.locus_step == locus_step && h->x.graph_fp == graph_fingerprint(g->g);
+}
+
+uint32_t psigpu_index_locus_step(const psigpu_index* h) { return h ? h->x.locus_step : 0; }
+
+// `<prefix>_loci_e<E>l<K>`: the reference's starting-loci file (SeedFinder::save_starts / open_starts,
+// seed_finder.hpp:1640-1679; get_sloci_filepath; psi::serialize of a container, utils.hpp:521-588):
+// u64 count, then `count` raw psi::Position<> = { gum id_type node id, gum offset_type offset } with
+// EXTERNAL node ids (coordinate_id on the way out, id_by_coordinate on the way in).  gum is not in the
+// reference tree; its GraphBaseTrait types are taken as int64_t / uint64_t (16 bytes per locus), and a
+// file whose size does not fit that layout is rejected.
+static std::string loci_path(const char* prefix, uint32_t k, uint32_t step)
+{
+  return std::string(prefix) + "_loci_e" + std::to_string(step) + "l" + std::to_string(k);
+}
+
+int psigpu_loci_save(const psigpu_index* h, const psigpu_graph* g, const char* prefix)
+{
+  if (!h || !g || !prefix) return PSIGPU_ERR_ARG;
+  const Index& x = h->x;
+  FILE* f = fopen(loci_path(prefix, x.k, x.locus_step).c_str(), "wb");
+  if (!f) return PSIGPU_ERR_IO;
+  uint64_t n = x.loci_node.size();
+  bool ok = fwrite(&n, 8, 1, f) == 1;
+  for (uint64_t i = 0; ok && i < n; ++i) {
+    if (x.loci_node[i] >= g->g.n_nodes()) { ok = false; break; }
+    int64_t id = (int64_t)g->g.node_id[x.loci_node[i]];
+    uint64_t off = x.loci_off[i];
+    ok = fwrite(&id, 8, 1, f) == 1 && fwrite(&off, 8, 1, f) == 1;
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? PSIGPU_OK : PSIGPU_ERR_IO;
+}
+
+int psigpu_loci_load(psigpu_index* h, const psigpu_graph* g, const char* prefix, uint32_t locus_step)
+{
+  if (!h || !g || !prefix) return PSIGPU_ERR_ARG;
+  if (locus_step == 0) locus_step = 1;
+  Index& x = h->x;
+  FILE* f = fopen(loci_path(prefix, x.k, locus_step).c_str(), "rb");
+  if (!f) return PSIGPU_ERR_IO;
+  uint64_t n = 0;
+  bool ok = fread(&n, 8, 1, f) == 1;
+  if (ok) {
+    fseek(f, 0, SEEK_END);
+    ok = (uint64_t)ftell(f) == 8 + 16 * n;           // the assumed Position<> layout
+    fseek(f, 8, SEEK_SET);
+  }
+  std::vector<std::pair<uint32_t, uint32_t>> loci;
+  if (ok) {
+    std::unordered_map<uint64_t, uint32_t> rank;
+    rank.reserve(g->g.n_nodes() * 2);
+    for (uint64_t v = 0; v < g->g.n_nodes(); ++v) rank.emplace(g->g.node_id[v], (uint32_t)v);
+    loci.reserve(n);
+    for (uint64_t i = 0; ok && i < n; ++i) {
+      int64_t id; uint64_t off;
+      ok = fread(&id, 8, 1, f) == 1 && fread(&off, 8, 1, f) == 1;
+      if (!ok) break;
+      auto it = rank.find((uint64_t)id);
+      ok = it != rank.end() && off < g->g.node_len(it->second);
+      if (ok) loci.emplace_back(it->second, (uint32_t)off);
+    }
+  }
+  fclose(f);
+  if (!ok) { g_host_err = "not a starting-loci file of this graph"; return PSIGPU_ERR_FORMAT; }
+  std::sort(loci.begin(), loci.end());            // by node rank, then offset (seed_finder.hpp:1695-1722 groups by node)
+  loci.erase(std::unique(loci.begin(), loci.end()), loci.end());
+  x.loci_node.resize(loci.size()); x.loci_off.resize(loci.size());
+  for (size_t i = 0; i < loci.size(); ++i) { x.loci_node[i] = loci[i].first; x.loci_off[i] = loci[i].second; }
+  x.locus_step = locus_step;
+  return PSIGPU_OK;
 }
 
 const uint8_t* psigpu_index_text(const psigpu_index* x)

@@ -2110,6 +2110,105 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
 }
 
 // ------------------------------------------------------------------------------------
+// MEM mode: SeedFinder::seeds_on_paths( sequence, callback ) -> find_mems
+// (reference include/psi/seed_finder.hpp:1459-1479, include/psi/index_iter.hpp:854-906).
+// Per read, the reference walks its path-index iterator FORWARD through the read: from `start` it
+// appends bases while the pattern still occurs on the indexed paths; the first time the pattern is
+// at least `minlen` long and has at most gocc_threshold occurrences, every occurrence is a hit
+// (read_offset = start, match_len = the pattern length, gocc = the number of occurrences) and the
+// search starts again one base behind the end of the pattern; a base that cannot be appended (or an
+// N) also restarts it, one base behind that base.  max_mem stops a read once that many hits are out.
+//
+// The reference can append because it indexes the REVERSED text; this index is over the forward text,
+// whose FM half only prepends.  Appending is done on the suffix array instead: the rows whose suffix
+// starts with the pattern are an interval, and the sub-interval whose next symbol is c is found by
+// two bisections over (SA[row] + depth)-th text symbols (whole SA + 4-bit text resident: sa_rate 1).
+// One lane per read: the walk is sequential inside a read and independent across reads.
+// ------------------------------------------------------------------------------------
+struct MemGroup { uint32_t read, start, plen, lo, cnt; };      // one reported pattern: SA rows [lo, lo + cnt)
+
+__device__ __forceinline__ int text_sym(const uint64_t* __restrict__ text4, uint64_t n, uint64_t pos)
+{
+  if (pos >= n) return -1;
+  const uint32_t nib = (uint32_t)(text4[pos >> 4] >> (60 - 4 * (pos & 15))) & 0xFu;
+  return (nib & 4u) ? -1 : (int)(nib & 3u);        // separators / the sentinel sort in front of every base
+}
+
+// first row in [lo, hi) whose symbol at depth `d` is >= c  (rows of one interval are ordered by it)
+__device__ __forceinline__ uint32_t mem_lower(const uint32_t* __restrict__ sa, const uint64_t* __restrict__ text4, uint64_t n,
+                                              uint32_t lo, uint32_t hi, uint32_t d, int c)
+{
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (text_sym(text4, n, (uint64_t)sa[mid] + d) < c) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(64)
+k_find_mems(const char* __restrict__ bases, const uint64_t* __restrict__ read_off, uint64_t n_reads,
+            const uint32_t* __restrict__ sa, const uint64_t* __restrict__ text4, uint32_t n, uint32_t minlen,
+            uint32_t gocc_thr, uint32_t max_mem, MemGroup* __restrict__ groups, uint64_t cap_groups,
+            unsigned long long* __restrict__ n_groups, unsigned long long* __restrict__ n_hits)
+{
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const char* pat = bases + read_off[r];
+  const uint64_t len = read_off[r + 1] - read_off[r];
+  uint64_t start = 0, nof = 0;
+  uint32_t plen = 0, lo = 0, hi = n;
+  bool has_hit = false;
+  while (start + plen < len) {
+    if (plen >= minlen && hi - lo <= gocc_thr) {
+      has_hit = true;
+      const unsigned long long g = atomicAdd(n_groups, 1ull);
+      atomicAdd(n_hits, (unsigned long long)(hi - lo));
+      if (g < cap_groups) groups[g] = MemGroup{ (uint32_t)r, (uint32_t)start, plen, lo, hi - lo };
+      nof += hi - lo;
+      if (nof >= max_mem) break;
+    }
+    bool ok = false;
+    if (!has_hit) {
+      const int c = base2(pat[start + plen]);
+      if (c >= 0) {
+        const uint32_t a = mem_lower(sa, text4, n, lo, hi, plen, c);
+        const uint32_t b = mem_lower(sa, text4, n, a, hi, plen, c + 1);
+        if (b > a) { lo = a; hi = b; ok = true; }
+      }
+    }
+    if (!ok) { lo = 0; hi = n; start += (uint64_t)plen + 1; plen = 0; has_hit = false; continue; }
+    ++plen;
+  }
+}
+
+struct MemHit { uint64_t node_id, node_offset, read_id, read_offset, match_len, gocc; };
+static_assert(sizeof(MemHit) == sizeof(psigpu_mem_hit), "MEM record layout");
+
+__global__ void __launch_bounds__(256)
+k_mem_locate(const MemGroup* __restrict__ groups, const uint64_t* __restrict__ group_off, uint64_t n_groups,
+             const uint32_t* __restrict__ sa, const SegRec* __restrict__ seg, const uint32_t* __restrict__ seg_dir,
+             uint64_t rec_offset, MemHit* __restrict__ out)
+{
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const MemGroup mg = groups[g];
+  MemHit* dst = out + group_off[g];
+  for (uint32_t i = 0; i < mg.cnt; ++i) {
+    const uint32_t pos = sa[mg.lo + i];
+    uint32_t d = seg_dir[pos >> DIR_SHIFT];
+    while (seg[d + 1].start <= pos) ++d;
+    const SegRec sr = seg[d];
+    dst[i] = MemHit{ sr.node_id, (uint64_t)sr.noff + (pos - sr.start), rec_offset + mg.read, mg.start, mg.plen, mg.cnt };
+  }
+}
+
+__global__ void k_mem_counts(const MemGroup* __restrict__ groups, uint64_t n, uint32_t* __restrict__ cnt)
+{
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n) cnt[g] = groups[g].cnt;
+}
+
+// ------------------------------------------------------------------------------------
 // Host-side plumbing
 // ------------------------------------------------------------------------------------
 struct DevBuf {
@@ -3297,6 +3396,85 @@ int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_
     *n_hits = n;
   }
   return PSIGPU_OK;
+}
+
+int psigpu_find_mems(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off, uint64_t n_reads, uint32_t minlen,
+                     uint32_t max_mem, uint64_t rec_offset, psigpu_mems* out)
+{
+  if (!ctx || !out || (n_reads && (!read_off || !bases))) return PSIGPU_ERR_ARG;
+  out->n = 0; out->data = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
+  if (minlen == 0) { ctx->err = "minimum match length must be positive"; return PSIGPU_ERR_ARG; }
+  if (n_reads >= 0xFFFFFFF0ull) { ctx->err = "too many reads in one chunk"; return PSIGPU_ERR_ARG; }
+  if (n_reads == 0 || ctx->n_paths == 0) return PSIGPU_OK;        // length( indexText ) == 0: nothing on paths (:1467)
+  if (ctx->sa_rate != 1 || !ctx->have_text4) {
+    ctx->err = "MEM mode needs the whole suffix array and the text on the device (sa_rate 1)";
+    return PSIGPU_ERR_STATE;
+  }
+  const uint64_t n_bases = read_off[n_reads];
+  for (uint64_t r = 0; r < n_reads; ++r)
+    if (read_off[r + 1] - read_off[r] >= 0xFFFFFFF0ull) { ctx->err = "read too long"; return PSIGPU_ERR_ARG; }
+  HIPCHK(ctx, ctx->w_bases.ensure(n_bases + 64));
+  HIPCHK(ctx, ctx->w_read_off.ensure((n_reads + 1) * 8));
+  if (n_bases) HIPCHK(ctx, hipMemcpy(ctx->w_bases.p, bases, n_bases, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->w_read_off.p, read_off, (n_reads + 1) * 8, hipMemcpyHostToDevice));
+  TmpBuf groups, ctr, cnt, goff, tiles, hits;
+  HIPCHK(ctx, ctr.alloc(64));
+  const uint32_t thr = ctx->gocc_thr ? ctx->gocc_thr : 0xFFFFFFFFu;
+  const uint32_t mm = max_mem ? max_mem : 0xFFFFFFFFu;
+  uint64_t cap_groups = n_bases / std::max<uint32_t>(1, minlen) + n_reads + 1024;      // a group consumes at least minlen + 1 bases
+  unsigned long long h[2] = { 0, 0 };
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    HIPCHK(ctx, groups.alloc(cap_groups * sizeof(MemGroup)));
+    HIPCHK(ctx, hipMemset(ctr.p, 0, 64));
+    k_find_mems<<<(unsigned)((n_reads + 63) / 64), 64>>>(ctx->w_bases.as<char>(), ctx->w_read_off.as<uint64_t>(), n_reads,
+                                                         ctx->samples.as<uint32_t>(), ctx->text4.as<uint64_t>(),
+                                                         (uint32_t)ctx->text_len, minlen, thr, mm, groups.as<MemGroup>(), cap_groups,
+                                                         ctr.as<unsigned long long>(), ctr.as<unsigned long long>() + 1);
+    HIPCHK(ctx, hipMemcpy(h, ctr.p, 16, hipMemcpyDeviceToHost));
+    if (h[0] <= cap_groups) break;
+    if (attempt) { ctx->err = "MEM group buffer overflow"; return PSIGPU_ERR_NOMEM; }
+    cap_groups = h[0] + 16;
+  }
+  const uint64_t n_groups = h[0], n_hits = h[1];
+  if (n_hits == 0) return PSIGPU_OK;
+  // group sizes -> offsets, then one record per occurrence
+  const uint64_t n_tiles = n_groups / SCAN_TILE + 1;
+  HIPCHK(ctx, cnt.alloc((n_groups + 1) * 4));
+  HIPCHK(ctx, goff.alloc((n_groups + 2) * 8));
+  HIPCHK(ctx, tiles.alloc(n_tiles * 8));
+  HIPCHK(ctx, hits.alloc(n_hits * sizeof(MemHit)));
+  k_mem_counts<<<(unsigned)((n_groups + 255) / 256), 256>>>(groups.as<MemGroup>(), n_groups, cnt.as<uint32_t>());
+  k_scan_tiles<<<(unsigned)n_tiles, SCAN_THREADS>>>(cnt.as<uint32_t>(), n_groups, tiles.as<uint64_t>());
+  k_scan_sums<<<1, SCAN_THREADS>>>(tiles.as<uint64_t>(), n_tiles, ctr.as<uint64_t>() + 2);
+  k_scan_final<<<(unsigned)n_tiles, SCAN_THREADS>>>(cnt.as<uint32_t>(), n_groups, tiles.as<uint64_t>(), goff.as<uint64_t>());
+  k_mem_locate<<<(unsigned)((n_groups + 255) / 256), 256>>>(groups.as<MemGroup>(), goff.as<uint64_t>(), n_groups,
+                                                            ctx->samples.as<uint32_t>(), ctx->seg.as<SegRec>(),
+                                                            ctx->seg_dir.as<uint32_t>(), rec_offset, hits.as<MemHit>());
+  psigpu_mem_hit* hp = (psigpu_mem_hit*)g_pinned.get(n_hits * sizeof(psigpu_mem_hit));
+  if (!hp) { ctx->err = "cannot allocate pinned host memory for the hits"; return PSIGPU_ERR_NOMEM; }
+  hipError_t e = hipMemcpy(hp, hits.p, n_hits * sizeof(psigpu_mem_hit), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { g_pinned.put(hp); ctx->err = hipGetErrorString(e); return PSIGPU_ERR_DEVICE; }
+  // the order groups were appended in depends on scheduling: hand the records out in the order the
+  // reference's loop produces them per read -- (read, read offset) -- and by position inside a group
+  std::sort(hp, hp + n_hits, [](const psigpu_mem_hit& a, const psigpu_mem_hit& b) {
+    if (a.read_id != b.read_id) return a.read_id < b.read_id;
+    if (a.read_offset != b.read_offset) return a.read_offset < b.read_offset;
+    if (a.node_id != b.node_id) return a.node_id < b.node_id;
+    return a.node_offset < b.node_offset;
+  });
+  out->data = hp;
+  out->n = n_hits;
+  return PSIGPU_OK;
+}
+
+void psigpu_free_mems(psigpu_mems* mems)
+{
+  if (!mems) return;
+  if (mems->data) g_pinned.put(mems->data);
+  mems->data = nullptr;
+  mems->n = 0;
 }
 
 int psigpu_copy_hits(psigpu_ctx* ctx, psigpu_hit* host_dst, const psigpu_hit* d_src, uint64_t n)

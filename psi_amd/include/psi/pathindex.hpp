@@ -191,6 +191,17 @@ namespace psi {
       return psigpu_index_save( h_, prefix.c_str() ) == PSIGPU_OK;
     }
 
+    /** `<prefix>_loci_e<E>l<K>` in the reference's format (SeedFinder::save_starts / open_starts,
+     *  seed_finder.hpp:1640-1679). */
+    bool save_loci( std::string const& prefix ) const
+    { return h_ && graph_ptr && psigpu_loci_save( h_, graph_ptr->handle(), prefix.c_str() ) == PSIGPU_OK; }
+    bool load_loci( std::string const& prefix, unsigned int step_size )
+    {
+      if ( !h_ || !graph_ptr || psigpu_loci_load( h_, graph_ptr->handle(), prefix.c_str(), step_size ) != PSIGPU_OK ) return false;
+      psigpu_index_view_get( h_, &view_ );
+      return true;
+    }
+
     psigpu_index_view const& view() const { return view_; }
     psigpu_index const* handle() const { return h_; }
     void clear() { reset( nullptr ); paths_set.clear(); }

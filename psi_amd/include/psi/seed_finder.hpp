@@ -134,8 +134,12 @@ namespace psi {
     {
       if ( !pindex.load( prefix ) ) return false;
       if ( !psigpu_index_matches( pindex.handle(), graph_ptr->handle(), seed_len, step_size ) ) {
-        pindex.clear();
-        return false;
+        /* same graph and seed length, other locus step: the paths are still good when a loci file
+         * for this step lies beside the index (open_starts, reference :1640-1657) */
+        bool ok = psigpu_index_matches( pindex.handle(), graph_ptr->handle(), seed_len,
+                                        psigpu_index_locus_step( pindex.handle() ) ) &&
+                  pindex.load_loci( prefix, step_size );
+        if ( !ok ) { pindex.clear(); return false; }
       }
       check( psigpu_load_index( ctx, &pindex.view() ) );
       check( psigpu_prepare( ctx, seed_len ) );
@@ -145,7 +149,7 @@ namespace psi {
 
     /** serialize_path_index( prefix, step ) -> bool (reference :1372-1394). */
     bool serialize_path_index( std::string const& prefix, unsigned int /*step_size*/ = 1 )
-    { return pindex.serialize( prefix ); }
+    { return pindex.serialize( prefix ) && pindex.save_loci( prefix ); }      /* + save_starts (:1659-1679) */
 
     /* ---- per chunk ---------------------------------------------------------------------- */
     readsrecord_type create_readrecord() const { return readsrecord_type(); }
@@ -163,6 +167,24 @@ namespace psi {
     /** seeds_on_paths( reads, reads_index, callback ) (reference :1426-1457). */
     void seeds_on_paths( SeedsRecord const& seeds, readsindex_type&, callback_type callback ) const
     { run( seeds, PSIGPU_ON_PATHS, callback ); }
+
+    /** seeds_on_paths( sequence, callback ) (reference :1459-1479): MEM mode -- find_mems
+     *  (index_iter.hpp:854-906) with minimum length = seed length, the finder's gocc threshold and
+     *  max_mem.  The callback gets psi::Seed<> with match_len and gocc filled; read_id is 0. */
+    void seeds_on_paths( std::string const& sequence, callback_type callback ) const
+    {
+      std::uint64_t off[ 2 ] = { 0, sequence.size() };
+      psigpu_mems mems{};
+      check( psigpu_find_mems( ctx, sequence.data(), off, 1, seed_len, max_mem, 0, &mems ) );
+      output_type h{};
+      for ( std::uint64_t i = 0; i < mems.n; ++i ) {
+        h.node_id = mems.data[ i ].node_id; h.node_offset = mems.data[ i ].node_offset;
+        h.read_id = mems.data[ i ].read_id; h.read_offset = mems.data[ i ].read_offset;
+        h.match_len = mems.data[ i ].match_len; h.gocc = mems.data[ i ].gocc;
+        callback( h );
+      }
+      psigpu_free_mems( &mems );
+    }
 
     /** setup_traverser( traverser, reads, reads_index ) (reference :1695-1701). */
     void setup_traverser( traverser_type& traverser, SeedsRecord const& seeds, readsindex_type& ) const

@@ -726,3 +726,38 @@ def test_device_entry_sort_unique_and_prepare():
     assert n == len(want) == f.counters()['n_hits']
     assert _eq(f.copy_hits(ptr, n), want)
     f.close()
+
+
+# ---------------------------------------------------------------------------------------
+# MEM mode: find_mems, reference include/psi/index_iter.hpp:854-906
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,minlen,npaths,patched,gocc,max_mem', [
+    ('x', 12, 1, False, 0, 0), ('x', 21, 3, False, 0, 0), ('x', 8, 2, True, 0, 0), ('x', 6, 2, False, 3, 0),
+    ('tiny', 5, 2, False, 0, 4), ('multi', 15, 2, True, 0, 2), ('tiny', 3, 4, False, 2, 0),
+])
+def test_find_mems_vs_brute(name, minlen, npaths, patched, gocc, max_mem):
+    """Greedy forward matching per read against the brute-force restatement (naive substring search over
+    the indexed path texts): restarts behind hits, mismatches and N; gocc threshold; max_mem."""
+    from oracle import brute
+    import random
+    b = brute.parse_gfa(os.path.join(REF, name + '.gfa'))
+    g = _graph(name + '.gfa')
+    f = psi_amd.SeedFinder(g, minlen, gocc_threshold=gocc)
+    f.create_path_index(npaths, rng_seed=1, patched=patched, context=minlen + 4 if patched else 0)
+    paths = [[b.ids[r] for r in p] for p in f.pindex.paths()]
+    rng = random.Random(7)
+    reads = []
+    walk = ''.join(b.seq[v] for v in paths[0])
+    for _ in range(60):
+        a = rng.randrange(max(1, len(walk) - 80))
+        r = list(walk[a:a + rng.randint(1, 80)])
+        for _ in range(rng.choice([0, 0, 1, 2, 4])):                  # substitutions, some to N
+            r[rng.randrange(len(r))] = rng.choice('ACGTN')
+        reads.append(''.join(r))
+    reads += ['', 'N', 'ACGT', walk[:minlen], walk[:minlen + 1], walk[5:5 + 2 * minlen + 3].lower()]
+    got = f.find_mems(reads, max_mem=max_mem, rec_offset=9)
+    want = np.array(brute.find_mems(b, paths, reads, minlen, f.pindex.trims(), gocc, max_mem, rec_offset=9),
+                    dtype=np.uint64).reshape(-1, 6)
+    assert len(want) > 10
+    assert _eq(got, want)
+    f.close()

@@ -368,6 +368,41 @@ def test_index_file_is_tied_to_graph_seed_length_and_step(tmp_path, ref_data):
         psi_amd.PathIndex.load(prefix)
 
 
+def test_reference_loci_file_format(tmp_path, ref_data):
+    """`<prefix>_loci_e<E>l<K>` (reference SeedFinder::save_starts / open_starts, seed_finder.hpp:1640-1679;
+    utils.hpp:521-588): u64 count + raw { node id, offset } records with external ids."""
+    b, g = _setup(ref_data, 'x')
+    px = psi_amd.PathIndex.build(g, 12, 1, step=2)
+    prefix = str(tmp_path / 'ix')
+    px.save_loci(g, prefix)
+    raw = np.fromfile(prefix + '_loci_e2l12', dtype=np.uint64)
+    ln, lo = px.loci
+    assert raw[0] == len(ln) and len(raw) == 1 + 2 * len(ln)
+    assert raw[1::2].tolist() == [b.ids[v] for v in ln.tolist()] and raw[2::2].tolist() == lo.tolist()
+    # a file written elsewhere for the same paths (here: step 1 loci, in shuffled order) replaces the loci
+    full = psi_amd.PathIndex.build(g, 12, 1, step=1)
+    fl, fo = full.loci
+    perm = np.random.default_rng(1).permutation(len(fl))
+    rec = np.empty(1 + 2 * len(fl), np.uint64)
+    rec[0] = len(fl)
+    rec[1::2] = np.array([b.ids[v] for v in fl[perm].tolist()], np.uint64)
+    rec[2::2] = fo[perm]
+    rec.tofile(prefix + '_loci_e1l12')
+    px.load_loci(g, prefix, 1)
+    assert px.loci[0].tolist() == fl.tolist() and px.loci[1].tolist() == fo.tolist()
+    assert px.matches(g, 12, 1)
+    # wrong size / unknown node / offset beyond the node: rejected
+    rec[:-1].tofile(prefix + '_loci_e1l12')
+    with pytest.raises(psi_amd.PsiGpuError):
+        px.load_loci(g, prefix, 1)
+    rec[1] = 10 ** 9
+    rec.tofile(prefix + '_loci_e1l12')
+    with pytest.raises(psi_amd.PsiGpuError):
+        px.load_loci(g, prefix, 1)
+    with pytest.raises(psi_amd.PsiGpuError):
+        px.load_loci(g, prefix, 5)                 # no such file
+
+
 def test_index_save_load_roundtrip(tmp_path, ref_data):
     b, g = _setup(ref_data, 'x')
     px = psi_amd.PathIndex.build(g, 20, 2, sa_rate=8, rng_seed=5)
