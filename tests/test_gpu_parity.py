@@ -490,6 +490,91 @@ def test_query_modes_agree_at_full_size(query_mode):
     assert _eq(res['kmer-table'], res['traverse']) and _eq(res['locus-table'], res['traverse'])
     hits = res['traverse']
     assert len(np.unique(hits[:, 2] * np.uint64(1000) + hits[:, 3])) == 7_000_000
+    # ... and they are the ORACLE's records: the C restatement of the reference path over the same index
+    # paths and starting loci, all 1 M reads (a few seconds on the box's host cores)
+    import oracle
+    from bench import oracle_objects
+    og, pidx = oracle_objects(sg, px)
+    ln, lo = px.loci
+    want = oracle.sort_unique(oracle.seeds_all(og, pidx, bytes(bases), off, k, k, ln, lo,
+                                               threads=oracle.lib().orc_max_threads()))
+    want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
+    assert _eq(res['kmer-table'], want)
+
+
+@pytest.mark.parametrize('query_mode', ['kmer-table'], indirect=True)
+def test_config2_whole_genome(query_mode):
+    """BASELINE.json configs[2]: whole-genome-like graph (3.1 Gbp backbone, 80 M SNV bubbles, 298 M nodes),
+    10 M x 150 bp reads, k = 21, one MI355X, index and tables resident in HBM.  No oracle run is possible at
+    this size, so: size-independent properties over all 70 M seeds, and oracle parity on a 50 Mbp window of
+    the same graph (reads drawn from the window; hits inside it compared with the oracle run on the window
+    alone).  Set PSI_TEST_WG=0 to skip (needs ~250 GB of host memory and ~4 minutes)."""
+    if os.environ.get('PSI_TEST_WG', '1') == '0':
+        pytest.skip('PSI_TEST_WG=0')
+    import torch
+    import oracle
+    k = 21
+    L, n_reads = 3_100_000_000, 10_000_000
+    sg = synth.snv_graph(L, 80_000_000, n_block=150_000_000, seed=11)
+    g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path])
+    bases, off = synth.sim_reads_snv(sg, n_reads, 150, seed=13)
+    # the last 200 k reads come from one 50 Mbp window: [w0, w0 + 50 M) of the backbone
+    w0, wlen, n_win = 1_000_000_000, 50_000_000, 200_000
+    rng = np.random.default_rng(5)
+    start = rng.integers(w0 + 1000, w0 + wlen - 1150, size=n_win)
+    idx = start[:, None] + np.arange(150)[None, :]
+    r = sg.backbone[idx]
+    a = sg.alt[idx]
+    r = np.where((a != 0) & (rng.random(size=idx.shape) < 0.5), a, r)
+    bases[(n_reads - n_win) * 150:] = r.reshape(-1)
+    px = psi_amd.PathIndex.build(g, k, 1, rng_seed=1, device=0)
+    assert px.text_len > 2_900_000_000 and px.view.n_loci > 1_000_000_000
+    f = psi_amd.SeedFinder(g, k)
+    f.set_path_index(px)
+    f.prepare()
+    d_bases = torch.from_numpy(bases).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    ptr, n_hits = f.seeds_all_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, len(bases),
+                                     stream=torch.cuda.current_stream().cuda_stream)
+    c = f.counters()
+    assert c['n_seeds'] == 70_000_000 and c['n_hits'] == n_hits
+    hits = f.copy_hits(ptr, n_hits)
+    # sensitivity: every seed of every (error-free) read is found; specificity: first bases agree
+    assert len(np.unique(hits[:, 2] * np.uint64(1000) + hits[:, 3])) == 70_000_000
+    lo = sg.label_off.astype(np.int64)
+    rank = hits[:500_000, 0].astype(np.int64) - 1
+    first = sg.labels[lo[rank] + hits[:500_000, 1].astype(np.int64)]
+    assert (first == bases[(hits[:500_000, 2] * np.uint64(150) + hits[:500_000, 3]).astype(np.int64)]).all()
+    # ---- oracle parity on the window -----------------------------------------------------------------
+    # node ranks of the window: labels follow the backbone in rank order with every alt base right behind
+    # its ref base, so backbone position p sits at label coordinate p + (SNVs in front of p)
+    lab = lambda pos: pos + int(np.count_nonzero(sg.alt[:pos]))                               # noqa: E731
+    v0 = int(np.searchsorted(sg.label_off, np.uint64(lab(w0)), side='left'))
+    v1 = int(np.searchsorted(sg.label_off, np.uint64(lab(w0 + wlen)), side='left'))
+    eo = sg.edge_off.astype(np.int64)
+    et = sg.edge_to[eo[v0]:eo[v1]].astype(np.int64)
+    src = np.repeat(np.arange(v0, v1), np.diff(eo[v0:v1 + 1]))
+    keep = (et >= v0) & (et < v1)
+    sub_edge_off = np.concatenate([[0], np.cumsum(np.bincount(src[keep] - v0, minlength=v1 - v0))]).astype(np.uint64)
+    og = oracle.OracleGraph(sg.node_id[v0:v1], (sg.label_off[v0:v1 + 1] - sg.label_off[v0]).astype(np.uint64),
+                            bytes(sg.labels[int(lo[v0]):int(lo[v1])]), sub_edge_off, (et[keep] - v0).astype(np.uint64))
+    path = px.paths()[0].astype(np.int64)
+    sub_path = path[(path >= v0) & (path < v1)] - v0
+    pidx = oracle.OraclePathIndex(og, [sub_path.tolist()])
+    ln, lc = px.loci
+    m = (ln >= v0) & (ln < v1)
+    wb = bytes(bases[(n_reads - n_win) * 150:])
+    woff = (np.arange(n_win + 1, dtype=np.uint64) * np.uint64(150))
+    want = oracle.sort_unique(oracle.seeds_all(og, pidx, wb, woff, k, k, (ln[m] - v0).astype(np.uint32), lc[m],
+                                               rec_offset=n_reads - n_win, threads=oracle.lib().orc_max_threads()))
+    got = hits[hits[:, 2] >= n_reads - n_win]
+    # compare away from the window's cut ends (walks that leave the window exist only in the whole graph)
+    margin = 64
+    inner = lambda h: h[(h[:, 0] >= sg.node_id[v0 + margin]) & (h[:, 0] < sg.node_id[v1 - margin])]     # noqa: E731
+    got, want = psi_amd.sort_unique(inner(got)), inner(want)
+    assert len(want) >= n_win * 7
+    assert _eq(got, want)
+    f.close()
 
 
 # ---------------------------------------------------------------------------------------
