@@ -13,6 +13,7 @@
 #include <deque>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -33,7 +34,7 @@ struct Options {                       // reference src/options.hpp:67-93
   unsigned long chunk_size = 0;
   bool patched = true, indexonly = false, nologfile = false, quiet = false, nocolor = false;
   bool nolog = false, verbose = false;
-  int device = 0;
+  std::vector< int > devices{ 0 };
   unsigned int query_mode = PSIGPU_MODE_KMER_TABLE;
 };
 
@@ -79,6 +80,8 @@ const char* USAGE =
   "  -D, --disable-log          disable logging\n"
   "  -v, --verbose              info messages on the console\n"
   "      --device INT           GPU ordinal (default: 0)\n"
+  "      --devices LIST         several GPUs, e.g. 0-7 or 0,2,3: the index is copied to each, every chunk's\n"
+  "                             reads are split into one contiguous range per GPU (same output)\n"
   "      --query-mode MODE      kmer-table | locus-table | traverse (default: kmer-table; same hits)\n"
   "  -h, --help\n";
 
@@ -156,7 +159,26 @@ Options parse_args( int argc, char** argv )
     else if ( a == "-C" ) o.nocolor = true;
     else if ( a == "-D" ) o.nolog = true;
     else if ( a == "-v" ) o.verbose = true;
-    else if ( a == "--device" ) o.device = (int)to_uint( a, need() );
+    else if ( a == "--device" ) o.devices.assign( 1, (int)to_uint( a, need() ) );
+    else if ( a == "--devices" ) {
+      o.devices.clear();
+      std::string list = need();
+      size_t p = 0;
+      while ( p <= list.size() ) {
+        size_t q = list.find( ',', p );
+        if ( q == std::string::npos ) q = list.size();
+        std::string tok = list.substr( p, q - p );
+        size_t dash = tok.find( '-' );
+        if ( dash == std::string::npos ) o.devices.push_back( (int)to_uint( a, tok ) );
+        else {
+          unsigned long lo = to_uint( a, tok.substr( 0, dash ) ), hi = to_uint( a, tok.substr( dash + 1 ) );
+          if ( hi < lo || hi - lo > 1024 ) throw std::runtime_error( "invalid device range '" + tok + "'" );
+          for ( unsigned long d = lo; d <= hi; ++d ) o.devices.push_back( (int)d );
+        }
+        p = q + 1;
+      }
+      if ( o.devices.empty() ) throw std::runtime_error( "--devices needs at least one GPU" );
+    }
     else if ( a == "--query-mode" ) {
       std::string m = need();
       if ( m == "kmer-table" ) o.query_mode = PSIGPU_MODE_KMER_TABLE;
@@ -253,7 +275,7 @@ int run( Options const& o, Logger& log )
   if ( out == nullptr ) throw std::runtime_error( "cannot open file '" + o.output_path + "'" );
 
   typedef SeedFinder< NoStats > finder_type;
-  finder_type finder( graph, o.seed_len, o.gocc_threshold, o.max_mem, o.device );
+  finder_type finder( graph, o.seed_len, o.gocc_threshold, o.max_mem, o.devices[ 0 ] );
   finder.set_query_mode( o.query_mode );
   log.info( "Looking for an existing path index..." );
   auto t0 = std::chrono::steady_clock::now();
@@ -292,6 +314,14 @@ int run( Options const& o, Logger& log )
    * the reads covered are the changes of read id along the array. */
   unsigned long long found = 0, covered = 0;
   HitWriter writer( out );
+  /* --devices: one finder (one psigpu_ctx) per further GPU, each with a copy of the graph and the index */
+  std::vector< std::unique_ptr< finder_type > > more;
+  for ( size_t d = 1; d < o.devices.size(); ++d ) {
+    more.emplace_back( new finder_type( graph, o.seed_len, o.gocc_threshold, o.max_mem, o.devices[ d ] ) );
+    more.back()->set_query_mode( o.query_mode );
+    more.back()->share_path_index( finder );
+  }
+  if ( !more.empty() ) log.info( "Index copied to " + std::to_string( o.devices.size() ) + " devices." );
 
   auto chunk = finder.create_readrecord();
   SeedsRecord seeds;
@@ -308,11 +338,43 @@ int run( Options const& o, Logger& log )
     finder.get_seeds( seeds, chunk, o.distance );
     auto seeds_index = finder.index_reads( seeds );
     log.info( "Finding all seeds..." );
-    psigpu_hits hits = finder.seeds_all_hits( seeds, seeds_index, traverser );
-    found += hits.n;
-    covered += count_covered_reads( hits );
-    writer.push( hits );                               // takes ownership, frees after writing
     auto st = finder.get_stats();
+    if ( more.empty() ) {
+      psigpu_hits hits = finder.seeds_all_hits( seeds, seeds_index, traverser );
+      found += hits.n;
+      covered += count_covered_reads( hits );
+      writer.push( hits );                             // takes ownership, frees after writing
+      st = finder.get_stats();
+    } else {
+      /* reads are independent given the index: GPU r answers the r-th contiguous range of the chunk
+       * (read ids stay global through the record offset); the ranges' sorted hit arrays, in range
+       * order, are the sorted chunk.  Each GPU returns its hits over its own host link: there is
+       * nothing to exchange between the devices. */
+      const size_t nd = o.devices.size();
+      std::vector< psigpu_hits > part( nd );
+      std::vector< std::string > err( nd );
+      std::vector< std::thread > th;
+      const std::uint64_t n = chunk.size();
+      for ( size_t r = 0; r < nd; ++r )
+        th.emplace_back( [ &, r ] {
+          const std::uint64_t b = n * r / nd, e = n * ( r + 1 ) / nd;
+          try { part[ r ] = ( r == 0 ? finder : *more[ r - 1 ] ).seeds_all_hits( seeds, b, e ); }
+          catch ( std::exception const& ex ) { err[ r ] = ex.what(); }
+        } );
+      for ( auto& t : th ) t.join();
+      for ( size_t r = 0; r < nd; ++r ) if ( !err[ r ].empty() ) throw std::runtime_error( "device " + std::to_string( o.devices[ r ] ) + ": " + err[ r ] );
+      st = finder.get_stats();
+      for ( size_t r = 0; r < nd; ++r ) {
+        found += part[ r ].n;
+        covered += count_covered_reads( part[ r ] );
+        writer.push( part[ r ] );
+        if ( r ) {
+          auto s2 = more[ r - 1 ]->get_stats();
+          st.n_hits_on_path += s2.n_hits_on_path; st.n_hits_off_path += s2.n_hits_off_path;
+          st.ms_total = std::max( st.ms_total, s2.ms_total );
+        }
+      }
+    }
     t_device += st.ms_total * 1e-3;
     log.info( "Found seeds on paths: " + std::to_string( st.n_hits_on_path ) + ", off paths: " +
               std::to_string( st.n_hits_off_path ) + " (raw), device time " + std::to_string( st.ms_total ) + " ms." );

@@ -215,6 +215,31 @@ namespace psi {
       return find( seeds, PSIGPU_ALL );
     }
 
+    /** The same for the reads [begin, end) of the chunk only: psikt --devices gives every GPU one
+     *  contiguous range of each chunk (reads are independent given the index; read ids stay global). */
+    psigpu_hits seeds_all_hits( SeedsRecord const& seeds, std::uint64_t begin, std::uint64_t end ) const
+    {
+      if ( seeds.chunk == nullptr ) throw std::runtime_error( "get_seeds() has not been called" );
+      Records const& c = *seeds.chunk;
+      if ( begin > end || end > c.size() ) throw std::runtime_error( "read range out of bounds" );
+      std::vector< std::uint64_t > off( end - begin + 1 );
+      for ( std::uint64_t i = begin; i <= end; ++i ) off[ i - begin ] = c.offsets[ i ] - c.offsets[ begin ];
+      psigpu_hits hits{};
+      check( psigpu_find_seeds( ctx, c.bases.data() + c.offsets[ begin ], off.data(), end - begin, seeds.seed_len,
+                                seeds.distance, c.get_record_offset() + begin, PSIGPU_ALL | PSIGPU_SORT_UNIQUE, &hits ) );
+      return hits;
+    }
+
+    /** Another finder (another GPU) takes this finder's path index and starting loci: the index is made
+     *  or loaded once and copied to every device. */
+    void share_path_index( SeedFinder const& other )
+    {
+      if ( other.pindex.empty() ) throw std::runtime_error( "the other finder has no path index" );
+      check( psigpu_load_index( ctx, &other.pindex.view() ) );
+      check( psigpu_prepare( ctx, seed_len ) );
+      shared_from = &other;
+    }
+
     /** seeds_all with one callback per phase (reference :1734-1743). */
     void seeds_all( SeedsRecord const& seeds, readsindex_type& index, traverser_type& traverser,
                     callback_type callback1, callback_type callback2 ) const
@@ -241,7 +266,7 @@ namespace psi {
       }
       return out;
     }
-    std::uint64_t get_nof_starting_loci() const { return pindex.view().n_loci; }
+    std::uint64_t get_nof_starting_loci() const { return ( shared_from ? shared_from->pindex : pindex ).view().n_loci; }
     std::uint64_t get_nof_uniq_nodes() const
     {
       auto const& v = pindex.view();
@@ -301,6 +326,7 @@ namespace psi {
     unsigned int pick_n = 0, pick_context = 0, built_step = 0;
     bool pick_patched = true;
     int device_ = 0;
+    SeedFinder const* shared_from = nullptr;
     pathindex_type pindex;
     psigpu_ctx* ctx = nullptr;
   };

@@ -97,6 +97,26 @@ def test_output_bytes_match_golden(tmp_path):
 
 
 @pytest.mark.gpu
+def test_devices_flag_splits_chunks_over_contexts(tmp_path):
+    """--devices: one context per listed GPU (here the same GPU three times: what can run on a one-GPU
+    box), every chunk split into contiguous read ranges, output identical to the single-device run."""
+    z = np.load(os.path.join(GOLDEN, 'hits_x_reads_n1000l100e0i0_k21_d1.npz'))
+    seq = os.path.join(REF, 'reads_n1000l100e0i0.seq')
+    want = z['hits'][np.lexsort((z['hits'][:, 1], z['hits'][:, 0], z['hits'][:, 3], z['hits'][:, 2]))]
+    for extra in (['--devices', '0,0,0'], ['--devices', '0-0', '-c', '333'], ['--devices', '0,0', '-c', '7', '-n', '2']):
+        out = str(tmp_path / 'out.gam')
+        args = ['-n', '1'] if '-n' not in extra else []
+        p = run(os.path.join(REF, 'x.gfa'), '-f', seq, '-l', '21', '-d', '1', '-o', out, '-Q', *args, *extra)
+        assert p.returncode == 0, p.stderr
+        got = _records(out)
+        if '-c' in extra:
+            got = got[np.lexsort((got[:, 1], got[:, 0], got[:, 3], got[:, 2]))]
+        assert got.shape == want.shape and (got == want).all()
+    p = run(os.path.join(REF, 'x.gfa'), '-f', seq, '-l', '21', '--devices', '0,99', '-o', str(tmp_path / 'o'), '-Q')
+    assert p.returncode == 1 and 'device' in p.stderr
+
+
+@pytest.mark.gpu
 def test_larger_run_matches_golden(tmp_path):
     z = np.load(os.path.join(GOLDEN, 'hits_x_reads_n1000l100e0i0_k21_d1.npz'))
     seq = os.path.join(REF, 'reads_n1000l100e0i0.seq')

@@ -32,3 +32,45 @@ def test_two_rank_gloo_gather(tmp_path):
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert out.read_text().startswith('OK 5010')
+
+
+def _run_two_ranks(script_args, env_extra, timeout=900):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PSI_AMD_NO_TORCH='0', **env_extra)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port)] + script_args
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu_through_the_hip_path(tmp_path):
+    """Both ranks share the box's one GPU (collectives on gloo): every rank answers its read range on the
+    device (patched index, sort-unique on the device), rank 0 gathers; the gathered array is the golden
+    hit set in sorted order."""
+    out = tmp_path / 'result.txt'
+    p = _run_two_ranks([os.path.join(ROOT, 'tests', '_dist_worker.py'), str(out)], {'PSI_DIST_HIP': '1'})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert out.read_text().startswith('OK 5010')
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_one_gpu():
+    """bench.py's N > 1 path end to end (PSI_BENCH_BACKEND=gloo: ranks share the GPU): one JSON line, weak
+    scaling, hit lists gathered on rank 0 in read-id order."""
+    import json
+    p = _run_two_ranks([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--reads', '20000', '--backbone', '3000000', '--snvs', '60000', '--nblock', '200000'],
+                       {'PSI_BENCH_BACKEND': 'gloo'})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.split('\n') if l.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 3
+    assert j['config']['seeds_per_step_per_gpu'] == 140000 and j['value'] > 0
+    g = j['gather_hits']
+    assert g['records'] >= 2 * 140000 and g['sorted_by_read_id'] and g['backend'] == 'gloo'
