@@ -248,6 +248,7 @@ def main():
     t_prep = time.time()
     finder.prepare()                      # the tables of the query mode: index load time, not query time
     t_prep = time.time() - t_prep
+    time.sleep(0.3)     # the driver clears the gigabytes of temporaries prepare() freed on the copy engines: let it finish
     if rank == 0:
         log('setup %.1f s (index %.1f s on the %s, tables %.2f s): %d nodes, %d edges, text %d, %d starting loci' %
             (time.time() - t0, t_ix, 'host' if args.host_build else 'device', t_prep, g.n_nodes, g.n_edges,
@@ -336,6 +337,14 @@ def main():
                'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': abytes,
                'traffic_gbs': (traffic / (avg_ms * 1e-3) / 1e9) if traffic and avg_ms > 0 else None,
                'kernel_ms_per_step': {n: v / steps for n, v in kern.items()}}
+        if dom == 'k_fm_search' and avg_ms > 0:
+            # the same secondary bound for K1: its divergent loads per launch -- interval-table entry per
+            # N-free seed, the locus-table slot probed beside it (locus-table mode), one 16-byte row record
+            # per row verified, two rank blocks per LF step still executed
+            loads = c['n_seeds_valid'] * (2 if mode == 'locus-table' else 1) + c['n_rows_verified'] + 2 * c['n_lf_steps']
+            out['random_loads_per_launch'] = float(loads)
+            out['random_loads_per_s'] = loads / (avg_ms * 1e-3)
+            out['random_load_peak_per_s'] = 41.4e9
         if dom == 'k_kmer_probe':
             # secondary bound: divergent 16-byte loads per second against the rate
             # tools/rand_sector2.hip measures on this part for a table of this size
@@ -422,31 +431,10 @@ def main():
         if gather:
             out['gather_hits'] = gather
     if world == 1 and not lean:
-        # ---- the same workload in the other query modes: the kernels north_star names --------------
-        by_mode = {args.mode: main_res}
-        for m in ('kmer-table', 'locus-table', 'traverse'):
-            if m in by_mode:
-                continue
-            f2 = psi_amd.SeedFinder(g, k, device=local_rank, mode=m)
-            f2.set_path_index(px)
-            f2.prepare()
-            by_mode[m] = time_mode(f2, 10, 3, m, False)
-            f2.close()
-        rbm = {}
-        for m, res in by_mode.items():
-            e = {'ms_per_step': res['elapsed'] / res['steps'] * 1e3, 'seeds_per_s': res['seeds'] / res['elapsed'],
-                 'hits_per_step': int(res['c']['n_hits']), 'dominant': roofline_of(res, m)}
-            if m != 'kmer-table':
-                e['k_fm_search'] = roofline_of(res, m, 'k_fm_search')
-                e['k_fm_locate'] = roofline_of(res, m, 'k_fm_locate')
-            if m == 'traverse':
-                e['k_traverse'] = roofline_of(res, m, 'k_traverse')
-            rbm[m] = e
-        out['roofline_by_mode'] = rbm
-
         # ---- the host entry point, PCIe included ------------------------------------
         hits = psi_amd.Hits()
         pin = [(psi_amd.pinned_copy(b), psi_amd.pinned_copy(o)) for b, o in batches]
+        time.sleep(0.3)
 
         def host_entry(src, flags, reps):
             calls = [(finder.ctx, psi_amd._ptr(b), psi_amd._ptr(o), args.reads, k, step, rec_offset, flags, C.byref(hits))
@@ -502,6 +490,30 @@ def main():
         out['series_1pct_error'] = {'ms_per_step': dt * 1e3, 'seeds_per_s': ce['n_seeds'] / dt, 'hits_per_s': ce['n_hits'] / dt,
                                     'hits_per_step': int(ce['n_hits'])}
         del d_eb, d_eo
+
+        # ---- the same workload in the other query modes: the kernels north_star names --------------
+        # (after the end-to-end measurement: closing a finder frees ~10 GB of tables, and the driver's
+        # clearing of freed VRAM keeps the copy engines busy for a few hundred milliseconds)
+        by_mode = {args.mode: main_res}
+        for m in ('kmer-table', 'locus-table', 'traverse'):
+            if m in by_mode:
+                continue
+            f2 = psi_amd.SeedFinder(g, k, device=local_rank, mode=m)
+            f2.set_path_index(px)
+            f2.prepare()
+            by_mode[m] = time_mode(f2, 10, 3, m, False)
+            f2.close()
+        rbm = {}
+        for m, res in by_mode.items():
+            e = {'ms_per_step': res['elapsed'] / res['steps'] * 1e3, 'seeds_per_s': res['seeds'] / res['elapsed'],
+                 'hits_per_step': int(res['c']['n_hits']), 'dominant': roofline_of(res, m)}
+            if m != 'kmer-table':
+                e['k_fm_search'] = roofline_of(res, m, 'k_fm_search')
+                e['k_fm_locate'] = roofline_of(res, m, 'k_fm_locate')
+            if m == 'traverse':
+                e['k_traverse'] = roofline_of(res, m, 'k_traverse')
+            rbm[m] = e
+        out['roofline_by_mode'] = rbm
 
         # ---- CPU baseline + parity gate -------------------------------------------------------------
         if args.cpu_reads != 0:

@@ -137,7 +137,7 @@ struct DevCounters {
   StripedCounter n_rows_verified; // SA rows K1 checked against the text
   PaddedCounter n_defer;         // seeds k_fm_search_direct left to the quad kernel
   PaddedCounter n_seeds_true;    // the scan's seed count (comes back to the host with the counters)
-  PaddedCounter max_read_len;    // longest read of the chunk (the hit sorter sizes its key fields with it)
+  StripedCounter max_read_len;   // longest read of the chunk, a running maximum per stripe (the hit sorter sizes its key fields with it)
   PaddedCounter dbg0, dbg1;      // diagnostics (builds with -DTRAV_STATS)
 };
 
@@ -407,8 +407,10 @@ k_seed_scan_final(const uint64_t* __restrict__ read_off, uint64_t n, uint32_t k,
     }
     s += c[i];
   }
+  // (one atomic per wave on ONE address would cost more than the scan itself: 11 ns each)
   for (int d = 32; d > 0; d >>= 1) longest = max(longest, (uint64_t)__shfl_down(longest, d));
-  if ((threadIdx.x & 63) == 0 && longest) atomicMax(&ctr->max_read_len.v, (unsigned long long)longest);
+  if ((threadIdx.x & 63) == 0 && longest)
+    atomicMax(&ctr->max_read_len.s[(blockIdx.x * 4 + (threadIdx.x >> 6)) & (STRIPES - 1)].v, (unsigned long long)longest);
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int d = 1; d < SCAN_THREADS; d <<= 1) {
@@ -3310,7 +3312,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     k_publish<<<1, 256, 0, stream>>>(reinterpret_cast<const uint4*>(ctr), reinterpret_cast<uint4*>(ctx->h_pinned_dev), (uint32_t)(sizeof(DevCounters) / 16));
     HIPCHK(ctx, hipStreamSynchronize(stream));
     true_seeds = h.n_seeds_true.v;
-    ctx->last_max_read_len = h.max_read_len.v;
+    ctx->last_max_read_len = 0;
+    for (int i = 0; i < STRIPES; ++i) ctx->last_max_read_len = std::max<uint64_t>(ctx->last_max_read_len, h.max_read_len.s[i].v);
     if (true_seeds > n_seeds) { ctx->err = "n_bases does not cover the reads"; return PSIGPU_ERR_ARG; }
     total_hits = h.n_hits_tab.v + h.n_hits_off.v;
     if (total_hits > cap) { overflow = true; cap = total_hits + total_hits / 16 + 1024; }

@@ -4,7 +4,7 @@ kernel stats, PMC summary and per-launch traffic of the query kernels, per query
 import csv, glob, json, sys
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+    rnd = sys.argv[1] if len(sys.argv) > 1 else 'r02'
     for tag, mode in (('k', 'kmer_table'), ('l', 'locus_table'), ('t', 'traverse')):
         d = 'gpurun_out/prof_%s' % tag
         try:
@@ -16,7 +16,8 @@ def main():
         json.dump(t, open('profiles/%s_%s_traffic.json' % (rnd, tag), 'w'), indent=1)
         rows = [l for l in open(d + '/pmc_summary.csv') if l.startswith('kernel,') or keep(l)]
         open('profiles/%s_pmc_summary_%s.csv' % (rnd, mode), 'w').writelines(rows)
-        f = glob.glob(d + '/stats/**/*kernel_stats.csv', recursive=True)[0]
+        import os
+        f = max(glob.glob(d + '/stats/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime)   # (gpurun_out keeps earlier runs)
         out = []
         for r in csv.reader(open(f)):
             if r[0] == 'Name' or int(r[1]) >= 3:
