@@ -1575,6 +1575,62 @@ __device__ __forceinline__ void resolve_hit(const MapView& mv, const LocusEnt* _
   }
 }
 
+// One round of emission, shared by K2 of the FM modes and of the k-mer table mode: 64 seeds, one per lane,
+// each with `cnt` hits described by `sh`.  When no seed of the round has more than two hits (the usual
+// case) every lane writes its own: the records of consecutive lanes are consecutive.  Otherwise the
+// round's HITS are handed out to the lanes 64 at a time: lane j finds the seed that owns hit j by
+// bisecting the prefix of the counts (shuffles), so a seed with many occurrences is spread over the wave
+// instead of serialising one lane.  `woff` (wave-uniform) is the wave's next output slot.
+__device__ __forceinline__ void emit_round(const MapView& mv, const LocusEnt* __restrict__ ent, const SeedHits& sh, uint32_t cnt,
+                                           uint2 si, uint64_t& woff, uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap)
+{
+  const uint32_t lane = lane_id();
+  uint32_t incl = cnt;
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+    if (lane >= (uint32_t)d) incl += t;
+  }
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+  if (total == 0) return;
+  if (!__any(cnt > 2)) {
+    const uint64_t out0 = woff + (incl - cnt);
+    for (uint32_t occ = 0; occ < 2; ++occ) {
+      if (occ < cnt && out0 + occ < cap) {
+        uint64_t nid, noff;
+        resolve_hit(mv, ent, sh, occ, nid, noff);
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + out0 + occ);
+        dst[0] = make_ulonglong2(nid, noff);
+        dst[1] = make_ulonglong2(rec_offset + si.x, (uint64_t)si.y);
+      }
+    }
+  } else {
+    for (uint32_t j = lane; j - lane < total; j += 64) {      // wave-uniform trip count
+      uint32_t a = 0, b = 63;                                  // owner: first seed whose inclusive prefix exceeds j
+      for (int it = 0; it < 6; ++it) {
+        uint32_t mid = (a + b) >> 1;
+        uint32_t v = (uint32_t)__shfl((int)incl, (int)mid);
+        if (v > j) b = mid; else a = mid + 1;
+      }
+      const int o = (int)min(a, 63u);
+      SeedHits oh;
+      oh.lo = (uint32_t)__shfl((int)sh.lo, o); oh.con = (uint32_t)__shfl((int)sh.con, o);
+      oh.aux = (uint32_t)__shfl((int)sh.aux, o); oh.on_node = (uint32_t)__shfl((int)sh.on_node, o);
+      oh.on_noff = (uint32_t)__shfl((int)sh.on_noff, o); oh.ofirst = (uint32_t)__shfl((int)sh.ofirst, o);
+      oh.ocnt = (uint32_t)__shfl((int)sh.ocnt, o); oh.onoff = (uint32_t)__shfl((int)sh.onoff, o);
+      const uint32_t o_excl = (uint32_t)__shfl((int)(incl - cnt), o);
+      const uint32_t o_rid = (uint32_t)__shfl((int)si.x, o), o_roff = (uint32_t)__shfl((int)si.y, o);
+      if (j < total && woff + j < cap) {
+        uint64_t nid, noff;
+        resolve_hit(mv, ent, oh, j - o_excl, nid, noff);
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + woff + j);
+        dst[0] = make_ulonglong2(nid, noff);
+        dst[1] = make_ulonglong2(rec_offset + o_rid, (uint64_t)o_roff);
+      }
+    }
+  }
+  woff += total;
+}
+
 // K2 for sa_rate == 1 (the whole suffix array is resident): no LF-walk, so no quad cooperation.
 // A wave round takes 64 seeds, one per lane.  When no seed of the round has more than two hits
 // (the usual case) every lane writes its own: the records of consecutive lanes are consecutive.
@@ -1582,8 +1638,7 @@ __device__ __forceinline__ void resolve_hit(const MapView& mv, const LocusEnt* _
 // owns hit j by bisecting the prefix of the counts (shuffles), so a seed with many occurrences
 // is spread over the wave instead of serialising one lane.
 __global__ void __launch_bounds__(256)
-k_fm_locate_direct(MapView mv, SeedOut so, bool have_off, const uint4* __restrict__ seed_res,
-                   const KmerSlot* __restrict__ ext, const LocusEnt* __restrict__ ent,
+k_fm_locate_direct(MapView mv, SeedOut so, bool have_off, const LocusEnt* __restrict__ ent,
                    const uint64_t* __restrict__ wave_off, const uint64_t* __restrict__ params, uint64_t seeds_cap,
                    uint32_t per_wave, const uint2* __restrict__ seed_info, uint64_t rec_offset,
                    psigpu_hit* __restrict__ hits, uint64_t cap)
@@ -1597,86 +1652,22 @@ k_fm_locate_direct(MapView mv, SeedOut so, bool have_off, const uint4* __restric
     const uint64_t item = base + lane;
     const bool have = item < s1;
     SeedHits sh = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    if (have && seed_res != nullptr) {
-      // k-mer table mode: the probe left (a, b), the wanted counts and what (a, b) means
-      const uint4 r = seed_res[item];
-      sh.con = r.z & RES_CNT;
-      const uint32_t coff = r.w & ~RES_INLINE;
-      if (r.z & RES_EXT) {
-        if (sh.con | coff) {
-          const uint4* e = reinterpret_cast<const uint4*>(ext + r.x);
-          const uint4 e0 = e[0], e1 = e[1];               // key, on_a, on_b | off_a, off_b, on_cnt, off_cnt
-          if (sh.con) {
-            if (e1.z & KT_INLINE) { sh.on_node = e0.z; sh.on_noff = e0.w; sh.aux = AUX_RESOLVED; }
-            else sh.lo = e0.z;
-          }
-          if (coff) { sh.ofirst = e1.x; sh.onoff = e1.y; sh.ocnt = (e1.w & KT_INLINE) ? (1u | OFF_INLINE) : coff; }
-        }
-      } else {
-        if (sh.con) { sh.on_node = r.x; sh.on_noff = r.y; sh.aux = AUX_RESOLVED; }
-        if (coff) { sh.ofirst = r.x; sh.onoff = r.y; sh.ocnt = 1u | OFF_INLINE; }
-      }
-    } else if (have) {
+    if (have) {
       sh.lo = so.iv_lo[item]; sh.con = so.iv_cnt[item];
       if (have_off) sh.ocnt = so.off_cnt[item];
     }
     const uint32_t cnt = sh.con + (sh.ocnt & ~OFF_INLINE);     // on-path occurrences first, then the table's loci
-    uint32_t incl = cnt;
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t t = (uint32_t)__shfl_up((int)incl, d);
-      if (lane >= (uint32_t)d) incl += t;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    if (total == 0) continue;
+    // the rest of a seed's description is only read for seeds that have hits
     uint2 si = make_uint2(0, 0);
     if (cnt) {
       si = seed_info[item];
-      if (seed_res == nullptr) {
-        if (sh.con) {
-          sh.aux = so.iv_aux[item];
-          if (sh.aux & AUX_RESOLVED) { sh.on_node = so.on_node[item]; sh.on_noff = so.on_noff[item]; }
-        }
-        if (sh.ocnt) { sh.ofirst = so.off_first[item]; sh.onoff = so.off_noff[item]; }
+      if (sh.con) {
+        sh.aux = so.iv_aux[item];
+        if (sh.aux & AUX_RESOLVED) { sh.on_node = so.on_node[item]; sh.on_noff = so.on_noff[item]; }
       }
+      if (sh.ocnt) { sh.ofirst = so.off_first[item]; sh.onoff = so.off_noff[item]; }
     }
-    if (!__any(cnt > 2)) {
-      const uint64_t out0 = woff + (incl - cnt);
-      for (uint32_t occ = 0; occ < 2; ++occ) {
-        if (occ < cnt && out0 + occ < cap) {
-          uint64_t nid, noff;
-          resolve_hit(mv, ent, sh, occ, nid, noff);
-          ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + out0 + occ);
-          dst[0] = make_ulonglong2(nid, noff);
-          dst[1] = make_ulonglong2(rec_offset + si.x, (uint64_t)si.y);
-        }
-      }
-    } else {
-      for (uint32_t j = lane; j - lane < total; j += 64) {      // wave-uniform trip count
-        // owner: the first seed whose inclusive prefix exceeds j
-        uint32_t a = 0, b = 63;
-        for (int it = 0; it < 6; ++it) {
-          uint32_t mid = (a + b) >> 1;
-          uint32_t v = (uint32_t)__shfl((int)incl, (int)mid);
-          if (v > j) b = mid; else a = mid + 1;
-        }
-        const int o = (int)min(a, 63u);
-        SeedHits oh;
-        oh.lo = (uint32_t)__shfl((int)sh.lo, o); oh.con = (uint32_t)__shfl((int)sh.con, o);
-        oh.aux = (uint32_t)__shfl((int)sh.aux, o); oh.on_node = (uint32_t)__shfl((int)sh.on_node, o);
-        oh.on_noff = (uint32_t)__shfl((int)sh.on_noff, o); oh.ofirst = (uint32_t)__shfl((int)sh.ofirst, o);
-        oh.ocnt = (uint32_t)__shfl((int)sh.ocnt, o); oh.onoff = (uint32_t)__shfl((int)sh.onoff, o);
-        const uint32_t o_excl = (uint32_t)__shfl((int)(incl - cnt), o);
-        const uint32_t o_rid = (uint32_t)__shfl((int)si.x, o), o_roff = (uint32_t)__shfl((int)si.y, o);
-        if (j < total && woff + j < cap) {
-          uint64_t nid, noff;
-          resolve_hit(mv, ent, oh, j - o_excl, nid, noff);
-          ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + woff + j);
-          dst[0] = make_ulonglong2(nid, noff);
-          dst[1] = make_ulonglong2(rec_offset + o_rid, (uint64_t)o_roff);
-        }
-      }
-    }
-    woff += total;
+    emit_round(mv, ent, sh, cnt, si, woff, rec_offset, hits, cap);
   }
 }
 
@@ -1759,50 +1750,7 @@ k_kmer_emit(MapView mv, const uint4* __restrict__ seed_res, const KmerSlot* __re
         if (coff) { sh.ofirst = r.x; sh.onoff = r.y; sh.ocnt = 1u | OFF_INLINE; }
       }
       const uint32_t cnt = sh.con + (sh.ocnt & ~OFF_INLINE);     // on-path occurrences first, then the loci
-      uint32_t incl = cnt;
-      for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= (uint32_t)d) incl += t;
-      }
-      const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-      if (total == 0) continue;
-      if (!__any(cnt > 2)) {
-        const uint64_t out0 = woff + (incl - cnt);
-        for (uint32_t occ = 0; occ < 2; ++occ) {
-          if (occ < cnt && out0 + occ < cap) {
-            uint64_t nid, noff;
-            resolve_hit(mv, ent, sh, occ, nid, noff);
-            ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + out0 + occ);
-            dst[0] = make_ulonglong2(nid, noff);
-            dst[1] = make_ulonglong2(rec_offset + si.x, (uint64_t)si.y);
-          }
-        }
-      } else {
-        for (uint32_t j = lane; j - lane < total; j += 64) {      // wave-uniform trip count
-          uint32_t a = 0, b = 63;                                  // owner: first seed whose inclusive prefix exceeds j
-          for (int it = 0; it < 6; ++it) {
-            uint32_t mid = (a + b) >> 1;
-            uint32_t v = (uint32_t)__shfl((int)incl, (int)mid);
-            if (v > j) b = mid; else a = mid + 1;
-          }
-          const int o = (int)min(a, 63u);
-          SeedHits oh;
-          oh.lo = (uint32_t)__shfl((int)sh.lo, o); oh.con = (uint32_t)__shfl((int)sh.con, o);
-          oh.aux = (uint32_t)__shfl((int)sh.aux, o); oh.on_node = (uint32_t)__shfl((int)sh.on_node, o);
-          oh.on_noff = (uint32_t)__shfl((int)sh.on_noff, o); oh.ofirst = (uint32_t)__shfl((int)sh.ofirst, o);
-          oh.ocnt = (uint32_t)__shfl((int)sh.ocnt, o); oh.onoff = (uint32_t)__shfl((int)sh.onoff, o);
-          const uint32_t o_excl = (uint32_t)__shfl((int)(incl - cnt), o);
-          const uint32_t o_rid = (uint32_t)__shfl((int)si.x, o), o_roff = (uint32_t)__shfl((int)si.y, o);
-          if (j < total && woff + j < cap) {
-            uint64_t nid, noff;
-            resolve_hit(mv, ent, oh, j - o_excl, nid, noff);
-            ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + woff + j);
-            dst[0] = make_ulonglong2(nid, noff);
-            dst[1] = make_ulonglong2(rec_offset + o_rid, (uint64_t)o_roff);
-          }
-        }
-      }
-      woff += total;
+      emit_round(mv, ent, sh, cnt, si, woff, rec_offset, hits, cap);
     }
   }
 }
@@ -2237,6 +2185,20 @@ struct TmpBuf {           // scoped device allocation (table construction)
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// fn(begin, end) over [0, n) on a few host threads (index-load time loops over all nodes / bases)
+template <typename F>
+void parallel_for(uint64_t n, uint64_t grain, F fn)
+{
+  unsigned hw = std::thread::hardware_concurrency();
+  uint64_t parts = std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1, 32), (n + grain - 1) / std::max<uint64_t>(1, grain));
+  if (parts <= 1) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  const uint64_t per = (n + parts - 1) / parts;
+  for (uint64_t t = 1; t < parts; ++t) th.emplace_back([=] { fn(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+  fn(0, std::min(n, per));
+  for (auto& t : th) t.join();
+}
+
 }  // namespace
 
 struct psigpu_ctx {
@@ -2463,29 +2425,47 @@ int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
   if (total >= (1ull << 40)) { ctx->err = "labels too long"; return PSIGPU_ERR_ARG; }
   std::vector<NodeRec> recs(n);
   std::vector<uint64_t> lab2(total / 32 + 2, 0), labn(total / 64 + 2, 0);
-  for (uint64_t v = 0; v < n; ++v) {
-    uint64_t o0 = g->label_off[v], o1 = g->label_off[v + 1];
-    uint64_t deg = g->edge_off[v + 1] - g->edge_off[v];
-    if (deg > 0xFFFF) { ctx->err = "out-degree above 65535"; return PSIGPU_ERR_ARG; }
-    if (o1 - o0 > 0xFFFFFFFFull || g->edge_off[v] > 0xFFFFFFFFull) { ctx->err = "graph too large"; return PSIGPU_ERR_ARG; }
-    bool has_n = false;
-    for (uint64_t i = o0; i < o1; ++i) {
+  // 2-bit labels and the N mask: threads take base ranges aligned to 64 bases, so that no two of them
+  // touch one word (300 M nodes / 3 G bases at whole-genome size: this loop and the next are the bulk
+  // of psigpu_load_graph)
+  parallel_for((total + 63) / 64, 1u << 14, [&](uint64_t w0, uint64_t w1) {
+    const uint64_t i1 = std::min<uint64_t>(total, w1 * 64);
+    for (uint64_t i = w0 * 64; i < i1; ++i) {
       uint64_t two;
       switch (g->labels[i]) {
         case 'A': case 'a': two = 0; break;
         case 'C': case 'c': two = 1; break;
         case 'G': case 'g': two = 2; break;
         case 'T': case 't': two = 3; break;
-        default: two = 0; has_n = true; labn[i >> 6] |= 1ull << (63 - (i & 63)); break;
+        default: two = 0; labn[i >> 6] |= 1ull << (63 - (i & 63)); break;
       }
       lab2[i >> 5] |= two << (62 - 2 * (i & 31));
     }
-    recs[v].w0 = o0 | (deg << 40) | ((uint64_t)has_n << 63);
-    recs[v].len = (uint32_t)(o1 - o0);
-  }
+  });
+  std::atomic<int> bad{ 0 };
+  parallel_for(n, 1u << 14, [&](uint64_t v0, uint64_t v1) {
+    for (uint64_t v = v0; v < v1; ++v) {
+      const uint64_t o0 = g->label_off[v], o1 = g->label_off[v + 1];
+      const uint64_t deg = g->edge_off[v + 1] - g->edge_off[v];
+      if (deg > 0xFFFF) { bad = 1; return; }
+      if (o1 - o0 > 0xFFFFFFFFull || g->edge_off[v] > 0xFFFFFFFFull) { bad = 2; return; }
+      bool has_n = false;
+      for (uint64_t w = o0 >> 6; w <= (o1 ? (o1 - 1) >> 6 : 0) && o1 > o0 && !has_n; ++w) {
+        uint64_t m = labn[w];
+        if (w == (o0 >> 6)) m &= ~0ull >> (o0 & 63);
+        if (w == ((o1 - 1) >> 6)) m &= ~0ull << (63 - ((o1 - 1) & 63));
+        has_n = m != 0;
+      }
+      recs[v].w0 = o0 | (deg << 40) | ((uint64_t)has_n << 63);
+      recs[v].len = (uint32_t)(o1 - o0);
+    }
+  });
+  if (bad == 1) { ctx->err = "out-degree above 65535"; return PSIGPU_ERR_ARG; }
+  if (bad == 2) { ctx->err = "graph too large"; return PSIGPU_ERR_ARG; }
   auto base_at = [&](uint64_t i) { return (lab2[i >> 5] >> (62 - 2 * (i & 31))) & 3ull; };
   auto n_at = [&](uint64_t i) { return (labn[i >> 6] >> (63 - (i & 63))) & 1ull; };
-  for (uint64_t v = 0; v < n; ++v) {
+  parallel_for(n, 1u << 14, [&](uint64_t v_begin, uint64_t v_end) {
+  for (uint64_t v = v_begin; v < v_end; ++v) {
     uint64_t o0 = g->label_off[v], len = g->label_off[v + 1] - o0;
     uint64_t head2 = 0; uint32_t headn = 0;
     uint64_t tot = 0;                       // inline bases so far
@@ -2521,9 +2501,11 @@ int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
     r.edge0 = cut ? (uint32_t)cur : (deg ? g->edge_to[g->edge_off[cur]] : NIL);
     r.edge_off = cut ? 0u : (deg == 2 ? g->edge_to[g->edge_off[cur] + 1] : (uint32_t)g->edge_off[cur]);
   }
+  });
   // compact 16-byte records for the common case
   std::vector<NodeLite> lite(n);
-  for (uint64_t v = 0; v < n; ++v) {
+  parallel_for(n, 1u << 14, [&](uint64_t v_begin, uint64_t v_end) {
+  for (uint64_t v = v_begin; v < v_end; ++v) {
     const NodeRec& r = recs[v];
     uint64_t deg = (r.w0 >> 40) & 0xFFFF;
     bool is_long = (r.w0 >> 62) & 1;
@@ -2536,6 +2518,7 @@ int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
                   : (r.len & 63u) | ((uint32_t)deg << 6) | ((uint32_t)((r.w0 >> 56) & 63u) << 8) |
                         ((uint32_t)(d1 & 0xFFFF) << 16);
   }
+  });
   int st;
   if ((st = upload(ctx, ctx->lite, lite.data(), n, 1))) return st;
   if ((st = upload(ctx, ctx->nodes, recs.data(), n, 1))) return st;
@@ -2567,6 +2550,23 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (x->text_len >= 0xFFFFFFF0ull) { ctx->err = "text too long for the 32-bit index layout"; return PSIGPU_ERR_ARG; }
   if (x->sa_rate == 0 || (x->sa_rate & (x->sa_rate - 1))) { ctx->err = "bad sa_rate"; return PSIGPU_ERR_ARG; }
+  // nothing inconsistent reaches the kernels: every array length follows from the text length
+  if (x->seed_len == 0 || x->seed_len > PSIGPU_MAX_SEED_LEN || x->text_len == 0 ||
+      x->n_blocks != x->text_len / BLOCK_SYMS + 1 || x->n_dir != (x->text_len >> DIR_SHIFT) + 1 ||
+      x->n_samples != (x->text_len + x->sa_rate - 1) / x->sa_rate || (x->n_exc && (!x->exc_row || !x->exc_sa)) ||
+      (x->n_loci && (!x->loci_node || !x->loci_off)) || !x->bwt_blocks || !x->sa_samples || !x->seg_start ||
+      !x->seg_dir) {
+    ctx->err = "inconsistent index view";
+    return PSIGPU_ERR_ARG;
+  }
+  if (!ctx->have_graph) { ctx->err = "load the graph before the index"; return PSIGPU_ERR_STATE; }
+  for (uint64_t i = 0; i < x->n_loci; ++i)
+    if (x->loci_node[i] >= ctx->n_nodes || x->loci_off[i] >= ctx->max_node_len) {
+      ctx->err = "starting locus outside the graph: the index does not belong to this graph";
+      return PSIGPU_ERR_ARG;
+    }
+  for (uint64_t i = 0; i < x->n_dir; ++i)
+    if (x->seg_dir[i] >= x->n_segs + (x->n_segs == 0)) { ctx->err = "inconsistent index view"; return PSIGPU_ERR_ARG; }
   int st;
   if ((st = upload(ctx, ctx->blocks, (const RankBlock*)x->bwt_blocks, x->n_blocks, 1))) return st;
   if ((st = upload(ctx, ctx->samples, x->sa_samples, x->n_samples, 1))) return st;
@@ -3235,8 +3235,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
                                               ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), d_params,
                                               n_seeds, per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap, ctr);
       else if (ctx->sa_rate == 1)
-        k_fm_locate_direct<<<grid, 256, 0, stream>>>(mv, so, probe || kprobe, kprobe ? ctx->w_seedres.as<uint4>() : nullptr,
-                                                     ctx->kt_ext.as<KmerSlot>(), oe, ctx->w_iv_tiles.as<uint64_t>(), d_params, n_seeds,
+        k_fm_locate_direct<<<grid, 256, 0, stream>>>(mv, so, probe, oe, ctx->w_iv_tiles.as<uint64_t>(), d_params, n_seeds,
                                                      per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap);
       else
         k_fm_locate<<<grid, 256, 0, stream>>>(fm, mv, so.iv_lo, so.iv_cnt, probe ? so.off_first : nullptr,
@@ -3517,11 +3516,16 @@ void psigpu_host_free(void* p)
 namespace {
 
 // is this host pointer pinned (hipHostMalloc / hipHostRegister), i.e. can the copy engine read it in place?
-bool host_ptr_is_pinned(const void* p)
+// `delta` = what to add to the host address to get the address the device side uses for the same
+// byte (0 for hipHostMalloc memory; memory pinned later with hipHostRegister may be mapped elsewhere)
+bool host_ptr_is_pinned(const void* p, ptrdiff_t* delta)
 {
+  *delta = 0;
   hipPointerAttribute_t a{};
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return a.type == hipMemoryTypeHost;
+  if (a.type != hipMemoryTypeHost) return false;
+  if (a.devicePointer && a.hostPointer) *delta = (const char*)a.devicePointer - (const char*)a.hostPointer;
+  return true;
 }
 
 // pageable -> pinned staging copy with a few threads (one core moves ~10 GB/s, the link 55)
@@ -3677,7 +3681,8 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     }
   }
   const size_t n_sub = cut.size() - 1;
-  const bool pinned_in = n_bases == 0 || host_ptr_is_pinned(bases);
+  ptrdiff_t pin_delta = 0;
+  const bool pinned_in = n_bases == 0 || host_ptr_is_pinned(bases, &pin_delta);
   { int st = pipeline_init(ctx); if (st != PSIGPU_OK) return st; }
 
   std::function<void(int)> trace_in;
@@ -3708,7 +3713,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     if (trace_in) trace_in(0);
     if (ctx->ec.ok) {
       if (nb == 0) hsa_signal_store_relaxed(ctx->ec.sig_in[j & 1], 0);
-      else if (!engine_copy(ctx, true, sl.bases.p, src, nb, ctx->ec.sig_in[j & 1])) return hipErrorUnknown;
+      else if (!engine_copy(ctx, true, sl.bases.p, pinned_in ? src + pin_delta : src, nb, ctx->ec.sig_in[j & 1])) return hipErrorUnknown;
     } else {
       if (nb) e = hipMemcpyAsync(sl.bases.p, src, nb, hipMemcpyHostToDevice, ctx->s_in);
       if (e == hipSuccess) e = hipEventRecord(sl.in_ready, ctx->s_in);

@@ -22,23 +22,23 @@ namespace {
 
 struct RawGraph {
   std::vector<uint64_t> ids;
-  std::vector<std::string> seqs;
-  std::unordered_map<uint64_t, uint32_t> rank;
+  std::vector<uint64_t> seq_off;                         // into seqbuf
+  std::vector<uint32_t> seq_len;
+  std::string seqbuf;                                    // labels in file order, upper case
   std::vector<std::pair<uint64_t, uint64_t>> edges;      // external ids, forward
   std::vector<std::pair<std::string, std::vector<uint64_t>>> paths;
 
-  void add_node(uint64_t id, std::string s)
+  // (a node that is defined twice keeps its last definition: resolved when ranks are assigned)
+  void add_node(uint64_t id, const char* s, size_t n)
   {
-    for (auto& c : s) c = (char)toupper((unsigned char)c);
-    auto it = rank.find(id);
-    if (it == rank.end()) {
-      rank.emplace(id, (uint32_t)ids.size());
-      ids.push_back(id);
-      seqs.push_back(std::move(s));
-    } else {
-      seqs[it->second] = std::move(s);
-    }
+    ids.push_back(id);
+    seq_off.push_back(seqbuf.size());
+    seq_len.push_back((uint32_t)n);
+    const size_t at = seqbuf.size();
+    seqbuf.append(s, n);
+    for (size_t i = at; i < at + n; ++i) seqbuf[i] = (char)toupper((unsigned char)seqbuf[i]);
   }
+  void add_node(uint64_t id, const std::string& s) { add_node(id, s.data(), s.size()); }
 };
 
 bool strip_orient(const std::string& tok, uint64_t* id, bool* rev)
@@ -48,26 +48,6 @@ bool strip_orient(const std::string& tok, uint64_t* id, bool* rev)
   if (o != '+' && o != '-') return false;
   *rev = (o == '-');
   *id = strtoull(tok.substr(0, tok.size() - 1).c_str(), nullptr, 10);
-  return true;
-}
-
-std::vector<std::string> split(const std::string& s, char sep)
-{
-  std::vector<std::string> out;
-  size_t p = 0;
-  while (true) {
-    size_t q = s.find(sep, p);
-    if (q == std::string::npos) { out.push_back(s.substr(p)); break; }
-    out.push_back(s.substr(p, q - p));
-    p = q + 1;
-  }
-  return out;
-}
-
-bool all_digits(const std::string& s)
-{
-  if (s.empty()) return false;
-  for (char c : s) if (c < '0' || c > '9') return false;
   return true;
 }
 
@@ -82,45 +62,107 @@ bool add_edge(RawGraph& rg, uint64_t a, bool ar, uint64_t b, bool br, std::strin
   return true;
 }
 
+// A line's tab-separated fields as (pointer, length) pairs into the file buffer.
+struct Fields {
+  const char* p[8];
+  size_t n[8];
+  int count = 0;
+  void cut(const char* b, const char* e, int want)
+  {
+    count = 0;
+    while (count < want) {
+      const char* t = (const char*)memchr(b, '\t', e - b);
+      p[count] = b; n[count] = (t && count + 1 < want ? t : e) - b;
+      ++count;
+      if (!t || count == want) break;
+      b = t + 1;
+    }
+  }
+};
+
+inline bool parse_u64(const char* p, size_t n, uint64_t* out)
+{
+  if (n == 0) return false;
+  uint64_t x = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (p[i] < '0' || p[i] > '9') return false;
+    x = x * 10 + (uint64_t)(p[i] - '0');
+  }
+  *out = x;
+  return true;
+}
+
 bool parse_gfa(const std::string& path, RawGraph& rg, std::string* err)
 {
-  std::ifstream in(path);
-  if (!in) { *err = "cannot open " + path; return false; }
-  std::string line;
-  while (std::getline(in, line)) {
-    if (line.empty()) continue;
-    if (!line.empty() && line.back() == '\r') line.pop_back();
-    auto f = split(line, '\t');
-    const std::string& t = f[0];
-    if (t == "S") {
-      if (f.size() < 3) { *err = "bad S line"; return false; }
-      uint64_t id = strtoull(f[1].c_str(), nullptr, 10);
-      // GFA 2: S id len seq ; GFA 1: S id seq [tags]
-      if (f.size() >= 4 && all_digits(f[2]) && f[3].find(':') == std::string::npos)
-        rg.add_node(id, f[3]);
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { *err = "cannot open " + path; return false; }
+  std::string buf;
+  {
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf.resize(sz > 0 ? (size_t)sz : 0);
+    size_t got = buf.empty() ? 0 : fread(&buf[0], 1, buf.size(), f);
+    fclose(f);
+    if (got != buf.size()) { *err = "cannot read " + path; return false; }
+  }
+  rg.seqbuf.reserve(buf.size() / 2);
+  const char* p = buf.data();
+  const char* const end = p + buf.size();
+  Fields fl;
+  while (p < end) {
+    const char* nl = (const char*)memchr(p, '\n', end - p);
+    const char* e = nl ? nl : end;
+    const char* next = nl ? nl + 1 : end;
+    if (e > p && e[-1] == '\r') --e;
+    if (e - p < 2 || p[1] != '\t') { p = next; continue; }
+    const char t = p[0];
+    if (t == 'S') {
+      fl.cut(p, e, 5);            // S id seq [tags...]  |  GFA 2: S id len seq [tags...]
+      if (fl.count < 3) { *err = "bad S line"; return false; }
+      uint64_t id, len2;
+      if (!parse_u64(fl.p[1], fl.n[1], &id)) id = strtoull(std::string(fl.p[1], fl.n[1]).c_str(), nullptr, 10);
+      // the 5th "field" is the rest of the line: cut the 4th at its own tab
+      size_t n3 = fl.count >= 4 ? fl.n[3] : 0;
+      if (fl.count >= 4 && parse_u64(fl.p[2], fl.n[2], &len2) && memchr(fl.p[3], ':', n3) == nullptr)
+        rg.add_node(id, fl.p[3], n3);
       else
-        rg.add_node(id, f[2]);
-    } else if (t == "E") {
-      if (f.size() < 4) { *err = "bad E line"; return false; }
+        rg.add_node(id, fl.p[2], fl.n[2]);
+    } else if (t == 'L') {
+      fl.cut(p, e, 6);
+      if (fl.count < 5) { *err = "bad L line"; return false; }
+      uint64_t a, b;
+      if (!parse_u64(fl.p[1], fl.n[1], &a)) a = strtoull(std::string(fl.p[1], fl.n[1]).c_str(), nullptr, 10);
+      if (!parse_u64(fl.p[3], fl.n[3], &b)) b = strtoull(std::string(fl.p[3], fl.n[3]).c_str(), nullptr, 10);
+      if (!add_edge(rg, a, fl.n[2] == 1 && fl.p[2][0] == '-', b, fl.n[4] == 1 && fl.p[4][0] == '-', err)) return false;
+    } else if (t == 'E') {
+      fl.cut(p, e, 5);
+      if (fl.count < 4) { *err = "bad E line"; return false; }
       uint64_t a, b; bool ar, br;
-      if (!strip_orient(f[2], &a, &ar) || !strip_orient(f[3], &b, &br)) { *err = "bad E line"; return false; }
+      if (!strip_orient(std::string(fl.p[2], fl.n[2]), &a, &ar) || !strip_orient(std::string(fl.p[3], fl.n[3]), &b, &br)) { *err = "bad E line"; return false; }
       if (!add_edge(rg, a, ar, b, br, err)) return false;
-    } else if (t == "L") {
-      if (f.size() < 5) { *err = "bad L line"; return false; }
-      uint64_t a = strtoull(f[1].c_str(), nullptr, 10), b = strtoull(f[3].c_str(), nullptr, 10);
-      if (!add_edge(rg, a, f[2] == "-", b, f[4] == "-", err)) return false;
-    } else if (t == "O" || t == "P") {
-      if (f.size() < 3) { *err = "bad path line"; return false; }
+    } else if (t == 'O' || t == 'P') {
+      fl.cut(p, e, 4);
+      if (fl.count < 3) { *err = "bad path line"; return false; }
+      const char sep = t == 'O' ? ' ' : ',';
       std::vector<uint64_t> nodes;
-      for (auto& tok : split(f[2], t == "O" ? ' ' : ',')) {
-        if (tok.empty()) continue;
-        uint64_t id; bool rev;
-        if (!strip_orient(tok, &id, &rev)) { *err = "bad path step"; return false; }
-        if (rev) { *err = "reverse path steps are not supported"; return false; }
-        nodes.push_back(id);
+      const char* q = fl.p[2];
+      const char* const qe = q + fl.n[2];
+      while (q < qe) {
+        const char* s2 = (const char*)memchr(q, sep, qe - q);
+        const char* te = s2 ? s2 : qe;
+        if (te > q) {
+          const char o = te[-1];
+          uint64_t id;
+          if ((o != '+' && o != '-') || te - q < 2 || !parse_u64(q, te - q - 1, &id)) { *err = "bad path step"; return false; }
+          if (o == '-') { *err = "reverse path steps are not supported"; return false; }
+          nodes.push_back(id);
+        }
+        q = s2 ? s2 + 1 : qe;
       }
-      rg.paths.emplace_back(f[1], std::move(nodes));
+      rg.paths.emplace_back(std::string(fl.p[1], fl.n[1]), std::move(nodes));
     }
+    p = next;
   }
   return true;
 }
@@ -284,50 +326,84 @@ Graph* load_graph_file(const std::string& path, int* status, std::string* err)
   }
   if (rg.ids.size() >= 0xFFFFFFF0ull) { *status = PSIGPU_ERR_FORMAT; *err = "too many nodes"; return nullptr; }
   Graph* g = new Graph;
-  uint64_t n = rg.ids.size();
   // Node rank = position in ascending external-id order (psikt loads with sort = true,
-  // src/psikt.cpp:249-251), so .gfa and .vg renderings of one graph give identical ranks.
-  {
-    std::vector<uint32_t> perm(n);
-    for (uint64_t i = 0; i < n; ++i) perm[i] = (uint32_t)i;
-    std::sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return rg.ids[a] < rg.ids[b]; });
-    std::vector<uint64_t> ids(n);
-    std::vector<std::string> seqs(n);
-    for (uint64_t i = 0; i < n; ++i) {
-      ids[i] = rg.ids[perm[i]];
-      seqs[i] = std::move(rg.seqs[perm[i]]);
-      rg.rank[ids[i]] = (uint32_t)i;
-    }
-    rg.ids.swap(ids);
-    rg.seqs.swap(seqs);
+  // src/psikt.cpp:249-251), so .gfa and .vg renderings of one graph give identical ranks.  A node
+  // defined twice keeps its last definition.
+  const uint64_t n_def = rg.ids.size();
+  std::vector<uint32_t> perm(n_def);
+  for (uint64_t i = 0; i < n_def; ++i) perm[i] = (uint32_t)i;
+  bool sorted = true;
+  for (uint64_t i = 1; i < n_def && sorted; ++i) sorted = rg.ids[i - 1] < rg.ids[i];
+  if (!sorted) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return rg.ids[a] < rg.ids[b]; });
+  g->node_id.reserve(n_def);
+  g->label_off.assign(1, 0);
+  g->label_off.reserve(n_def + 1);
+  g->labels.reserve(rg.seqbuf.size());
+  for (uint64_t i = 0; i < n_def; ++i) {
+    const uint32_t d = perm[i];
+    if (i + 1 < n_def && rg.ids[perm[i + 1]] == rg.ids[d]) continue;      // a later definition follows
+    g->node_id.push_back(rg.ids[d]);
+    g->labels.append(rg.seqbuf, rg.seq_off[d], rg.seq_len[d]);
+    g->label_off.push_back(g->labels.size());
   }
-  g->node_id = rg.ids;
-  g->label_off.assign(n + 1, 0);
-  for (uint64_t i = 0; i < n; ++i) g->label_off[i + 1] = g->label_off[i] + rg.seqs[i].size();
-  g->labels.reserve(g->label_off[n]);
-  for (auto& s : rg.seqs) g->labels += s;
-  // CSR in edge file order per source node, duplicates dropped
-  std::vector<std::vector<uint32_t>> adj(n);
-  for (auto& e : rg.edges) {
-    auto a = rg.rank.find(e.first), b = rg.rank.find(e.second);
-    if (a == rg.rank.end() || b == rg.rank.end()) {
+  const uint64_t n = g->node_id.size();
+  // id -> rank: a direct table when the ids are dense (the usual case), bisection otherwise
+  const uint64_t id_min = n ? g->node_id.front() : 0, id_max = n ? g->node_id.back() : 0;
+  const bool dense = n && id_max - id_min < 4 * n + 1024;
+  std::vector<uint32_t> direct;
+  if (dense) {
+    direct.assign(id_max - id_min + 1, 0xFFFFFFFFu);
+    for (uint64_t r = 0; r < n; ++r) direct[g->node_id[r] - id_min] = (uint32_t)r;
+  }
+  auto rank_of = [&](uint64_t id, uint32_t* r) -> bool {
+    if (dense) {
+      if (id < id_min || id > id_max || direct[id - id_min] == 0xFFFFFFFFu) return false;
+      *r = direct[id - id_min];
+      return true;
+    }
+    auto it = std::lower_bound(g->node_id.begin(), g->node_id.end(), id);
+    if (it == g->node_id.end() || *it != id) return false;
+    *r = (uint32_t)(it - g->node_id.begin());
+    return true;
+  };
+  // CSR in edge file order per source node, duplicates dropped: count, place, then squeeze
+  std::vector<uint32_t> ea(rg.edges.size()), eb(rg.edges.size());
+  g->edge_off.assign(n + 1, 0);
+  for (size_t i = 0; i < rg.edges.size(); ++i) {
+    if (!rank_of(rg.edges[i].first, &ea[i]) || !rank_of(rg.edges[i].second, &eb[i])) {
       *status = PSIGPU_ERR_FORMAT; *err = "edge refers to an unknown node"; delete g; return nullptr;
     }
-    auto& v = adj[a->second];
-    if (std::find(v.begin(), v.end(), b->second) == v.end()) v.push_back(b->second);
+    ++g->edge_off[ea[i] + 1];
   }
-  g->edge_off.assign(n + 1, 0);
-  for (uint64_t i = 0; i < n; ++i) g->edge_off[i + 1] = g->edge_off[i] + adj[i].size();
-  g->edge_to.reserve(g->edge_off[n]);
-  for (auto& v : adj) g->edge_to.insert(g->edge_to.end(), v.begin(), v.end());
+  for (uint64_t v = 0; v < n; ++v) g->edge_off[v + 1] += g->edge_off[v];
+  {
+    std::vector<uint32_t> to(rg.edges.size());
+    std::vector<uint64_t> fill(g->edge_off.begin(), g->edge_off.end() - 1);
+    for (size_t i = 0; i < rg.edges.size(); ++i) to[fill[ea[i]]++] = eb[i];       // stable: file order kept
+    g->edge_to.reserve(to.size());
+    uint64_t prev_end = 0;
+    for (uint64_t v = 0; v < n; ++v) {
+      const uint64_t b0 = prev_end, e0 = g->edge_off[v + 1];
+      const uint64_t first = g->edge_to.size();
+      for (uint64_t j = b0; j < e0; ++j) {
+        bool dup = false;
+        for (uint64_t q = first; q < g->edge_to.size() && !dup; ++q) dup = g->edge_to[q] == to[j];
+        if (!dup) g->edge_to.push_back(to[j]);
+      }
+      prev_end = e0;
+      g->edge_off[v] = first;
+    }
+    g->edge_off[n] = g->edge_to.size();
+  }
   for (auto& p : rg.paths) {
     std::vector<uint32_t> nodes;
+    nodes.reserve(p.second.size());
     for (uint64_t id : p.second) {
-      auto it = rg.rank.find(id);
-      if (it == rg.rank.end()) {
+      uint32_t r;
+      if (!rank_of(id, &r)) {
         *status = PSIGPU_ERR_FORMAT; *err = "path refers to an unknown node"; delete g; return nullptr;
       }
-      nodes.push_back(it->second);
+      nodes.push_back(r);
     }
     g->paths.push_back(std::move(nodes));
     g->path_names.push_back(p.first);

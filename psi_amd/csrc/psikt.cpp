@@ -41,10 +41,12 @@ struct Options {                       // reference src/options.hpp:67-93
 struct Logger {
   FILE* file = nullptr;
   bool console_info = false, quiet = false, off = false;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   void line( const char* level, std::string const& msg, bool to_console )
   {
     if ( off ) return;
-    if ( file ) { fprintf( file, "[%s] %s\n", level, msg.c_str() ); fflush( file ); }
+    double t = std::chrono::duration< double >( std::chrono::steady_clock::now() - t0 ).count();   /* seconds since start */
+    if ( file ) { fprintf( file, "[%9.3f] [%s] %s\n", t, level, msg.c_str() ); fflush( file ); }
     if ( to_console && !quiet ) fprintf( stderr, "[psikt] [%s] %s\n", level, msg.c_str() );
   }
   void info( std::string const& m ) { line( "info", m, console_info ); }

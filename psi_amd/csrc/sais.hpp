@@ -2,8 +2,11 @@
 //
 // Host-side, one-off index construction.  The reference builds its
 // suffix array inside sdsl::construct (reference include/psi/fmindex.hpp:257-271), a
-// third-party library that is not available here; this is an independent implementation
-// of the published algorithm.  Indices are int32 (text length < 2^31).
+// third-party library that is not available here; this is an implementation of the published
+// algorithm.  Its decomposition (bucket counts / bucket ends, two induction sweeps, LMS-substring
+// naming, recursion on the reduced string) follows the structure of the well-known public
+// reference implementation sais-lite (Yuta Mori, 2008-2010, MIT licence) -- not part of the
+// reference tree.  Indices are int32 (text length < 2^31).
 #pragma once
 #include <cstdint>
 #include <cstring>

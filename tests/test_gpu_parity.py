@@ -733,7 +733,7 @@ def test_regression_all_t_31mer_with_an_ext_record(query_mode):
 # sort-unique on the device
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize('sub_bytes', [64, 1000, 30_000])
-@pytest.mark.parametrize('pinned', [False, True])
+@pytest.mark.parametrize('pinned', [False, True, 'torch'])
 def test_host_entry_pipeline_equals_one_batch(monkeypatch, sub_bytes, pinned):
     """A chunk cut into many sub-batches (ragged reads, reads with N, empty reads) gives the hits of
     the chunk answered in one piece; read ids stay global; the sorted result is the sorted chunk."""
@@ -750,7 +750,11 @@ def test_host_entry_pipeline_equals_one_batch(monkeypatch, sub_bytes, pinned):
     want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
     bases, off = psi_amd.pack_reads(ragged)
     keep = []
-    if pinned:
+    if pinned == 'torch':           # page-locked by somebody else's allocator
+        import torch
+        keep = [torch.from_numpy(bases).pin_memory(), torch.from_numpy(off.astype(np.int64)).pin_memory()]
+        bases, off = keep[0].numpy(), keep[1].numpy().view(np.uint64)
+    elif pinned:
         keep = [psi_amd.pinned_copy(bases), psi_amd.pinned_copy(off)]
         bases, off = keep[0].array, keep[1].array
     monkeypatch.setenv('PSIGPU_SUB_BYTES', str(sub_bytes))

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """One-off campaign beyond the committed seeds of tests/test_gpu_parity.py::test_random_graphs_vs_brute:
 random graphs (cycles, N runs, empty-ish nodes, out-degree up to 6) x random k / seed distance /
-indexed paths / SA rate / interval table, every query mode and walk caps 0 / 1 / 3, device index
-build on and off, against the brute-force definition.  `python tools/fuzz_modes.py FIRST LAST [low]`."""
+indexed paths -- full or PATCHED with a random context -- / SA rate / interval table, every query mode
+and walk caps 0 / 1 / 3, device index build on and off, against the brute-force definition; the host
+entry point with a random sub-batch size and sort-unique on the device; the starting loci against the
+brute-force definition over the (trimmed) paths; MEM mode against brute.find_mems.
+`python tools/fuzz_modes.py FIRST LAST [low]`."""
 import os
 import random
 import sys
@@ -41,11 +44,22 @@ def main():
         for _ in range(2):
             k = rng.choice([3, 8, 12, 13, 16, 21, 25, 31])
             step = rng.choice([1, 2, k, k + 3])
-            npaths = rng.choice([0, 1, 1, 2, 3])
+            npaths = rng.choice([0, 1, 1, 2, 3, 5])
+            patched = npaths > 1 and rng.random() < 0.6
             want = np.array(brute.hit_set(g, [r.upper() for r in reads], k, step), dtype=np.uint64).reshape(-1, 4)
             px = psi_amd.PathIndex.build(pg, k, npaths, rng_seed=seed, sa_rate=rng.choice([1, 1, 1, 2, 8]),
                                          ftab_len=rng.choice([0, 0, 4, psi_amd.NO_FTAB]),
-                                         device=rng.choice([None, 0]))
+                                         device=rng.choice([None, 0]), patched=patched,
+                                         context=rng.choice([0, k, k + 1, k + 7]) if patched else 0)
+            # starting loci = brute-force definition over the trimmed paths (acyclic graphs only: the
+            # brute force lists walks, the product's candidate sets handle repeats on their own)
+            paths_ids = [[g.ids[r] for r in p] for p in px.paths()]
+            if all(len(set(p)) == len(p) for p in paths_ids) and len(g.ids) <= 40 and k <= 16:
+                ln, lo = px.loci
+                got_loci = [(g.ids[v], int(o)) for v, o in zip(ln.tolist(), lo.tolist())]
+                if got_loci != brute.uncovered_loci(g, paths_ids, k, px.trims()):
+                    print('LOCI MISMATCH', seed, k, npaths, patched, flush=True)
+                    sys.exit(1)
             for mode in ('kmer-table', 'locus-table', 'traverse'):
                 for cap in ((0,) if mode == 'traverse' else (0, 1, 3)):
                     f = psi_amd.SeedFinder(pg, k, mode=mode, walk_cap=cap)
@@ -54,6 +68,26 @@ def main():
                     if not (got.shape == want.shape and (got == want).all()):
                         print('MISMATCH', seed, k, step, npaths, mode, cap, got.shape, want.shape, flush=True)
                         sys.exit(1)
+                    if cap == 0:
+                        # host entry point in pieces, sorted on the device
+                        os.environ['PSIGPU_SUB_BYTES'] = str(rng.choice([16, 200, 3000, 1 << 30]))
+                        su = f.seeds_all(reads, step=step, sort_unique=True, rec_offset=5)
+                        os.environ.pop('PSIGPU_SUB_BYTES')
+                        w2 = want.copy(); w2[:, 2] += 5
+                        w2 = w2[np.lexsort((w2[:, 1], w2[:, 0], w2[:, 3], w2[:, 2]))]
+                        if not (su.shape == w2.shape and (su == w2).all()):
+                            print('SORT-UNIQUE MISMATCH', seed, k, step, npaths, mode, flush=True)
+                            sys.exit(1)
+                    if mode == 'kmer-table' and cap == 0 and npaths and px.view.sa_rate == 1:
+                        gocc, mm = rng.choice([0, 0, 2]), rng.choice([0, 0, 3])
+                        f2 = psi_amd.SeedFinder(pg, k, mode=mode, gocc_threshold=gocc)
+                        f2.set_path_index(px)
+                        gm = f2.find_mems(reads, max_mem=mm)
+                        wm = np.array(brute.find_mems(g, paths_ids, reads, k, px.trims(), gocc, mm), dtype=np.uint64).reshape(-1, 6)
+                        f2.close()
+                        if not (gm.shape == wm.shape and (gm == wm).all()):
+                            print('MEM MISMATCH', seed, k, npaths, patched, gocc, mm, gm.shape, wm.shape, flush=True)
+                            sys.exit(1)
                     f.close()
                     n_cases += 1
     print('ok: seeds %d..%d, %d finder runs' % (first, last, n_cases))

@@ -78,6 +78,14 @@ def main():
             m = re.findall(pat, text)
             if m:
                 r[key] = float(m[-1]) if '.' in m[-1] else int(m[-1])
+        # seconds since process start at which each phase was reached (the log lines carry them)
+        for key, pat in (('t_graph_loaded', r'\[\s*([0-9.]+)\] \[info\] Number of nodes'),
+                         ('t_index_ready', r'\[\s*([0-9.]+)\] \[info\] Number of starting loci'),
+                         ('t_reads_loaded', r'\[\s*([0-9.]+)\] \[info\] Fetched'),
+                         ('t_done', r'\[\s*([0-9.]+)\] \[info\] Number of reads covered')):
+            m = re.findall(pat, text)
+            if m:
+                r[key] = float(m[-1])
         if p.returncode:
             r['stderr'] = p.stderr[-500:]
         runs[name] = r

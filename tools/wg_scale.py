@@ -55,6 +55,9 @@ def main():
     f = psi_amd.SeedFinder(g, args.k, device=0)
     f.set_path_index(px)
     out['upload_s'] = time.time() - t
+    t = time.time()
+    f.prepare()
+    out['prepare_s'] = time.time() - t
     log('upload %.0f s' % out['upload_s'])
     d_bases = torch.from_numpy(bases).cuda()
     d_off = torch.from_numpy(off.astype(np.int64)).cuda()
@@ -73,10 +76,7 @@ def main():
     log('step %.1f ms, %.3g seeds/s' % (dt * 1e3, out['seeds_per_s']))
     # properties (no oracle at this size): every seed of every error-free read is found where it was
     # sampled from, and sampled hits spell their seed
-    import ctypes
-    hits = np.zeros((n_hits, 4), np.uint64)
-    hip = ctypes.CDLL('libamdhip64.so')
-    assert hip.hipMemcpy(hits.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(n_hits * 32), 2) == 0
+    hits = f.copy_hits(ptr, n_hits)
     per_read = (150 - args.k) // args.k + 1
     found = np.unique(hits[:, 2] * np.uint64(1000) + hits[:, 3])
     out['all_seeds_found'] = bool(len(found) == args.reads * per_read)
