@@ -2265,7 +2265,7 @@ struct psigpu_ctx {
   hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
   // the pipeline's transfers, each direction on a copy engine of its own (see pipeline_init)
   struct EngineCopy {
-    bool ok = false;
+    bool ok = false, hsa_up = false;             // hsa_up: this context holds a reference on the HSA runtime
     hsa_agent_t gpu{}, cpu{};
     uint32_t eng_in = 0, eng_out = 0;            // hsa_amd_sdma_engine_id_t bits
     hsa_signal_t sig_in[2]{}, sig_out[2]{};      // per slot: 1 while the slot's transfer is in flight
@@ -2378,6 +2378,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
   }
   for (hipStream_t st : { ctx->s_in, ctx->s_comp, ctx->s_out }) if (st) (void)hipStreamDestroy(st);
   if (ctx->ec.ok) for (int i = 0; i < 2; ++i) { (void)hsa_signal_destroy(ctx->ec.sig_in[i]); (void)hsa_signal_destroy(ctx->ec.sig_out[i]); }
+  if (ctx->ec.hsa_up) (void)hsa_shut_down();
   if (ctx->have_events) for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -3570,6 +3571,7 @@ static void engine_copy_init(psigpu_ctx* ctx)
   ec.ok = false;
   if (getenv("PSIGPU_NO_ENGINE_COPY")) return;
   if (hsa_init() != HSA_STATUS_SUCCESS) return;
+  ec.hsa_up = true;                                           // released in psigpu_destroy (hsa_init is counted)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return;
   std::vector<hsa_agent_t> agents;
