@@ -366,6 +366,19 @@ int gpu_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in,
   return PSIGPU_OK;
 }
 
+// running maximum of a u64 array, in place (the path k-mers of the direct k-mer table build, device.hip)
+int gpu_running_max_u64(uint64_t* data, uint64_t n, std::string* err)
+{
+  if (n == 0) return PSIGPU_OK;
+  Buf tmp;
+  size_t need = 0;
+  GB_CHK(rocprim::inclusive_scan(nullptr, need, data, data, (size_t)n, rocprim::maximum<uint64_t>(), 0));
+  GB_CHK(tmp.alloc(need));
+  GB_CHK(rocprim::inclusive_scan(tmp.p, need, data, data, (size_t)n, rocprim::maximum<uint64_t>(), 0));
+  GB_CHK(hipDeviceSynchronize());
+  return PSIGPU_OK;
+}
+
 // ------------------------------------------------------------------------------------
 // Starting loci on the device (reference add_uncovered_loci,
 // include/psi/seed_finder.hpp:1481-1541, and add_all_loci :1543-1585 when no path is indexed).

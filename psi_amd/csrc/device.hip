@@ -1029,12 +1029,12 @@ k_lkt_probe(LktView lk, const uint64_t* __restrict__ seed_key, const uint64_t* _
 // k-mer table (PSIGPU_MODE_KMER_TABLE).  With the seed length fixed by the index, a seed is a
 // key: the table maps every k-mer of the indexed paths to its suffix-array interval (what the
 // backward search of K1 would return) and every k-mer spelled by a k-walk from a starting locus
-// to its run in the locus entries (what the traverser would find), in ONE 32-byte slot -- a
-// seed costs one random sector instead of interval table + row records + locus table.  A k-mer
-// with a single occurrence / a single locus carries that position in the slot.  The FM-index
-// kernels stay the path for any other seed length and when the table does not fit.
+// to its run in the locus entries (what the traverser would find), in ONE slot -- a seed costs
+// one random sector instead of interval table + row records + locus table.  A k-mer with a
+// single occurrence / a single locus carries that position in the slot.  The FM-index kernels
+// stay the path for any other seed length and when the table does not fit.
 // ------------------------------------------------------------------------------------
-struct KmerSlot {           // 32 bytes, two per 64-byte sector
+struct KmerSlot {           // the full description of a k-mer, 32 bytes: kept only for the few that need it (EXT)
   uint64_t key;             // KEY_INVALID: empty
   uint32_t on_a, on_b;      // on_cnt & KT_INLINE: (node rank, offset) of the only occurrence; else on_a = first SA row
   uint32_t off_a, off_b;    // off_cnt & KT_INLINE: (node rank, offset) of the only locus; else off_a = first locus entry
@@ -1043,11 +1043,11 @@ struct KmerSlot {           // 32 bytes, two per 64-byte sector
 static_assert(sizeof(KmerSlot) == 32, "k-mer table slot must be 32 bytes");
 constexpr uint32_t KT_INLINE = 0x80000000u;
 
-// What the query probes is a table of 16-BYTE slots made from the 32-byte records above: a
-// divergent 16-byte load is the unit the memory pipeline charges for (two loads per probe cost
-// twice: 27.9 G against 41.4 G probes/s, tools/rand_sector2.hip), and nearly every k-mer fits
-// one: its single occurrence, its single locus, or both at the same position.  The rest keep
-// their 32-byte record in a side array and pay a second access.
+// What the query probes is a table of 16-BYTE slots: a divergent 16-byte load is the unit the
+// memory pipeline charges for (two loads per probe cost twice: 27.9 G against 41.4 G probes/s,
+// tools/rand_sector2.hip), and nearly every k-mer fits one: its single occurrence, its single
+// locus, or both at the same position.  The rest keep a 32-byte record in a side array and pay a
+// second access.
 struct Slot16 {
   uint64_t kt;              // bits 0..61 the k-mer, bits 62..63 what (a, b) is
   uint32_t a, b;            // K16_ON1 / K16_OFF1 / K16_BOTH1: (node rank, offset); K16_EXT: a = index of the record
@@ -1056,7 +1056,10 @@ constexpr uint64_t K16_KEY = (1ull << 62) - 1;
 constexpr uint64_t K16_ON1 = 0, K16_OFF1 = 1, K16_BOTH1 = 2, K16_EXT = 3;   // empty slot: (a, b) == (NIL, NIL)
 constexpr uint32_t RES_INLINE = 0x80000000u, RES_EXT = 0x40000000u, RES_CNT = 0x3FFFFFFFu;
 
-struct KmerTableView { const Slot16* ht; uint64_t ht_mask; const KmerSlot* ext; };
+// any number of slots (the whole-genome table has to fit): slot = hash * n_slots / 2^64
+struct KmerTableView { const Slot16* ht; uint64_t n_slots; const KmerSlot* ext; };
+__device__ __forceinline__ uint64_t kt_home(uint64_t key, uint64_t n_slots) { return __umul64hi(mix64(key), n_slots); }
+__device__ __forceinline__ uint64_t kt_next(uint64_t h, uint64_t n_slots) { return h + 1 < n_slots ? h + 1 : 0; }
 
 __device__ __forceinline__ uint64_t slot16_type(const KmerSlot& r)
 {
@@ -1065,75 +1068,6 @@ __device__ __forceinline__ uint64_t slot16_type(const KmerSlot& r)
   if (off1 && r.on_cnt == 0) return K16_OFF1;
   if (on1 && off1 && r.on_a == r.off_a && r.on_b == r.off_b) return K16_BOTH1;
   return K16_EXT;
-}
-
-__global__ void k_kt_count_ext(const KmerSlot* __restrict__ big, uint64_t n, unsigned long long* __restrict__ n_ext)
-{
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool e = false;
-  if (i < n) { KmerSlot r = big[i]; e = r.key != KEY_INVALID && slot16_type(r) == K16_EXT; }
-  uint64_t m = __ballot(e);
-  if (m && lane_id() == 0) atomicAdd(n_ext, (unsigned long long)__popcll(m));
-}
-
-__global__ void k_kt_compress(const KmerSlot* __restrict__ big, uint64_t n, Slot16* __restrict__ ht, uint64_t ht_mask,
-                              KmerSlot* __restrict__ ext, unsigned long long* __restrict__ n_ext)
-{
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  KmerSlot r = big[i];
-  if (r.key == KEY_INVALID) return;
-  const uint64_t type = slot16_type(r);
-  uint32_t a = r.on_cnt ? r.on_a : r.off_a, b = r.on_cnt ? r.on_b : r.off_b;
-  if (type == K16_EXT) {
-    a = (uint32_t)atomicAdd(n_ext, 1ull); b = 0;
-    ext[a] = r;
-  }
-  // Keys are distinct: claim the first empty slot.  A slot is empty while its payload (a, b) is
-  // (NIL, NIL) -- the key word cannot say so: the all-T 31-mer with an EXT record is all ones too.
-  const unsigned long long payload = (unsigned long long)a | ((unsigned long long)b << 32);
-  uint64_t h = mix64(r.key) & ht_mask;
-  while (true) {
-    unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&ht[h].a), ~0ull, payload);
-    if (prev == ~0ull) { ht[h].kt = r.key | (type << 62); return; }
-    h = (h + 1) & ht_mask;
-  }
-}
-
-__global__ void k_kt_fill(KmerSlot* __restrict__ ht, uint64_t n)
-{
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint4* p = reinterpret_cast<uint4*>(ht + i);
-  p[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-  p[1] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-// k-mer at the head of every suffix-array row (KEY_INVALID when a separator or the end of the
-// text is within k symbols), and the number of rows that start a new k-mer
-__global__ void k_path_kmers(const uint32_t* __restrict__ sa, uint64_t n, uint32_t k, const uint64_t* __restrict__ text4,
-                             uint64_t* __restrict__ pk)
-{
-  uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= n) return;
-  uint32_t pos = sa[row];
-  uint64_t key = 0;
-  bool ok = (uint64_t)pos + k <= n;
-  for (uint32_t i = 0; ok && i < k; ++i) {
-    uint32_t a = pos + i;
-    uint64_t nib = (text4[a >> 4] >> (60 - 4 * (a & 15))) & 0xFull;
-    if (nib & 4) ok = false;
-    key = (key << 2) | (nib & 3);
-  }
-  pk[row] = ok ? key : KEY_INVALID;
-}
-
-__global__ void k_count_heads(const uint64_t* __restrict__ keys, uint64_t n, unsigned long long* __restrict__ out)
-{
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool head = i < n && keys[i] != KEY_INVALID && (i == 0 || keys[i - 1] != keys[i]);
-  uint64_t m = __ballot(head);
-  if (m && lane_id() == 0) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 
 // length of the run of equal keys starting at i (gallop, then bisect)
@@ -1150,58 +1084,136 @@ __device__ __forceinline__ uint64_t run_end(const uint64_t* __restrict__ keys, u
   return hi;
 }
 
-__device__ __forceinline__ KmerSlot* kt_claim(KmerSlot* __restrict__ ht, uint64_t ht_mask, uint64_t key)
+// ---- construction of the 16-byte slots -----------------------------------------------------------------
+// A table of full 32-byte records in between would take more than the device has at whole-genome size
+// (6.4 G k-mers), so the slots are made straight from the two sorted k-mer streams: the path k-mers in
+// suffix-array order and the sorted (k-mer, locus) pairs.  pk[row] = ((k-mer + 1) << 1) | 1 at rows whose
+// suffix starts with a k-mer, carried forward with the low bit cleared at the others (a max-scan: valid
+// k-mers are non-decreasing along the suffix array), so pk >> 1 is monotone and can be bisected.
+__global__ void k_pk_encode(const uint32_t* __restrict__ sa, uint64_t n, uint32_t k, const uint64_t* __restrict__ text4,
+                            uint64_t* __restrict__ pk)
 {
-  uint64_t h = mix64(key) & ht_mask;
+  uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  uint32_t pos = sa[row];
+  uint64_t key = 0;
+  bool ok = (uint64_t)pos + k <= n;
+  for (uint32_t i = 0; ok && i < k; ++i) {
+    uint32_t a = pos + i;
+    uint64_t nib = (text4[a >> 4] >> (60 - 4 * (a & 15))) & 0xFull;
+    if (nib & 4) ok = false;
+    key = (key << 2) | (nib & 3);
+  }
+  pk[row] = ok ? (((key + 1) << 1) | 1ull) : 0ull;
+}
+
+// after the max-scan: rows that are not the start of a k-mer keep the carried value with the low bit cleared
+__global__ void k_pk_fix(const uint32_t* __restrict__ sa, uint64_t n, uint32_t k, const uint64_t* __restrict__ text4,
+                         uint64_t* __restrict__ pk)
+{
+  uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  uint32_t pos = sa[row];
+  bool ok = (uint64_t)pos + k <= n;
+  for (uint32_t i = 0; ok && i < k; ++i) {
+    uint32_t a = pos + i;
+    if ((text4[a >> 4] >> (60 - 4 * (a & 15))) & 4ull) ok = false;
+  }
+  if (!ok) pk[row] &= ~1ull;
+}
+
+// first index in [lo, hi) with (a[i] >> sh) >= v
+__device__ __forceinline__ uint64_t lower_bound_sh(const uint64_t* __restrict__ a, uint64_t lo, uint64_t hi, uint64_t v, uint32_t sh)
+{
+  while (lo < hi) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if ((a[mid] >> sh) < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ void kt_place(Slot16* __restrict__ ht, uint64_t n_slots, uint64_t key, uint64_t type, uint32_t a, uint32_t b)
+{
+  const unsigned long long payload = (unsigned long long)a | ((unsigned long long)b << 32);
+  uint64_t h = kt_home(key, n_slots);
   while (true) {
-    unsigned long long prev = atomicCAS((unsigned long long*)&ht[h].key, (unsigned long long)KEY_INVALID,
-                                        (unsigned long long)key);
-    if (prev == KEY_INVALID || prev == key) return ht + h;
-    h = (h + 1) & ht_mask;
+    unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&ht[h].a), ~0ull, payload);
+    if (prev == ~0ull) { ht[h].kt = key | (type << 62); return; }
+    h = kt_next(h, n_slots);
   }
 }
 
-// path k-mers: the first row of every run claims a slot
-__global__ void k_kt_insert_on(const uint64_t* __restrict__ pk, uint64_t n, const uint32_t* __restrict__ sa,
+// One thread per suffix-array row; the first row of every run of equal path k-mers makes the k-mer's slot,
+// with what the starting loci contribute to it (found by bisection in the sorted pairs).
+// FILL = false: only count the k-mers that need a 32-byte record (EXT).
+template <bool FILL>
+__global__ void k_kt_direct_on(const uint64_t* __restrict__ pk, uint64_t n, const uint32_t* __restrict__ sa,
                                const SegRec* __restrict__ seg, const uint32_t* __restrict__ seg_rank,
-                               const uint32_t* __restrict__ seg_dir, KmerSlot* __restrict__ ht, uint64_t ht_mask)
+                               const uint32_t* __restrict__ seg_dir, const uint64_t* __restrict__ okeys,
+                               const uint32_t* __restrict__ ovals, uint64_t n_off, const uint2* __restrict__ loci,
+                               Slot16* __restrict__ ht, uint64_t n_slots, KmerSlot* __restrict__ ext,
+                               unsigned long long* __restrict__ n_ext, unsigned long long* __restrict__ n_heads)
 {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint64_t key = pk[i];
-  if (key == KEY_INVALID || (i && pk[i - 1] == key)) return;
-  uint64_t cnt = run_end(pk, n, i) - i;
-  KmerSlot* sl = kt_claim(ht, ht_mask, key);
-  if (cnt == 1) {
-    uint32_t p = sa[i];
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool head = false;
+  uint64_t v = 0;
+  if (i < n) { v = pk[i]; head = (v & 1ull) && (i == 0 || (pk[i - 1] >> 1) != (v >> 1)); }
+  if (!FILL) {
+    const uint64_t hm = __ballot(head);
+    if (hm && lane_id() == 0) atomicAdd(n_heads, (unsigned long long)__popcll(hm));
+  }
+  if (!head) return;
+  const uint64_t key = (v >> 1) - 1;
+  // rows of this k-mer: the rows carrying its value, minus the carried (low bit clear) ones at their end
+  const uint64_t r_end = lower_bound_sh(pk, i + 1, n, (v >> 1) + 1, 1);
+  uint64_t lo = i + 1, hi = r_end;                       // first row in (i, r_end) with the low bit clear
+  while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (pk[mid] & 1ull) lo = mid + 1; else hi = mid; }
+  const uint64_t on_cnt = lo - i;
+  const uint64_t j = lower_bound_sh(okeys, 0, n_off, key, 0);
+  uint64_t off_cnt = 0;
+  if (j < n_off && okeys[j] == key) off_cnt = lower_bound_sh(okeys, j + 1, n_off, key + 1, 0) - j;
+  KmerSlot r;
+  r.key = key; r.on_a = r.on_b = r.off_a = r.off_b = 0;
+  if (on_cnt == 1) {
+    const uint32_t p = sa[i];
     uint32_t d = seg_dir[p >> DIR_SHIFT];
     while (seg[d + 1].start <= p) ++d;
-    sl->on_a = seg_rank[d];
-    sl->on_b = seg[d].noff + (p - seg[d].start);
-    sl->on_cnt = 1u | KT_INLINE;
-  } else {
-    sl->on_a = (uint32_t)i;
-    sl->on_cnt = (uint32_t)min(cnt, (uint64_t)0x7FFFFFFFu);
-  }
+    r.on_a = seg_rank[d]; r.on_b = seg[d].noff + (p - seg[d].start); r.on_cnt = 1u | KT_INLINE;
+  } else { r.on_a = (uint32_t)i; r.on_cnt = (uint32_t)min(on_cnt, (uint64_t)0x7FFFFFFFu); }
+  if (off_cnt == 1) { const uint2 lc = loci[ovals[j]]; r.off_a = lc.x; r.off_b = lc.y; r.off_cnt = 1u | KT_INLINE; }
+  else { r.off_a = (uint32_t)j; r.off_cnt = (uint32_t)off_cnt; }
+  const uint64_t type = slot16_type(r);
+  if (type == K16_EXT) {
+    const unsigned long long e = atomicAdd(n_ext, 1ull);
+    if (FILL) { ext[e] = r; kt_place(ht, n_slots, key, type, (uint32_t)e, 0); }
+  } else if (FILL) kt_place(ht, n_slots, key, type, r.on_a, r.on_b);
 }
 
-// k-mers of the starting loci's k-walks (sorted pairs): first entry of every run
-__global__ void k_kt_insert_off(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                const uint2* __restrict__ loci, uint64_t n, KmerSlot* __restrict__ ht, uint64_t ht_mask)
+// One thread per sorted (k-mer, locus) pair; the first pair of every run whose k-mer is NOT a path k-mer
+// makes the slot (the others were made by k_kt_direct_on).
+template <bool FILL>
+__global__ void k_kt_direct_off(const uint64_t* __restrict__ okeys, const uint32_t* __restrict__ ovals, uint64_t n_off,
+                                const uint2* __restrict__ loci, const uint64_t* __restrict__ pk, uint64_t n,
+                                Slot16* __restrict__ ht, uint64_t n_slots, KmerSlot* __restrict__ ext,
+                                unsigned long long* __restrict__ n_ext)
 {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint64_t key = keys[i];
-  if (i && keys[i - 1] == key) return;
-  uint64_t cnt = run_end(keys, n, i) - i;
-  KmerSlot* sl = kt_claim(ht, ht_mask, key);
-  if (cnt == 1) {
-    uint2 lc = loci[vals[i]];
-    sl->off_a = lc.x; sl->off_b = lc.y;
-    sl->off_cnt = 1u | KT_INLINE;
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_off) return;
+  const uint64_t key = okeys[j];
+  if (j && okeys[j - 1] == key) return;
+  const uint64_t at = lower_bound_sh(pk, 0, n, key + 1, 1);
+  if (at < n && (pk[at] >> 1) == key + 1) return;        // a path k-mer: its slot holds the loci too
+  const uint64_t off_cnt = lower_bound_sh(okeys, j + 1, n_off, key + 1, 0) - j;
+  if (off_cnt == 1) {
+    if (FILL) { const uint2 lc = loci[ovals[j]]; kt_place(ht, n_slots, key, K16_OFF1, lc.x, lc.y); }
   } else {
-    sl->off_a = (uint32_t)i;
-    sl->off_cnt = (uint32_t)cnt;
+    const unsigned long long e = atomicAdd(n_ext, 1ull);
+    if (FILL) {
+      KmerSlot r;
+      r.key = key; r.on_a = r.on_b = 0; r.on_cnt = 0; r.off_a = (uint32_t)j; r.off_b = 0; r.off_cnt = (uint32_t)off_cnt;
+      ext[e] = r;
+      kt_place(ht, n_slots, key, K16_EXT, (uint32_t)e, 0);
+    }
   }
 }
 
@@ -1226,7 +1238,7 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
     const uint64_t key = seed_key[seed];
     uint4 res = make_uint4(0, 0, 0, 0);
     if (key != KEY_INVALID) {
-      uint64_t h = mix64(key) & kt.ht_mask;
+      uint64_t h = kt_home(key, kt.n_slots);
       while (true) {
         const uint4 v = *reinterpret_cast<const uint4*>(kt.ht + h);
         const uint64_t w = (uint64_t)v.x | ((uint64_t)v.y << 32);
@@ -1246,7 +1258,7 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
           break;
         }
         if (empty) break;
-        h = (h + 1) & kt.ht_mask;
+        h = kt_next(h, kt.n_slots);
       }
     }
     seed_res[seed] = res;
@@ -2211,7 +2223,7 @@ struct psigpu_ctx {
   // index
   bool have_index = false;
   uint32_t index_k = 0, sa_rate = 0, context = 0, n_paths = 0;
-  uint64_t text_len = 0, n_exc = 0, n_loci = 0;
+  uint64_t text_len = 0, n_exc = 0, n_loci = 0, n_segs = 0;
   uint64_t C[4] = { 0, 0, 0, 0 };
   uint32_t ftab_len = 0;
   DevBuf ftab, text4;
@@ -2545,6 +2557,8 @@ int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
   return PSIGPU_OK;
 }
 
+static int build_row_records(psigpu_ctx* ctx, uint32_t k);
+
 int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
 {
   if (!ctx || !x) return PSIGPU_ERR_ARG;
@@ -2606,35 +2620,51 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
     if ((st = upload(ctx, ctx->loci, lc.data(), x->n_loci, 1))) return st;
   }
   if ((st = upload(ctx, ctx->seg_rank, x->seg_node, x->n_segs, 1))) return st;
+  ctx->index_k = x->seed_len; ctx->sa_rate = x->sa_rate; ctx->context = x->context;
+  ctx->n_paths = x->n_paths; ctx->text_len = x->text_len; ctx->n_exc = x->n_exc; ctx->n_segs = x->n_segs;
+  if ((st = build_row_records(ctx, x->seed_len))) return st;
+  ctx->index_k = x->seed_len; ctx->sa_rate = x->sa_rate; ctx->context = x->context;
+  ctx->n_paths = x->n_paths; ctx->text_len = x->text_len; ctx->n_exc = x->n_exc;
+  ctx->n_loci = x->n_loci;
+  for (int i = 0; i < 4; ++i) ctx->C[i] = x->C[i];
+  ctx->have_index = true;
+  lkt_release(ctx);
+  return PSIGPU_OK;
+}
+
+// Per-row records of the FM modes (SaRec for seed length k, and the located suffix array): derived from
+// the suffix array, the text and the segment table that are already on the device.  Skipped (not an error)
+// when they do not fit or do not apply.
+static int build_row_records(psigpu_ctx* ctx, uint32_t k)
+{
   ctx->sarec_k = 0;
   ctx->sarec.release();
+  ctx->have_saloc = false;
+  ctx->saloc.release();
   static const bool no_sarec = getenv("PSIGPU_NO_SAREC") != nullptr;         // A/B
-  if (x->sa_rate == 1 && ctx->have_text4 && ctx->ftab_len && x->seed_len >= ctx->ftab_len &&
-      x->seed_len - ctx->ftab_len <= 29 && x->n_segs && !no_sarec) {
-    // per-row records for the index's seed length; skipped (not an error) when they do not fit
-    DevBuf& seg_rank = ctx->seg_rank;
-    hipError_t e = ctx->sarec.ensure(x->n_samples * sizeof(SaRec));
+  const uint64_t n_rows = (ctx->text_len + ctx->sa_rate - 1) / ctx->sa_rate;
+  if (ctx->sa_rate == 1 && ctx->have_text4 && ctx->ftab_len && k >= ctx->ftab_len && k - ctx->ftab_len <= 29 &&
+      ctx->n_segs && !no_sarec) {
+    hipError_t e = ctx->sarec.ensure(n_rows * sizeof(SaRec));
     if (e == hipSuccess) {
-      k_build_sarec<<<(unsigned)((x->n_samples + 255) / 256), 256>>>(
-          ctx->samples.as<uint32_t>(), x->n_samples, x->seed_len - ctx->ftab_len, ctx->seg.as<SegRec>(),
-          seg_rank.as<uint32_t>(), ctx->seg_dir.as<uint32_t>(), ctx->text4.as<uint64_t>(), ctx->sarec.as<SaRec>());
+      k_build_sarec<<<(unsigned)((n_rows + 255) / 256), 256>>>(
+          ctx->samples.as<uint32_t>(), n_rows, k - ctx->ftab_len, ctx->seg.as<SegRec>(), ctx->seg_rank.as<uint32_t>(),
+          ctx->seg_dir.as<uint32_t>(), ctx->text4.as<uint64_t>(), ctx->sarec.as<SaRec>());
       HIPCHK(ctx, hipDeviceSynchronize());
-      ctx->sarec_k = x->seed_len;
+      ctx->sarec_k = k;
     } else {
       (void)hipGetLastError();
       ctx->sarec.release();
     }
   }
-  ctx->have_saloc = false;
-  ctx->saloc.release();
-  if (x->sa_rate == 1 && x->n_segs && !no_sarec) {
+  if (ctx->sa_rate == 1 && ctx->n_segs && !no_sarec) {
     // located suffix array: only when it is a small part of what is free (the tables come later)
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)x->n_samples * 8 * 6 < free_b &&
-        ctx->saloc.ensure(x->n_samples * sizeof(uint2)) == hipSuccess) {
-      k_build_saloc<<<(unsigned)((x->n_samples + 255) / 256), 256>>>(ctx->samples.as<uint32_t>(), x->n_samples,
-                                                                    ctx->seg.as<SegRec>(), ctx->seg_rank.as<uint32_t>(),
-                                                                    ctx->seg_dir.as<uint32_t>(), ctx->saloc.as<uint2>());
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)n_rows * 8 * 6 < free_b &&
+        ctx->saloc.ensure(n_rows * sizeof(uint2)) == hipSuccess) {
+      k_build_saloc<<<(unsigned)((n_rows + 255) / 256), 256>>>(ctx->samples.as<uint32_t>(), n_rows, ctx->seg.as<SegRec>(),
+                                                               ctx->seg_rank.as<uint32_t>(), ctx->seg_dir.as<uint32_t>(),
+                                                               ctx->saloc.as<uint2>());
       HIPCHK(ctx, hipDeviceSynchronize());
       ctx->have_saloc = true;
     } else {
@@ -2642,12 +2672,61 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
       ctx->saloc.release();
     }
   }
-  ctx->index_k = x->seed_len; ctx->sa_rate = x->sa_rate; ctx->context = x->context;
-  ctx->n_paths = x->n_paths; ctx->text_len = x->text_len; ctx->n_exc = x->n_exc;
-  ctx->n_loci = x->n_loci;
-  for (int i = 0; i < 4; ++i) ctx->C[i] = x->C[i];
-  ctx->have_index = true;
-  lkt_release(ctx);
+  return PSIGPU_OK;
+}
+
+// The k-mer table built straight into its 16-byte slots (see k_pk_encode).  `okeys` / `ovals`: the sorted
+// (k-mer, locus) pairs.  Returns PSIGPU_ERR_NOMEM when it does not fit either (kt_ready stays false).
+static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, const uint32_t* ovals, uint64_t n_off,
+                           unsigned long long* d_cnt /* two counters */)
+{
+  const uint64_t n_rows = ctx->text_len;
+  TmpBuf pk;
+  if (pk.alloc((n_rows + 1) * 8) != hipSuccess) { (void)hipGetLastError(); return PSIGPU_ERR_NOMEM; }
+  const unsigned grid_rows = (unsigned)((n_rows + 255) / 256), grid_off = (unsigned)((n_off + 255) / 256);
+  k_pk_encode<<<grid_rows, 256>>>(ctx->samples.as<uint32_t>(), n_rows, k, ctx->text4.as<uint64_t>(), pk.as<uint64_t>());
+  {
+    std::string serr;
+    int st = psigpu::gpu_running_max_u64(pk.as<uint64_t>(), n_rows, &serr);
+    if (st != PSIGPU_OK) { (void)hipGetLastError(); return PSIGPU_ERR_NOMEM; }
+  }
+  k_pk_fix<<<grid_rows, 256>>>(ctx->samples.as<uint32_t>(), n_rows, k, ctx->text4.as<uint64_t>(), pk.as<uint64_t>());
+  // pass 1: how many k-mers need a 32-byte record, how many path k-mers there are
+  HIPCHK(ctx, hipMemset(d_cnt, 0, 16));
+  k_kt_direct_on<false><<<grid_rows, 256>>>(pk.as<uint64_t>(), n_rows, ctx->samples.as<uint32_t>(), ctx->seg.as<SegRec>(),
+                                            ctx->seg_rank.as<uint32_t>(), ctx->seg_dir.as<uint32_t>(), okeys, ovals, n_off,
+                                            ctx->loci.as<uint2>(), nullptr, 0, nullptr, d_cnt, d_cnt + 1);
+  if (n_off)
+    k_kt_direct_off<false><<<grid_off, 256>>>(okeys, ovals, n_off, ctx->loci.as<uint2>(), pk.as<uint64_t>(), n_rows, nullptr, 0,
+                                              nullptr, d_cnt);
+  unsigned long long h[2] = { 0, 0 };
+  HIPCHK(ctx, hipMemcpy(h, d_cnt, 16, hipMemcpyDeviceToHost));
+  const uint64_t n_ext = h[0], n_on = h[1];
+  if (n_ext >= 0xFFFFFFF0ull) return PSIGPU_ERR_NOMEM;
+  // slots: load 0.5 when there is room, down to 0.75 when there is not
+  uint64_t slots = 0;
+  hipError_t e = hipErrorOutOfMemory;
+  for (uint64_t pct : { 200ull, 160ull, 133ull }) {
+    slots = std::max<uint64_t>(1024, (n_on + n_off) * pct / 100);      // (an upper bound on the distinct k-mers)
+    e = ctx->kt_ht.ensure(slots * sizeof(Slot16));
+    if (e == hipSuccess) e = ctx->kt_ext.ensure((n_ext + 1) * sizeof(KmerSlot));
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    ctx->kt_ht.release(); ctx->kt_ext.release();
+  }
+  if (e != hipSuccess) return PSIGPU_ERR_NOMEM;
+  HIPCHK(ctx, hipMemset(ctx->kt_ht.p, 0xFF, slots * sizeof(Slot16)));
+  HIPCHK(ctx, hipMemset(d_cnt, 0, 16));
+  k_kt_direct_on<true><<<grid_rows, 256>>>(pk.as<uint64_t>(), n_rows, ctx->samples.as<uint32_t>(), ctx->seg.as<SegRec>(),
+                                           ctx->seg_rank.as<uint32_t>(), ctx->seg_dir.as<uint32_t>(), okeys, ovals, n_off,
+                                           ctx->loci.as<uint2>(), ctx->kt_ht.as<Slot16>(), slots, ctx->kt_ext.as<KmerSlot>(),
+                                           d_cnt, d_cnt + 1);
+  if (n_off)
+    k_kt_direct_off<true><<<grid_off, 256>>>(okeys, ovals, n_off, ctx->loci.as<uint2>(), pk.as<uint64_t>(), n_rows,
+                                             ctx->kt_ht.as<Slot16>(), slots, ctx->kt_ext.as<KmerSlot>(), d_cnt);
+  HIPCHK(ctx, hipDeviceSynchronize());
+  ctx->kt_ht_size = slots; ctx->kt_n_path_kmers = n_on; ctx->kt_n_ext = n_ext;
+  ctx->kt_ready = true;
   return PSIGPU_OK;
 }
 
@@ -2866,54 +2945,29 @@ static int ensure_lkt(psigpu_ctx* ctx, uint32_t k, const GraphView& gv)
     sorted_keys = keys_b.as<uint64_t>(); sorted_vals = ctx->lkt_ent.as<uint32_t>();
     keys_a.drop(); vals_a.drop();
   }
-  // k-mer table mode: path k-mers and locus k-mers in one table of 32-byte slots (needs the whole
-  // suffix array and the text on the device); when it does not fit, the 16-byte locus table below
+  // k-mer table mode: path k-mers and locus k-mers in one table of 16-byte slots (needs the whole suffix
+  // array and the text on the device); when it does not fit, the 16-byte locus table below
   if (ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->sa_rate == 1 && ctx->have_text4 && ctx->n_paths) {
-    const uint64_t n_rows = ctx->text_len;
-    TmpBuf pk;
-    hipError_t e = pk.alloc((n_rows + 1) * 8);
-    uint64_t n_on = 0;
-    if (e == hipSuccess) {
-      k_path_kmers<<<(unsigned)((n_rows + 255) / 256), 256>>>(ctx->samples.as<uint32_t>(), n_rows, k, ctx->text4.as<uint64_t>(),
-                                                             pk.as<uint64_t>());
-      HIPCHK(ctx, hipMemset(d_dropped, 0, 8));
-      k_count_heads<<<(unsigned)((n_rows + 255) / 256), 256>>>(pk.as<uint64_t>(), n_rows, d_dropped);
-      HIPCHK(ctx, hipMemcpy(&n_on, d_dropped, 8, hipMemcpyDeviceToHost));
-      uint64_t slots = 1024;
-      while (slots < 2 * (n_on + n_ent)) slots <<= 1;
-      // 32-byte records first (temporary), then the 16-byte slots the query probes
-      TmpBuf big;
-      e = big.alloc(slots * sizeof(KmerSlot));
-      if (e == hipSuccess) e = ctx->kt_ht.ensure(slots * sizeof(Slot16));
-      if (e == hipSuccess) {
-        k_kt_fill<<<(unsigned)((slots + 255) / 256), 256>>>(big.as<KmerSlot>(), slots);
-        k_kt_insert_on<<<(unsigned)((n_rows + 255) / 256), 256>>>(pk.as<uint64_t>(), n_rows, ctx->samples.as<uint32_t>(),
-                                                                 ctx->seg.as<SegRec>(), ctx->seg_rank.as<uint32_t>(),
-                                                                 ctx->seg_dir.as<uint32_t>(), big.as<KmerSlot>(), slots - 1);
-        if (n_ent)
-          k_kt_insert_off<<<(unsigned)((n_ent + 255) / 256), 256>>>(sorted_keys, sorted_vals, ctx->loci.as<uint2>(), n_ent,
-                                                                   big.as<KmerSlot>(), slots - 1);
-        unsigned long long n_ext = 0;
-        HIPCHK(ctx, hipMemset(d_dropped, 0, 8));
-        k_kt_count_ext<<<(unsigned)((slots + 255) / 256), 256>>>(big.as<KmerSlot>(), slots, d_dropped);
-        HIPCHK(ctx, hipMemcpy(&n_ext, d_dropped, 8, hipMemcpyDeviceToHost));
-        e = ctx->kt_ext.ensure((n_ext + 1) * sizeof(KmerSlot));
-        if (e == hipSuccess && n_ext < 0xFFFFFFF0ull) {
-          HIPCHK(ctx, hipMemset(ctx->kt_ht.p, 0xFF, slots * sizeof(Slot16)));
-          HIPCHK(ctx, hipMemset(d_dropped, 0, 8));
-          k_kt_compress<<<(unsigned)((slots + 255) / 256), 256>>>(big.as<KmerSlot>(), slots, ctx->kt_ht.as<Slot16>(), slots - 1,
-                                                                 ctx->kt_ext.as<KmerSlot>(), d_dropped);
-          HIPCHK(ctx, hipDeviceSynchronize());
-          ctx->kt_ht_size = slots; ctx->kt_n_path_kmers = n_on; ctx->kt_n_ext = n_ext;
-          ctx->kt_ready = true;
-        }
-      }
-    }
-    if (!ctx->kt_ready) {
+    int st = build_kt_direct(ctx, k, sorted_keys, sorted_vals, n_ent, d_dropped);
+    if (st == PSIGPU_ERR_NOMEM) {
+      // not beside the per-row records of the FM modes (whole-genome indexes): give those up for the room;
+      // they are made again if the table does not fit even then
       (void)hipGetLastError();
       ctx->kt_ht.release(); ctx->kt_ext.release();
-      ctx->lkt_note = "k-mer table does not fit the device: path k-mers stay with the FM index";
+      const bool had_rows = ctx->sarec_k != 0 || ctx->have_saloc;
+      const uint32_t sarec_k_was = ctx->sarec_k ? ctx->sarec_k : ctx->index_k;
+      ctx->sarec.release(); ctx->saloc.release();
+      ctx->sarec_k = 0; ctx->have_saloc = false;
+      st = had_rows ? build_kt_direct(ctx, k, sorted_keys, sorted_vals, n_ent, d_dropped) : PSIGPU_ERR_NOMEM;
+      if (st == PSIGPU_ERR_NOMEM) {
+        (void)hipGetLastError();
+        ctx->kt_ht.release(); ctx->kt_ext.release();
+        ctx->lkt_note = "k-mer table does not fit the device: path k-mers stay with the FM index";
+        if (had_rows) { int rs = build_row_records(ctx, sarec_k_was); if (rs != PSIGPU_OK) return rs; }
+        st = PSIGPU_OK;
+      }
     }
+    if (st != PSIGPU_OK) return st;
   }
   uint64_t ht_size = 1024;
   if (!ctx->kt_ready) {
@@ -3190,7 +3244,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         if (probe) lk = LktView{ ctx->lkt_ht.as<TableSlot>(), ctx->lkt_ht_size, ctx->lkt_ent.as<LocusEnt>() };
         bool probed = false;
         if (kprobe) {
-          KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size - 1, ctx->kt_ext.as<KmerSlot>() };
+          KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
           k_kmer_probe<<<grid, 256, 0, stream>>>(kt, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave,
                                                  (flags & PSIGPU_ON_PATHS) != 0, want_off, thr, ctx->w_seedres.as<uint4>(),
                                                  ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), ctr);

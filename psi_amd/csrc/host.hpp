@@ -84,6 +84,7 @@ int gpu_find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_
                            int device, std::vector<uint32_t>& loci_node, std::vector<uint32_t>& loci_off, std::string* err);
 int gpu_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, uint64_t n,
                        unsigned end_bit, std::string* err);
+int gpu_running_max_u64(uint64_t* data, uint64_t n, std::string* err);
 
 // hits.cpp: parallel sort-unique of hit records by (read_id, read_offset, node_id, node_offset) on the
 // host: only for records that do not fit the device sorter's 64-bit key (HitSorter::fits)

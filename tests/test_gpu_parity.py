@@ -538,6 +538,8 @@ def test_config2_whole_genome(query_mode):
                                      stream=torch.cuda.current_stream().cuda_stream)
     c = f.counters()
     assert c['n_seeds'] == 70_000_000 and c['n_hits'] == n_hits
+    print('whole genome: %d path k-mers + %d locus k-mers tabulated, %.1f ms on the device for 10 M reads' %
+          (c['n_path_kmers'], c['n_locus_kmers'], c['ms_total']))
     hits = f.copy_hits(ptr, n_hits)
     # sensitivity: every seed of every (error-free) read is found; specificity: first bases agree
     assert len(np.unique(hits[:, 2] * np.uint64(1000) + hits[:, 3])) == 70_000_000
