@@ -27,6 +27,7 @@ extern "C" {
 
 #define PSIGPU_ABI_VERSION 3
 #define PSIGPU_MAX_SEED_LEN 31u   /* seeds are 2-bit packed into one 64-bit word */
+#define PSIGPU_MAX_PARTS 8u       /* parts of an index whose text passes the 32-bit row limit */
 
 /* Status codes */
 enum {
@@ -122,6 +123,14 @@ typedef struct psigpu_index_view {
   uint64_t n_loci;
   const uint32_t* loci_node;
   const uint32_t* loci_off;
+  /* further PARTS of the index: rows, text positions and table indexes are 32 bits wide, so paths
+   * whose concatenation would pass 2^32 symbols are indexed in groups, each with a text, FM arrays and
+   * a segment table of its own (the fields from text_len to seg_dir; seed_len, n_paths, the loci and
+   * this list are read from the first part only).  An index in several parts is answered from the
+   * k-mer table (PSIGPU_MODE_KMER_TABLE): its k-mers are tabulated over all parts at psigpu_prepare. */
+  uint32_t n_more_parts;
+  uint32_t reserved2;
+  const struct psigpu_index_view* more_parts;     /* [n_more_parts] */
 } psigpu_index_view;
 
 /* ------------------------------------------------------------------------------------
@@ -166,6 +175,9 @@ typedef struct psigpu_index_opts {
   uint32_t patched;        /* psikt's default (no -P): index the first walk of a region whole and of every
                               further walk only the stretches no earlier walk covers (psigpu_index_build only) */
   uint32_t reserved1;
+  uint64_t max_part_text;  /* text symbols per index part; 0 = the 32-bit row limit (2^32 - 256 on the device,
+                              2^31 - 16 on the host).  An index whose paths do not fit one part is made in
+                              several (whole-genome graphs with several indexed walks); tests set it small */
 } psigpu_index_opts;
 
 /* SeedFinder::create_path_index(n, patched, context, step_size, ...) (seed_finder.hpp:1330-1355):

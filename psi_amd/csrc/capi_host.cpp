@@ -172,12 +172,10 @@ psigpu_index* psigpu_index_build_patches(const psigpu_graph* g, const psigpu_ind
 
 void psigpu_index_free(psigpu_index* x) { delete x; }
 
-int psigpu_index_view_get(const psigpu_index* h, psigpu_index_view* v)
+static void fill_view(const Index& x, const Index& first, psigpu_index_view* v)
 {
-  if (!h || !v) return PSIGPU_ERR_ARG;
-  const Index& x = h->x;
-  v->seed_len = x.k; v->sa_rate = x.sa_rate; v->context = x.context;
-  v->n_paths = (uint32_t)x.paths.size();
+  v->seed_len = first.k; v->sa_rate = x.sa_rate; v->context = first.context;
+  v->n_paths = (uint32_t)first.paths.size();
   v->text_len = x.n;
   v->n_blocks = x.blocks.size();
   v->bwt_blocks = x.blocks.data();
@@ -190,6 +188,17 @@ int psigpu_index_view_get(const psigpu_index* h, psigpu_index_view* v)
   v->seg_start = x.seg_start.data(); v->seg_node = x.seg_node.data(); v->seg_noff = x.seg_noff.data();
   v->n_dir = x.seg_dir.size(); v->seg_dir = x.seg_dir.data();
   v->n_loci = x.loci_node.size(); v->loci_node = x.loci_node.data(); v->loci_off = x.loci_off.data();
+  v->n_more_parts = 0; v->reserved2 = 0; v->more_parts = nullptr;
+}
+
+int psigpu_index_view_get(const psigpu_index* h, psigpu_index_view* v)
+{
+  if (!h || !v) return PSIGPU_ERR_ARG;
+  fill_view(h->x, h->x, v);
+  h->more_views.resize(h->x.more.size());
+  for (size_t i = 0; i < h->x.more.size(); ++i) fill_view(h->x.more[i], h->x, &h->more_views[i]);
+  v->n_more_parts = (uint32_t)h->more_views.size();
+  v->more_parts = h->more_views.empty() ? nullptr : h->more_views.data();
   return PSIGPU_OK;
 }
 

@@ -55,6 +55,10 @@ struct Index {
   std::vector<uint32_t> loci_node, loci_off;
   std::vector<uint8_t> text;                   // kept only on request
   std::vector<int32_t> sa;                     // kept only on request
+  // An index whose text would pass the 32-bit row limit is made in several PARTS: consecutive groups
+  // of paths, each with its own text, FM arrays and segment table (the fields above; paths, loci and the
+  // scalars live in the first part only).  Parts beyond the first:
+  std::vector<Index> more;
 };
 
 // graph.cpp
@@ -111,4 +115,7 @@ Index* load_index(const std::string& prefix, int* status);
 }  // namespace psigpu
 
 struct psigpu_graph { psigpu::Graph g; };
-struct psigpu_index { psigpu::Index x; };
+struct psigpu_index {
+  psigpu::Index x;
+  mutable std::vector<psigpu_index_view> more_views;      // views of x.more, handed out by psigpu_index_view_get
+};

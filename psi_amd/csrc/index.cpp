@@ -218,6 +218,172 @@ static inline int base_sym(char ch)
   }
 }
 
+// FM arrays + segment table over the concatenation of paths [p0, p1): one PART of the index (an index
+// is one part unless its text would pass the 32-bit row limit).  `head` / `tail`: per-path trimming.
+static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa_rate, bool keep, bool no_ftab,
+                      const std::vector<std::vector<uint32_t>>& paths, const std::vector<uint32_t>& head,
+                      const std::vector<uint32_t>& tail, size_t p0, size_t p1, Index* x, std::string* err)
+{
+  x->sa_rate = sa_rate;
+  // ---- text + segments -----------------------------------------------------------
+  std::vector<uint8_t> T;
+  uint64_t est = 1;
+  for (size_t pi = p0; pi < p1; ++pi) { for (uint32_t v : paths[pi]) est += g.node_len(v); ++est; }
+  T.reserve(est);
+  auto& ss = x->seg_start; auto& sn = x->seg_node; auto& so = x->seg_noff;
+  bool first_path = true;
+  for (size_t pi = p0; pi < p1; ++pi) {
+    const auto& P = paths[pi];
+    if (P.empty()) continue;
+    if (!first_path) T.push_back(SYM_SEP);
+    first_path = false;
+    bool in_gap = false;           // last emitted symbol was a separator for an N run
+    for (size_t si = 0; si < P.size(); ++si) {
+      const uint32_t v = P[si];
+      const char* lab = g.labels.data() + g.label_off[v];
+      // a patched path starts at its head offset and ends after its tail length
+      // (Path::left / right, path_base.hpp:113-114, :240-246)
+      const uint64_t o_begin = si == 0 ? head[pi] : 0;
+      const uint64_t len = (si + 1 == P.size() && tail[pi]) ? tail[pi] : g.node_len(v);
+      bool open = false;           // a segment of this node is open
+      for (uint64_t o = o_begin; o < len; ++o) {
+        int s = base_sym(lab[o]);
+        if (s < 0) {
+          if (!in_gap) { T.push_back(SYM_SEP); in_gap = true; }
+          open = false;
+          continue;
+        }
+        if (!open) {
+          ss.push_back((uint32_t)T.size()); sn.push_back(v); so.push_back((uint32_t)o);
+          open = true;
+        }
+        in_gap = false;
+        T.push_back((uint8_t)s);
+      }
+    }
+  }
+  T.push_back(SYM_END);
+  const uint64_t n = T.size();
+  x->n = n;
+  if (ss.empty() || ss[0] != 0) {          // position 0 must belong to a segment
+    ss.insert(ss.begin(), 0); sn.insert(sn.begin(), NO_NODE); so.insert(so.begin(), 0);
+  }
+  ss.push_back((uint32_t)n);
+  {
+    uint64_t nd = (n >> DIR_SHIFT) + 1;
+    x->seg_dir.resize(nd);
+    uint64_t s = 0;
+    for (uint64_t i = 0; i < nd; ++i) {
+      uint64_t pos = i << DIR_SHIFT;
+      while (s + 1 < sn.size() && ss[s + 1] <= pos) ++s;
+      x->seg_dir[i] = (uint32_t)s;
+    }
+  }
+
+  // interval-table length
+  uint32_t q = opts.ftab_len;
+  if (q == 0) {                       // auto: ceil(log4 n); at most 13 (512 MiB) when built on the host,
+    q = 1;                            // 15 (8 GiB: whole-genome texts) when built on the device -- 16 can be asked for, but the
+                                      // 32-GiB table was measured slower at 2.95 G symbols (its own misses cost more than the rows it saves)
+    const uint32_t q_max = opts.build_on_device ? 15 : 13;
+    while (q < q_max && (1ull << (2 * q)) < n) ++q;
+  }
+  if (q == 0xFFFFFFFFu || p0 == p1 || no_ftab) q = 0;
+  // (the host builder marks "no q-mer here" with a 32-bit all-ones code: 16-mers need the device builder)
+  if (q > 16 || (q == 16 && !opts.build_on_device)) {
+    *err = "ftab_len above 16 (15 for host builds)"; return PSIGPU_ERR_ARG;
+  }
+
+  std::vector<int32_t> SA;
+  if (opts.build_on_device) {
+    // suffix array, rank blocks, samples, exceptions, interval table, 4-bit text on the GPU
+    int st = gpu_build_fm(T, sa_rate, q, (int)opts.build_on_device - 1, x, keep ? &SA : nullptr, err);
+    if (st != PSIGPU_OK) return st;
+  } else {
+  // ---- suffix array ----------------------------------------------------------------
+  SA.resize(n);
+  suffix_array(T.data(), SA.data(), (int32_t)n, 6);
+
+  // ---- BWT rank blocks, samples, exceptions -----------------------------------------
+  uint64_t nblk = n / BLOCK_SYMS + 1;
+  x->blocks.assign(nblk, RankBlock{ { 0, 0, 0 }, 0, { 0, 0, 0, 0, 0, 0 } });
+  x->samples.resize((n + sa_rate - 1) / sa_rate);
+  uint64_t cnt[4] = { 0, 0, 0, 0 }, nexc = 0, nsep = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t b = i / BLOCK_SYMS, j = i % BLOCK_SYMS;
+    if (j == 0) {
+      RankBlock& B = x->blocks[b];
+      B.cnt[0] = (uint32_t)cnt[0]; B.cnt[1] = (uint32_t)cnt[1]; B.cnt[2] = (uint32_t)cnt[2];
+      B.exc = (uint32_t)(nexc << 8);
+    }
+    uint8_t c = SA[i] ? T[SA[i] - 1] : T[n - 1];
+    uint64_t two;
+    if (c >= SYM_A) { two = c - SYM_A; ++cnt[two]; }
+    else {
+      two = 0;
+      x->exc_row.push_back((uint32_t)i);
+      x->exc_sa.push_back((uint32_t)SA[i]);
+      ++nexc;
+      RankBlock& B = x->blocks[b];
+      if ((B.exc & 0xFF) < 255) ++B.exc;
+      if (c == SYM_SEP) ++nsep;
+    }
+    // bit planes per group of 64 symbols: word 2g = low bits, word 2g+1 = high bits
+    x->blocks[b].sym[2 * (j >> 6)] |= (two & 1) << (j & 63);
+    x->blocks[b].sym[2 * (j >> 6) + 1] |= (two >> 1) << (j & 63);
+    if (i % sa_rate == 0) x->samples[i / sa_rate] = (uint32_t)SA[i];
+  }
+  if (n % BLOCK_SYMS == 0) {
+    RankBlock& B = x->blocks[nblk - 1];
+    B.cnt[0] = (uint32_t)cnt[0]; B.cnt[1] = (uint32_t)cnt[1]; B.cnt[2] = (uint32_t)cnt[2];
+    B.exc = (uint32_t)(nexc << 8);
+  }
+  if (nexc >= (1u << 24)) {
+    *err = "too many separators in the indexed text"; return PSIGPU_ERR_ARG;
+  }
+  x->C[0] = 1 + nsep;
+  x->C[1] = x->C[0] + cnt[0];
+  x->C[2] = x->C[1] + cnt[1];
+  x->C[3] = x->C[2] + cnt[2];
+
+  // ---- the text itself, 4 bits per symbol ---------------------------------------------------
+  x->text4.assign(n / 16 + 2, 0);
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t nib = T[i] >= SYM_A ? (uint64_t)(T[i] - SYM_A) : 4ull;
+    x->text4[i >> 4] |= nib << (60 - 4 * (i & 15));
+  }
+
+  // ---- interval table for the last q bases of a seed -----------------------------------
+  {
+    x->ftab_len = q;
+    if (q) {
+      // code[p] = 2-bit code of T[p, p+q) (first base most significant) or NONE
+      const uint32_t NONE = 0xFFFFFFFFu;
+      std::vector<uint32_t> code(n, NONE);
+      uint32_t mask = (uint32_t)((1ull << (2 * q)) - 1), run = 0, good = 0;
+      for (uint64_t i = 0; i < n; ++i) {          // rolling over windows ending at i
+        uint8_t c = T[i];
+        if (c >= SYM_A) { run = ((run << 2) | (uint32_t)(c - SYM_A)) & mask; ++good; }
+        else { run = 0; good = 0; }
+        if (good >= q) code[i + 1 - q] = run;
+      }
+      x->ftab.assign(2ull << (2 * q), 0);
+      for (uint64_t i = 0; i < n; ++i) {
+        uint32_t c = code[SA[i]];
+        if (c == NONE) continue;
+        uint32_t* e = &x->ftab[2ull * c];
+        if (e[1] == 0) e[0] = (uint32_t)i;
+        e[1] = (uint32_t)i + 1;
+      }
+    }
+  }
+
+  }
+
+  if (keep) { x->text = std::move(T); x->sa = std::move(SA); }
+  return PSIGPU_OK;
+}
+
 uint64_t graph_fingerprint(const Graph& g)
 {
   // node count, total label length, edge count and the node ids: enough to tell that an index file
@@ -269,167 +435,41 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
   x->locus_step = step ? step : 1;
   x->graph_fp = graph_fingerprint(g);
 
-  // ---- text + segments -----------------------------------------------------------
-  std::vector<uint8_t> T;
-  uint64_t est = 1;
-  for (auto& P : paths) { for (uint32_t v : P) est += g.node_len(v); ++est; }
+  // ---- parts: the paths in order, a new part whenever the text would pass the row limit ------------
   // host SA-IS works on int32 indices; the device builder and the index layout on u32
-  const uint64_t max_text = opts.build_on_device ? 0xFFFFFF00ull : 0x7FFFFFF0ull;
-  if (est >= max_text) {
-    *status = PSIGPU_ERR_ARG;
-    *err = opts.build_on_device ? "indexed text too long for the 32-bit index layout"
-                                : "indexed text too long for the host suffix sorter (build on the device)";
-    delete x; return nullptr;
-  }
-  T.reserve(est);
-  auto& ss = x->seg_start; auto& sn = x->seg_node; auto& so = x->seg_noff;
-  bool first_path = true;
-  for (size_t pi = 0; pi < paths.size(); ++pi) {
-    const auto& P = paths[pi];
-    if (P.empty()) continue;
-    if (!first_path) T.push_back(SYM_SEP);
-    first_path = false;
-    bool in_gap = false;           // last emitted symbol was a separator for an N run
-    for (size_t si = 0; si < P.size(); ++si) {
-      const uint32_t v = P[si];
-      const char* lab = g.labels.data() + g.label_off[v];
-      // a patched path starts at its head offset and ends after its tail length
-      // (Path::left / right, path_base.hpp:113-114, :240-246)
-      const uint64_t o_begin = si == 0 ? x->path_head[pi] : 0;
-      const uint64_t len = (si + 1 == P.size() && x->path_tail[pi]) ? x->path_tail[pi] : g.node_len(v);
-      bool open = false;           // a segment of this node is open
-      for (uint64_t o = o_begin; o < len; ++o) {
-        int s = base_sym(lab[o]);
-        if (s < 0) {
-          if (!in_gap) { T.push_back(SYM_SEP); in_gap = true; }
-          open = false;
-          continue;
-        }
-        if (!open) {
-          ss.push_back((uint32_t)T.size()); sn.push_back(v); so.push_back((uint32_t)o);
-          open = true;
-        }
-        in_gap = false;
-        T.push_back((uint8_t)s);
-      }
-    }
-  }
-  T.push_back(SYM_END);
-  const uint64_t n = T.size();
-  x->n = n;
-  if (ss.empty() || ss[0] != 0) {          // position 0 must belong to a segment
-    ss.insert(ss.begin(), 0); sn.insert(sn.begin(), NO_NODE); so.insert(so.begin(), 0);
-  }
-  ss.push_back((uint32_t)n);
+  const uint64_t hard_max = opts.build_on_device ? 0xFFFFFF00ull : 0x7FFFFFF0ull;
+  const uint64_t max_text = opts.max_part_text ? std::min<uint64_t>(opts.max_part_text, hard_max) : hard_max;
+  std::vector<size_t> cuts{ 0 };
   {
-    uint64_t nd = (n >> DIR_SHIFT) + 1;
-    x->seg_dir.resize(nd);
-    uint64_t s = 0;
-    for (uint64_t i = 0; i < nd; ++i) {
-      uint64_t pos = i << DIR_SHIFT;
-      while (s + 1 < sn.size() && ss[s + 1] <= pos) ++s;
-      x->seg_dir[i] = (uint32_t)s;
+    uint64_t cur = 1;
+    for (size_t pi = 0; pi < paths.size(); ++pi) {
+      uint64_t len = 1;
+      for (uint32_t v : paths[pi]) len += g.node_len(v);
+      if (len + 1 >= hard_max) {
+        *status = PSIGPU_ERR_ARG;
+        *err = opts.build_on_device ? "one indexed path is too long for the 32-bit index layout"
+                                    : "indexed text too long for the host suffix sorter (build on the device)";
+        delete x; return nullptr;
+      }
+      if (cur + len >= max_text && cuts.back() != pi) { cuts.push_back(pi); cur = 1; }
+      cur += len;
     }
+    cuts.push_back(paths.size());
   }
-
-  // interval-table length
-  uint32_t q = opts.ftab_len;
-  if (q == 0) {                       // auto: ceil(log4 n); at most 13 (512 MiB) when built on the host,
-    q = 1;                            // 15 (8 GiB: whole-genome texts) when built on the device -- 16 can be asked for, but the
-                                      // 32-GiB table was measured slower at 2.95 G symbols (its own misses cost more than the rows it saves)
-    const uint32_t q_max = opts.build_on_device ? 15 : 13;
-    while (q < q_max && (1ull << (2 * q)) < n) ++q;
+  const size_t n_parts = cuts.size() - 1;
+  if (n_parts > 1 && (sa_rate != 1 || keep)) {
+    *status = PSIGPU_ERR_ARG; *err = "an index in several parts needs sa_rate 1 (and cannot keep its text)"; delete x; return nullptr;
   }
-  if (q == 0xFFFFFFFFu || paths.empty()) q = 0;
-  // (the host builder marks "no q-mer here" with a 32-bit all-ones code: 16-mers need the device builder)
-  if (q > 16 || (q == 16 && !opts.build_on_device)) {
-    *status = PSIGPU_ERR_ARG; *err = "ftab_len above 16 (15 for host builds)"; delete x; return nullptr;
-  }
-
-  std::vector<int32_t> SA;
-  if (opts.build_on_device) {
-    // suffix array, rank blocks, samples, exceptions, interval table, 4-bit text on the GPU
-    int st = gpu_build_fm(T, sa_rate, q, (int)opts.build_on_device - 1, x, keep ? &SA : nullptr, err);
+  if (n_parts > PSIGPU_MAX_PARTS) { *status = PSIGPU_ERR_ARG; *err = "indexed text too long (too many parts)"; delete x; return nullptr; }
+  {
+    // several parts are only ever read to tabulate their k-mers: no interval tables
+    int st = build_part(g, opts, sa_rate, keep, n_parts > 1, paths, x->path_head, x->path_tail, cuts[0], cuts[1], x, err);
     if (st != PSIGPU_OK) { *status = st; delete x; return nullptr; }
-  } else {
-  // ---- suffix array ----------------------------------------------------------------
-  SA.resize(n);
-  suffix_array(T.data(), SA.data(), (int32_t)n, 6);
-
-  // ---- BWT rank blocks, samples, exceptions -----------------------------------------
-  uint64_t nblk = n / BLOCK_SYMS + 1;
-  x->blocks.assign(nblk, RankBlock{ { 0, 0, 0 }, 0, { 0, 0, 0, 0, 0, 0 } });
-  x->samples.resize((n + sa_rate - 1) / sa_rate);
-  uint64_t cnt[4] = { 0, 0, 0, 0 }, nexc = 0, nsep = 0;
-  for (uint64_t i = 0; i < n; ++i) {
-    uint64_t b = i / BLOCK_SYMS, j = i % BLOCK_SYMS;
-    if (j == 0) {
-      RankBlock& B = x->blocks[b];
-      B.cnt[0] = (uint32_t)cnt[0]; B.cnt[1] = (uint32_t)cnt[1]; B.cnt[2] = (uint32_t)cnt[2];
-      B.exc = (uint32_t)(nexc << 8);
+    for (size_t pt = 1; pt < n_parts; ++pt) {
+      x->more.emplace_back();
+      st = build_part(g, opts, sa_rate, false, true, paths, x->path_head, x->path_tail, cuts[pt], cuts[pt + 1], &x->more.back(), err);
+      if (st != PSIGPU_OK) { *status = st; delete x; return nullptr; }
     }
-    uint8_t c = SA[i] ? T[SA[i] - 1] : T[n - 1];
-    uint64_t two;
-    if (c >= SYM_A) { two = c - SYM_A; ++cnt[two]; }
-    else {
-      two = 0;
-      x->exc_row.push_back((uint32_t)i);
-      x->exc_sa.push_back((uint32_t)SA[i]);
-      ++nexc;
-      RankBlock& B = x->blocks[b];
-      if ((B.exc & 0xFF) < 255) ++B.exc;
-      if (c == SYM_SEP) ++nsep;
-    }
-    // bit planes per group of 64 symbols: word 2g = low bits, word 2g+1 = high bits
-    x->blocks[b].sym[2 * (j >> 6)] |= (two & 1) << (j & 63);
-    x->blocks[b].sym[2 * (j >> 6) + 1] |= (two >> 1) << (j & 63);
-    if (i % sa_rate == 0) x->samples[i / sa_rate] = (uint32_t)SA[i];
-  }
-  if (n % BLOCK_SYMS == 0) {
-    RankBlock& B = x->blocks[nblk - 1];
-    B.cnt[0] = (uint32_t)cnt[0]; B.cnt[1] = (uint32_t)cnt[1]; B.cnt[2] = (uint32_t)cnt[2];
-    B.exc = (uint32_t)(nexc << 8);
-  }
-  if (nexc >= (1u << 24)) {
-    *status = PSIGPU_ERR_ARG; *err = "too many separators in the indexed text"; delete x; return nullptr;
-  }
-  x->C[0] = 1 + nsep;
-  x->C[1] = x->C[0] + cnt[0];
-  x->C[2] = x->C[1] + cnt[1];
-  x->C[3] = x->C[2] + cnt[2];
-
-  // ---- the text itself, 4 bits per symbol ---------------------------------------------------
-  x->text4.assign(n / 16 + 2, 0);
-  for (uint64_t i = 0; i < n; ++i) {
-    uint64_t nib = T[i] >= SYM_A ? (uint64_t)(T[i] - SYM_A) : 4ull;
-    x->text4[i >> 4] |= nib << (60 - 4 * (i & 15));
-  }
-
-  // ---- interval table for the last q bases of a seed -----------------------------------
-  {
-    x->ftab_len = q;
-    if (q) {
-      // code[p] = 2-bit code of T[p, p+q) (first base most significant) or NONE
-      const uint32_t NONE = 0xFFFFFFFFu;
-      std::vector<uint32_t> code(n, NONE);
-      uint32_t mask = (uint32_t)((1ull << (2 * q)) - 1), run = 0, good = 0;
-      for (uint64_t i = 0; i < n; ++i) {          // rolling over windows ending at i
-        uint8_t c = T[i];
-        if (c >= SYM_A) { run = ((run << 2) | (uint32_t)(c - SYM_A)) & mask; ++good; }
-        else { run = 0; good = 0; }
-        if (good >= q) code[i + 1 - q] = run;
-      }
-      x->ftab.assign(2ull << (2 * q), 0);
-      for (uint64_t i = 0; i < n; ++i) {
-        uint32_t c = code[SA[i]];
-        if (c == NONE) continue;
-        uint32_t* e = &x->ftab[2ull * c];
-        if (e[1] == 0) e[0] = (uint32_t)i;
-        e[1] = (uint32_t)i + 1;
-      }
-    }
-  }
-
   }
 
   // the device routine tracks coverage with one bit per path: full, simple (no node twice) paths, at most 64
@@ -448,7 +488,6 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
   } else {
     find_starting_loci(g, paths, x->path_head, x->path_tail, k, step, x->loci_node, x->loci_off);
   }
-  if (keep) { x->text = std::move(T); x->sa = std::move(SA); }
   *status = PSIGPU_OK;
   return x;
 }

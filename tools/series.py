@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""SURVEY §8(d) series beside the headline bench line, one JSON line each (profiles/r01_series.jsonl):
+"""SURVEY §8(d) series beside the headline bench line, one JSON line each (profiles/r02_series.jsonl):
 
   config 2 (chr22-like SNV graph, 1 M x 150 bp, k = 21):  P in {1, 8} x d in {21, 1} x error in {0, 1 %}
   config 5 (HLA-like bubble graph, k = 31, no path index: every locus goes through the traverser)
