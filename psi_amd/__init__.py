@@ -56,14 +56,15 @@ class IndexView(C.Structure):
                 ('ftab', C.c_void_p), ('text4', C.c_void_p), ('n_segs', C.c_uint64), ('seg_start', C.c_void_p),
                 ('seg_node', C.c_void_p), ('seg_noff', C.c_void_p), ('n_dir', C.c_uint64),
                 ('seg_dir', C.c_void_p), ('n_loci', C.c_uint64), ('loci_node', C.c_void_p),
-                ('loci_off', C.c_void_p)]
+                ('loci_off', C.c_void_p), ('n_more_parts', C.c_uint32), ('reserved2', C.c_uint32),
+                ('more_parts', C.c_void_p)]
 
 
 class IndexOpts(C.Structure):
     _fields_ = [('seed_len', C.c_uint32), ('n_per_region', C.c_uint32), ('locus_step', C.c_uint32),
                 ('sa_rate', C.c_uint32), ('ftab_len', C.c_uint32), ('keep_text_sa', C.c_uint32),
                 ('rng_seed', C.c_uint64), ('build_on_device', C.c_uint32), ('context', C.c_uint32),
-                ('patched', C.c_uint32), ('reserved1', C.c_uint32)]
+                ('patched', C.c_uint32), ('reserved1', C.c_uint32), ('max_part_text', C.c_uint64)]
 
 
 MODE_KMER_TABLE, MODE_TRAVERSE, MODE_LOCUS_TABLE = 0, 1, 2
@@ -311,12 +312,13 @@ class PathIndex:
     @classmethod
     def build(cls, g: Graph, k: int, n_paths: int, step: int = 1, sa_rate: int = 0,
               rng_seed: int = 0, ftab_len: int = 0, keep: bool = False, device: Optional[int] = None,
-              patched: bool = False, context: int = 0) -> 'PathIndex':
+              patched: bool = False, context: int = 0, max_part_text: int = 0) -> 'PathIndex':
         """`device`: GPU ordinal to build the suffix array / FM arrays on (None = host SA-IS);
-        `patched` / `context`: psikt's default indexing mode (no -P) and its -t."""
+        `patched` / `context`: psikt's default indexing mode (no -P) and its -t; `max_part_text`: text
+        symbols per index part (0 = the 32-bit row limit; tests set it small to get several parts)."""
         st = C.c_int(0)
         opts = IndexOpts(k, n_paths, step, sa_rate, ftab_len, int(keep), rng_seed,
-                         0 if device is None else device + 1, context, int(patched), 0)
+                         0 if device is None else device + 1, context, int(patched), 0, max_part_text)
         h = lib().psigpu_index_build(g.h, C.byref(opts), C.byref(st))
         if not h:
             raise PsiGpuError('index build failed (%d): %s' % (st.value, _host_err()))
@@ -326,7 +328,7 @@ class PathIndex:
     def build_paths(cls, g: Graph, k: int, paths: Sequence[Sequence[int]], step: int = 1,
                     sa_rate: int = 0, keep: bool = False, ftab_len: int = 0,
                     device: Optional[int] = None, head: Optional[Sequence[int]] = None,
-                    tail: Optional[Sequence[int]] = None, context: int = 0) -> 'PathIndex':
+                    tail: Optional[Sequence[int]] = None, context: int = 0, max_part_text: int = 0) -> 'PathIndex':
         """`head` / `tail`: per path, the offset of its first indexed base in its first node and the
         number of indexed bases of its last node (0 = all): a patch (Path::left / right)."""
         poff = np.zeros(len(paths) + 1, dtype=np.uint64)
@@ -336,7 +338,8 @@ class PathIndex:
         else:
             pnodes = np.zeros(0, np.uint32)
         st = C.c_int(0)
-        opts = IndexOpts(k, 0, step, sa_rate, ftab_len, int(keep), 0, 0 if device is None else device + 1, context, 0, 0)
+        opts = IndexOpts(k, 0, step, sa_rate, ftab_len, int(keep), 0, 0 if device is None else device + 1, context, 0, 0,
+                         max_part_text)
         hd = None if head is None else np.ascontiguousarray(head, dtype=np.uint32)
         tl = None if tail is None else np.ascontiguousarray(tail, dtype=np.uint32)
         h = lib().psigpu_index_build_patches(g.h, C.byref(opts), len(paths), _ptr(poff), _ptr(pnodes),
@@ -372,7 +375,14 @@ class PathIndex:
 
     @property
     def text_len(self) -> int:
-        return self.view.text_len
+        """Indexed symbols over all parts."""
+        return self.view.text_len + sum(v.text_len for v in self.more_parts())
+
+    def more_parts(self) -> List['IndexView']:
+        n = self.view.n_more_parts
+        if not n:
+            return []
+        return list((IndexView * n).from_address(self.view.more_parts))
 
     def text(self) -> np.ndarray:
         """Indexed text (needs keep=True): 0 sentinel, 1 separator, 2..5 = ACGT."""

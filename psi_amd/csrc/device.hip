@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -110,6 +111,7 @@ struct SeedOut {
 };
 constexpr uint32_t OFF_INLINE = 0x80000000u;
 constexpr uint32_t AUX_RESOLVED = 0x80000000u;
+constexpr uint32_t AUX_ONPOS = 0x40000000u;       // the occurrences are the run on_pos[lo, lo + con) (k-mer table)
 constexpr uint64_t LKT_INLINE = 1ull << 63;   // table slot: val = node rank, dup = offset of the k-mer's only locus     // SA interval of a seed, cnt == 0: no occurrence
 
 // Device-side counters, one per 128-byte line: atomics on different counters must not
@@ -783,6 +785,7 @@ struct MapView {
   uint32_t sarec_rem;
   const uint2* saloc;           // (node rank, offset) of SA[row] for every row, or nullptr
   const uint2* loci;            // starting loci (node rank, offset): what the tables' locus runs index
+  const uint2* on_pos;          // k-mer table: (node rank, offset) runs of the path k-mers with several occurrences
   const uint64_t* node_id;      // rank -> external id ...
   uint64_t id_base;             // ... or id = rank + id_base when the ids are consecutive
   bool id_affine;
@@ -1143,48 +1146,78 @@ __device__ __forceinline__ void kt_place(Slot16* __restrict__ ht, uint64_t n_slo
   }
 }
 
-// One thread per suffix-array row; the first row of every run of equal path k-mers makes the k-mer's slot,
-// with what the starting loci contribute to it (found by bisection in the sorted pairs).
-// FILL = false: only count the k-mers that need a 32-byte record (EXT).
+// The path k-mer streams of the index's parts (one part unless the text passes the 32-bit row limit).
+struct PkPart {
+  const uint64_t* pk; uint64_t n;                    // encoded k-mers along the part's suffix array
+  const uint32_t* sa; const SegRec* seg; const uint32_t* seg_rank; const uint32_t* seg_dir;
+};
+struct PkParts { PkPart p[PSIGPU_MAX_PARTS]; uint32_t n_parts; };
+
+// rows [first, first + count) of `key` in a part (count 0: not a k-mer of this part)
+__device__ __forceinline__ uint64_t pk_run(const PkPart& pt, uint64_t key, uint64_t* first)
+{
+  const uint64_t at = lower_bound_sh(pt.pk, 0, pt.n, key + 1, 1);
+  if (at >= pt.n || (pt.pk[at] >> 1) != key + 1) return 0;
+  const uint64_t r_end = lower_bound_sh(pt.pk, at + 1, pt.n, key + 2, 1);
+  uint64_t lo = at + 1, hi = r_end;                  // first row in (at, r_end) with the low bit clear (a carried value)
+  while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (pt.pk[mid] & 1ull) lo = mid + 1; else hi = mid; }
+  *first = at;
+  return lo - at;
+}
+
+__device__ __forceinline__ uint2 pk_position(const PkPart& pt, uint64_t row)
+{
+  const uint32_t p = pt.sa[row];
+  uint32_t d = pt.seg_dir[p >> DIR_SHIFT];
+  while (pt.seg[d + 1].start <= p) ++d;
+  return make_uint2(pt.seg_rank[d], pt.seg[d].noff + (p - pt.seg[d].start));
+}
+
+// One thread per suffix-array row of part `q`; the first row of every run of equal path k-mers makes the
+// k-mer's slot -- unless an earlier part holds the k-mer too (that part makes it) -- with the k-mer's
+// occurrences in the later parts and what the starting loci contribute to it (bisection in the sorted
+// pairs).  A k-mer with one occurrence keeps its position in the slot; the positions of the others go to
+// `on_pos` (a run per k-mer), so that a query needs nothing of the FM parts.
+// FILL = false: only count the k-mers that need a 32-byte record (EXT), the positions, the path k-mers.
 template <bool FILL>
-__global__ void k_kt_direct_on(const uint64_t* __restrict__ pk, uint64_t n, const uint32_t* __restrict__ sa,
-                               const SegRec* __restrict__ seg, const uint32_t* __restrict__ seg_rank,
-                               const uint32_t* __restrict__ seg_dir, const uint64_t* __restrict__ okeys,
+__global__ void k_kt_direct_on(PkParts parts, uint32_t q, const uint64_t* __restrict__ okeys,
                                const uint32_t* __restrict__ ovals, uint64_t n_off, const uint2* __restrict__ loci,
                                Slot16* __restrict__ ht, uint64_t n_slots, KmerSlot* __restrict__ ext,
-                               unsigned long long* __restrict__ n_ext, unsigned long long* __restrict__ n_heads)
+                               uint2* __restrict__ on_pos, unsigned long long* __restrict__ cnt /* [0] EXT records, [1] path k-mers, [2] positions */)
 {
+  const PkPart& me = parts.p[q];
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool head = false;
-  uint64_t v = 0;
-  if (i < n) { v = pk[i]; head = (v & 1ull) && (i == 0 || (pk[i - 1] >> 1) != (v >> 1)); }
-  if (!FILL) {
-    const uint64_t hm = __ballot(head);
-    if (hm && lane_id() == 0) atomicAdd(n_heads, (unsigned long long)__popcll(hm));
-  }
-  if (!head) return;
+  if (i >= me.n) return;
+  const uint64_t v = me.pk[i];
+  if (!(v & 1ull) || (i != 0 && (me.pk[i - 1] >> 1) == (v >> 1))) return;       // not the first row of a k-mer
   const uint64_t key = (v >> 1) - 1;
-  // rows of this k-mer: the rows carrying its value, minus the carried (low bit clear) ones at their end
-  const uint64_t r_end = lower_bound_sh(pk, i + 1, n, (v >> 1) + 1, 1);
-  uint64_t lo = i + 1, hi = r_end;                       // first row in (i, r_end) with the low bit clear
-  while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (pk[mid] & 1ull) lo = mid + 1; else hi = mid; }
-  const uint64_t on_cnt = lo - i;
+  uint64_t first[PSIGPU_MAX_PARTS], count[PSIGPU_MAX_PARTS], on_cnt = 0;
+  for (uint32_t r = 0; r < q; ++r)
+    if (pk_run(parts.p[r], key, &first[r])) return;                              // an earlier part owns this k-mer
+  for (uint32_t r = q; r < parts.n_parts; ++r) { count[r] = pk_run(parts.p[r], key, &first[r]); on_cnt += count[r]; }
+  if (!FILL) atomicAdd(&cnt[1], 1ull);
   const uint64_t j = lower_bound_sh(okeys, 0, n_off, key, 0);
   uint64_t off_cnt = 0;
   if (j < n_off && okeys[j] == key) off_cnt = lower_bound_sh(okeys, j + 1, n_off, key + 1, 0) - j;
   KmerSlot r;
   r.key = key; r.on_a = r.on_b = r.off_a = r.off_b = 0;
   if (on_cnt == 1) {
-    const uint32_t p = sa[i];
-    uint32_t d = seg_dir[p >> DIR_SHIFT];
-    while (seg[d + 1].start <= p) ++d;
-    r.on_a = seg_rank[d]; r.on_b = seg[d].noff + (p - seg[d].start); r.on_cnt = 1u | KT_INLINE;
-  } else { r.on_a = (uint32_t)i; r.on_cnt = (uint32_t)min(on_cnt, (uint64_t)0x7FFFFFFFu); }
+    const uint2 at = pk_position(me, i);
+    r.on_a = at.x; r.on_b = at.y; r.on_cnt = 1u | KT_INLINE;
+  } else {
+    const unsigned long long base = atomicAdd(&cnt[2], (unsigned long long)on_cnt);
+    if (FILL) {
+      uint64_t w = base;
+      for (uint32_t pr = q; pr < parts.n_parts; ++pr)
+        for (uint64_t t = 0; t < count[pr]; ++t) on_pos[w++] = pk_position(parts.p[pr], first[pr] + t);
+    }
+    r.on_a = (uint32_t)base; r.on_cnt = (uint32_t)min(on_cnt, (uint64_t)0x3FFFFFFFu);
+  }
   if (off_cnt == 1) { const uint2 lc = loci[ovals[j]]; r.off_a = lc.x; r.off_b = lc.y; r.off_cnt = 1u | KT_INLINE; }
   else { r.off_a = (uint32_t)j; r.off_cnt = (uint32_t)off_cnt; }
   const uint64_t type = slot16_type(r);
   if (type == K16_EXT) {
-    const unsigned long long e = atomicAdd(n_ext, 1ull);
+    const unsigned long long e = atomicAdd(&cnt[0], 1ull);
     if (FILL) { ext[e] = r; kt_place(ht, n_slots, key, type, (uint32_t)e, 0); }
   } else if (FILL) kt_place(ht, n_slots, key, type, r.on_a, r.on_b);
 }
@@ -1193,21 +1226,23 @@ __global__ void k_kt_direct_on(const uint64_t* __restrict__ pk, uint64_t n, cons
 // makes the slot (the others were made by k_kt_direct_on).
 template <bool FILL>
 __global__ void k_kt_direct_off(const uint64_t* __restrict__ okeys, const uint32_t* __restrict__ ovals, uint64_t n_off,
-                                const uint2* __restrict__ loci, const uint64_t* __restrict__ pk, uint64_t n,
+                                const uint2* __restrict__ loci, PkParts parts,
                                 Slot16* __restrict__ ht, uint64_t n_slots, KmerSlot* __restrict__ ext,
-                                unsigned long long* __restrict__ n_ext)
+                                unsigned long long* __restrict__ cnt)
 {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_off) return;
   const uint64_t key = okeys[j];
   if (j && okeys[j - 1] == key) return;
-  const uint64_t at = lower_bound_sh(pk, 0, n, key + 1, 1);
-  if (at < n && (pk[at] >> 1) == key + 1) return;        // a path k-mer: its slot holds the loci too
+  for (uint32_t r = 0; r < parts.n_parts; ++r) {
+    uint64_t f;
+    if (pk_run(parts.p[r], key, &f)) return;             // a path k-mer: its slot holds the loci too
+  }
   const uint64_t off_cnt = lower_bound_sh(okeys, j + 1, n_off, key + 1, 0) - j;
   if (off_cnt == 1) {
     if (FILL) { const uint2 lc = loci[ovals[j]]; kt_place(ht, n_slots, key, K16_OFF1, lc.x, lc.y); }
   } else {
-    const unsigned long long e = atomicAdd(n_ext, 1ull);
+    const unsigned long long e = atomicAdd(&cnt[0], 1ull);
     if (FILL) {
       KmerSlot r;
       r.key = key; r.on_a = r.on_b = 0; r.on_cnt = 0; r.off_a = (uint32_t)j; r.off_b = 0; r.off_cnt = (uint32_t)off_cnt;
@@ -1561,6 +1596,10 @@ __device__ __forceinline__ void resolve_hit(const MapView& mv, const LocusEnt* _
     if ((sh.aux & AUX_RESOLVED) && occ == 0) {
       nid = mv.id_affine ? mv.id_base + sh.on_node : mv.node_id[sh.on_node];
       noff = sh.on_noff;
+    } else if (sh.aux & AUX_ONPOS) {
+      const uint2 at = mv.on_pos[sh.lo + occ];
+      nid = mv.id_affine ? mv.id_base + at.x : mv.node_id[at.x];
+      noff = at.y;
     } else if (mv.sarec != nullptr && rem == mv.sarec_rem) {
       // verified by K1 against this row's record: it names the seed's first base
       uint2 at = *reinterpret_cast<const uint2*>(&mv.sarec[row]);
@@ -1753,7 +1792,7 @@ k_kmer_emit(MapView mv, const uint4* __restrict__ seed_res, const KmerSlot* __re
           const uint4 e0 = e[0], e1 = e[1];               // key, on_a, on_b | off_a, off_b, on_cnt, off_cnt
           if (sh.con) {
             if (e1.z & KT_INLINE) { sh.on_node = e0.z; sh.on_noff = e0.w; sh.aux = AUX_RESOLVED; }
-            else sh.lo = e0.z;
+            else { sh.lo = e0.z; sh.aux = AUX_ONPOS; }
           }
           if (coff) { sh.ofirst = e1.x; sh.onoff = e1.y; sh.ocnt = (e1.w & KT_INLINE) ? (1u | OFF_INLINE) : coff; }
         }
@@ -2240,7 +2279,14 @@ struct psigpu_ctx {
   uint32_t query_mode = PSIGPU_MODE_KMER_TABLE, walk_cap = 0;
   bool lkt_ready = false, lkt_failed = false;
   bool kt_ready = false;           // the table also holds the path k-mers (KmerSlot), K1 is one probe
-  DevBuf kt_ht, kt_ext, seg_rank;
+  DevBuf kt_ht, kt_ext, kt_onpos, seg_rank;
+  // further parts of an index whose text passes the 32-bit row limit: only what tabulating their k-mers
+  // needs (suffix array, text, segment table)
+  struct FmPart {
+    DevBuf samples, text4, seg, seg_dir, seg_rank;
+    uint64_t text_len = 0, n_segs = 0;
+  };
+  std::vector<std::unique_ptr<FmPart>> more;
   uint64_t kt_ht_size = 0, kt_n_path_kmers = 0, kt_n_ext = 0;
   uint32_t lkt_k = 0;
   DevBuf lkt_ht, lkt_ent, lkt_res;
@@ -2381,6 +2427,8 @@ void psigpu_destroy(psigpu_ctx* ctx)
                     &ctx->w_iv_tiles_off, &ctx->w_defer, &ctx->sarec, &ctx->saloc, &ctx->kt_ht, &ctx->kt_ext, &ctx->seg_rank, &ctx->w_seedres };
   for (auto* b : all) b->release();
   ctx->ids_sorted.release(); ctx->w_sorted[0].release(); ctx->w_sorted[1].release(); ctx->w_count.release();
+  ctx->kt_onpos.release();
+  for (auto& m : ctx->more) { m->samples.release(); m->text4.release(); m->seg.release(); m->seg_dir.release(); m->seg_rank.release(); }
   ctx->w_hits_alt.release();
   for (auto& sl : ctx->slot) {
     sl.bases.release(); sl.off.release();
@@ -2412,6 +2460,7 @@ int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr)
 static void lkt_release(psigpu_ctx* ctx)
 {
   ctx->lkt_ht.release(); ctx->lkt_ent.release(); ctx->lkt_res.release(); ctx->kt_ht.release(); ctx->kt_ext.release();
+  ctx->kt_onpos.release();
   ctx->lkt_ready = false; ctx->lkt_failed = false; ctx->kt_ready = false;
   ctx->kt_ht_size = ctx->kt_n_path_kmers = 0;
   ctx->lkt_ht_size = ctx->lkt_n_ent = ctx->lkt_n_res = ctx->lkt_n_walks = 0;
@@ -2559,6 +2608,24 @@ int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
 
 static int build_row_records(psigpu_ctx* ctx, uint32_t k);
 
+// segment table of one part: (text start, node offset, external node id) per segment + a sentinel record at
+// text_len, the directory, and the node rank of every segment
+static int upload_segments(psigpu_ctx* ctx, const psigpu_index_view* x, const std::vector<uint64_t>& ids, DevBuf& seg,
+                           DevBuf& seg_dir, DevBuf& seg_rank)
+{
+  std::vector<SegRec> segs(x->n_segs + 1);
+  for (uint64_t i = 0; i < x->n_segs; ++i) {
+    uint32_t v = x->seg_node[i];
+    if (v != NO_NODE && v >= ctx->n_nodes) { ctx->err = "index does not belong to this graph"; return PSIGPU_ERR_ARG; }
+    segs[i] = SegRec{ x->seg_start[i], x->seg_noff[i], v == NO_NODE ? 0 : ids[v] };
+  }
+  segs[x->n_segs] = SegRec{ x->seg_start[x->n_segs], 0, 0 };
+  int st;
+  if ((st = upload(ctx, seg, segs.data(), segs.size(), 1))) return st;
+  if ((st = upload(ctx, seg_dir, x->seg_dir, x->n_dir, 1))) return st;
+  return upload(ctx, seg_rank, x->seg_node, x->n_segs, 1);
+}
+
 int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
 {
   if (!ctx || !x) return PSIGPU_ERR_ARG;
@@ -2598,28 +2665,33 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
     ctx->ftab_len = x->ftab_len;
   }
   if ((st = upload(ctx, ctx->exc_sa, x->exc_sa, x->n_exc, 1))) return st;
-  {
-    // (text start, node offset, external node id) per segment + a sentinel record at text_len
-    if (!ctx->have_graph) { ctx->err = "load the graph before the index"; return PSIGPU_ERR_STATE; }
-    std::vector<uint64_t> ids(ctx->n_nodes);
-    if (ctx->n_nodes)
-      HIPCHK(ctx, hipMemcpy(ids.data(), ctx->node_id.p, ctx->n_nodes * 8, hipMemcpyDeviceToHost));
-    std::vector<SegRec> segs(x->n_segs + 1);
-    for (uint64_t i = 0; i < x->n_segs; ++i) {
-      uint32_t v = x->seg_node[i];
-      if (v != NO_NODE && v >= ctx->n_nodes) { ctx->err = "index does not belong to this graph"; return PSIGPU_ERR_ARG; }
-      segs[i] = SegRec{ x->seg_start[i], x->seg_noff[i], v == NO_NODE ? 0 : ids[v] };
+  std::vector<uint64_t> ids(ctx->n_nodes);
+  if (ctx->n_nodes) HIPCHK(ctx, hipMemcpy(ids.data(), ctx->node_id.p, ctx->n_nodes * 8, hipMemcpyDeviceToHost));
+  if ((st = upload_segments(ctx, x, ids, ctx->seg, ctx->seg_dir, ctx->seg_rank))) return st;
+  // further parts (an index whose text passes the 32-bit row limit): suffix array, text, segments
+  ctx->more.clear();
+  if (x->n_more_parts > PSIGPU_MAX_PARTS - 1 || (x->n_more_parts && !x->more_parts)) { ctx->err = "too many index parts"; return PSIGPU_ERR_ARG; }
+  for (uint32_t pi = 0; pi < x->n_more_parts; ++pi) {
+    const psigpu_index_view* m = &x->more_parts[pi];
+    if (x->sa_rate != 1 || m->sa_rate != 1 || !m->text4 || !x->text4 || m->text_len == 0 || m->text_len >= 0xFFFFFFF0ull ||
+        m->n_samples != m->text_len || m->n_dir != (m->text_len >> DIR_SHIFT) + 1 || !m->sa_samples || !m->seg_start || !m->seg_dir) {
+      ctx->err = "inconsistent index part (parts need the whole suffix array and the text)";
+      return PSIGPU_ERR_ARG;
     }
-    segs[x->n_segs] = SegRec{ x->seg_start[x->n_segs], 0, 0 };
-    if ((st = upload(ctx, ctx->seg, segs.data(), segs.size(), 1))) return st;
+    for (uint64_t i = 0; i < m->n_dir; ++i)
+      if (m->seg_dir[i] >= m->n_segs + (m->n_segs == 0)) { ctx->err = "inconsistent index part"; return PSIGPU_ERR_ARG; }
+    ctx->more.emplace_back(new psigpu_ctx::FmPart);
+    psigpu_ctx::FmPart& fp = *ctx->more.back();
+    fp.text_len = m->text_len; fp.n_segs = m->n_segs;
+    if ((st = upload(ctx, fp.samples, m->sa_samples, m->n_samples, 1))) return st;
+    if ((st = upload(ctx, fp.text4, m->text4, m->text_len / 16 + 2))) return st;
+    if ((st = upload_segments(ctx, m, ids, fp.seg, fp.seg_dir, fp.seg_rank))) return st;
   }
-  if ((st = upload(ctx, ctx->seg_dir, x->seg_dir, x->n_dir, 1))) return st;
   {
     std::vector<uint2> lc(x->n_loci);
     for (uint64_t i = 0; i < x->n_loci; ++i) lc[i] = make_uint2(x->loci_node[i], x->loci_off[i]);
     if ((st = upload(ctx, ctx->loci, lc.data(), x->n_loci, 1))) return st;
   }
-  if ((st = upload(ctx, ctx->seg_rank, x->seg_node, x->n_segs, 1))) return st;
   ctx->index_k = x->seed_len; ctx->sa_rate = x->sa_rate; ctx->context = x->context;
   ctx->n_paths = x->n_paths; ctx->text_len = x->text_len; ctx->n_exc = x->n_exc; ctx->n_segs = x->n_segs;
   if ((st = build_row_records(ctx, x->seed_len))) return st;
@@ -2675,34 +2747,49 @@ static int build_row_records(psigpu_ctx* ctx, uint32_t k)
   return PSIGPU_OK;
 }
 
-// The k-mer table built straight into its 16-byte slots (see k_pk_encode).  `okeys` / `ovals`: the sorted
-// (k-mer, locus) pairs.  Returns PSIGPU_ERR_NOMEM when it does not fit either (kt_ready stays false).
+// The k-mer table built straight into its 16-byte slots (see k_pk_encode), over all parts of the index.
+// `okeys` / `ovals`: the sorted (k-mer, locus) pairs.  Returns PSIGPU_ERR_NOMEM when it does not fit
+// (kt_ready stays false).
 static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, const uint32_t* ovals, uint64_t n_off,
-                           unsigned long long* d_cnt /* two counters */)
+                           unsigned long long* d_cnt /* room for four counters */)
 {
-  const uint64_t n_rows = ctx->text_len;
-  TmpBuf pk;
-  if (pk.alloc((n_rows + 1) * 8) != hipSuccess) { (void)hipGetLastError(); return PSIGPU_ERR_NOMEM; }
-  const unsigned grid_rows = (unsigned)((n_rows + 255) / 256), grid_off = (unsigned)((n_off + 255) / 256);
-  k_pk_encode<<<grid_rows, 256>>>(ctx->samples.as<uint32_t>(), n_rows, k, ctx->text4.as<uint64_t>(), pk.as<uint64_t>());
-  {
+  const uint32_t n_parts = 1 + (uint32_t)ctx->more.size();
+  TmpBuf pk[PSIGPU_MAX_PARTS];
+  PkParts parts{};
+  parts.n_parts = n_parts;
+  uint64_t rows_all = 0;
+  for (uint32_t q = 0; q < n_parts; ++q) {
+    PkPart& pt = parts.p[q];
+    const uint64_t* text4;
+    if (q == 0) {
+      pt.n = ctx->text_len; pt.sa = ctx->samples.as<uint32_t>(); pt.seg = ctx->seg.as<SegRec>();
+      pt.seg_rank = ctx->seg_rank.as<uint32_t>(); pt.seg_dir = ctx->seg_dir.as<uint32_t>(); text4 = ctx->text4.as<uint64_t>();
+    } else {
+      const psigpu_ctx::FmPart& fp = *ctx->more[q - 1];
+      pt.n = fp.text_len; pt.sa = fp.samples.as<uint32_t>(); pt.seg = fp.seg.as<SegRec>();
+      pt.seg_rank = fp.seg_rank.as<uint32_t>(); pt.seg_dir = fp.seg_dir.as<uint32_t>(); text4 = fp.text4.as<uint64_t>();
+    }
+    rows_all += pt.n;
+    if (pk[q].alloc((pt.n + 1) * 8) != hipSuccess) { (void)hipGetLastError(); return PSIGPU_ERR_NOMEM; }
+    pt.pk = pk[q].as<uint64_t>();
+    const unsigned grid = (unsigned)((pt.n + 255) / 256);
+    k_pk_encode<<<grid, 256>>>(pt.sa, pt.n, k, text4, pk[q].as<uint64_t>());
     std::string serr;
-    int st = psigpu::gpu_running_max_u64(pk.as<uint64_t>(), n_rows, &serr);
-    if (st != PSIGPU_OK) { (void)hipGetLastError(); return PSIGPU_ERR_NOMEM; }
+    if (psigpu::gpu_running_max_u64(pk[q].as<uint64_t>(), pt.n, &serr) != PSIGPU_OK) { (void)hipGetLastError(); return PSIGPU_ERR_NOMEM; }
+    k_pk_fix<<<grid, 256>>>(pt.sa, pt.n, k, text4, pk[q].as<uint64_t>());
   }
-  k_pk_fix<<<grid_rows, 256>>>(ctx->samples.as<uint32_t>(), n_rows, k, ctx->text4.as<uint64_t>(), pk.as<uint64_t>());
-  // pass 1: how many k-mers need a 32-byte record, how many path k-mers there are
-  HIPCHK(ctx, hipMemset(d_cnt, 0, 16));
-  k_kt_direct_on<false><<<grid_rows, 256>>>(pk.as<uint64_t>(), n_rows, ctx->samples.as<uint32_t>(), ctx->seg.as<SegRec>(),
-                                            ctx->seg_rank.as<uint32_t>(), ctx->seg_dir.as<uint32_t>(), okeys, ovals, n_off,
-                                            ctx->loci.as<uint2>(), nullptr, 0, nullptr, d_cnt, d_cnt + 1);
-  if (n_off)
-    k_kt_direct_off<false><<<grid_off, 256>>>(okeys, ovals, n_off, ctx->loci.as<uint2>(), pk.as<uint64_t>(), n_rows, nullptr, 0,
-                                              nullptr, d_cnt);
-  unsigned long long h[2] = { 0, 0 };
-  HIPCHK(ctx, hipMemcpy(h, d_cnt, 16, hipMemcpyDeviceToHost));
-  const uint64_t n_ext = h[0], n_on = h[1];
-  if (n_ext >= 0xFFFFFFF0ull) return PSIGPU_ERR_NOMEM;
+  const unsigned grid_off = (unsigned)((n_off + 255) / 256);
+  // pass 1: how many k-mers need a 32-byte record, how many path k-mers there are, how many positions of
+  // k-mers with several occurrences
+  HIPCHK(ctx, hipMemset(d_cnt, 0, 32));
+  for (uint32_t q = 0; q < n_parts; ++q)
+    k_kt_direct_on<false><<<(unsigned)((parts.p[q].n + 255) / 256), 256>>>(parts, q, okeys, ovals, n_off, ctx->loci.as<uint2>(), nullptr, 0,
+                                                                          nullptr, nullptr, d_cnt);
+  if (n_off) k_kt_direct_off<false><<<grid_off, 256>>>(okeys, ovals, n_off, ctx->loci.as<uint2>(), parts, nullptr, 0, nullptr, d_cnt);
+  unsigned long long h[3] = { 0, 0, 0 };
+  HIPCHK(ctx, hipMemcpy(h, d_cnt, 24, hipMemcpyDeviceToHost));
+  const uint64_t n_ext = h[0], n_on = h[1], n_pos = h[2];
+  if (n_ext >= 0xFFFFFFF0ull || n_pos >= 0xFFFFFFF0ull) return PSIGPU_ERR_NOMEM;
   // slots: load 0.5 when there is room, down to 0.75 when there is not
   uint64_t slots = 0;
   hipError_t e = hipErrorOutOfMemory;
@@ -2710,23 +2797,25 @@ static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, c
     slots = std::max<uint64_t>(1024, (n_on + n_off) * pct / 100);      // (an upper bound on the distinct k-mers)
     e = ctx->kt_ht.ensure(slots * sizeof(Slot16));
     if (e == hipSuccess) e = ctx->kt_ext.ensure((n_ext + 1) * sizeof(KmerSlot));
+    if (e == hipSuccess) e = ctx->kt_onpos.ensure((n_pos + 1) * sizeof(uint2));
     if (e == hipSuccess) break;
     (void)hipGetLastError();
-    ctx->kt_ht.release(); ctx->kt_ext.release();
+    ctx->kt_ht.release(); ctx->kt_ext.release(); ctx->kt_onpos.release();
   }
   if (e != hipSuccess) return PSIGPU_ERR_NOMEM;
   HIPCHK(ctx, hipMemset(ctx->kt_ht.p, 0xFF, slots * sizeof(Slot16)));
-  HIPCHK(ctx, hipMemset(d_cnt, 0, 16));
-  k_kt_direct_on<true><<<grid_rows, 256>>>(pk.as<uint64_t>(), n_rows, ctx->samples.as<uint32_t>(), ctx->seg.as<SegRec>(),
-                                           ctx->seg_rank.as<uint32_t>(), ctx->seg_dir.as<uint32_t>(), okeys, ovals, n_off,
-                                           ctx->loci.as<uint2>(), ctx->kt_ht.as<Slot16>(), slots, ctx->kt_ext.as<KmerSlot>(),
-                                           d_cnt, d_cnt + 1);
+  HIPCHK(ctx, hipMemset(d_cnt, 0, 32));
+  for (uint32_t q = 0; q < n_parts; ++q)
+    k_kt_direct_on<true><<<(unsigned)((parts.p[q].n + 255) / 256), 256>>>(parts, q, okeys, ovals, n_off, ctx->loci.as<uint2>(),
+                                                                         ctx->kt_ht.as<Slot16>(), slots, ctx->kt_ext.as<KmerSlot>(),
+                                                                         ctx->kt_onpos.as<uint2>(), d_cnt);
   if (n_off)
-    k_kt_direct_off<true><<<grid_off, 256>>>(okeys, ovals, n_off, ctx->loci.as<uint2>(), pk.as<uint64_t>(), n_rows,
-                                             ctx->kt_ht.as<Slot16>(), slots, ctx->kt_ext.as<KmerSlot>(), d_cnt);
+    k_kt_direct_off<true><<<grid_off, 256>>>(okeys, ovals, n_off, ctx->loci.as<uint2>(), parts, ctx->kt_ht.as<Slot16>(), slots,
+                                             ctx->kt_ext.as<KmerSlot>(), d_cnt);
   HIPCHK(ctx, hipDeviceSynchronize());
   ctx->kt_ht_size = slots; ctx->kt_n_path_kmers = n_on; ctx->kt_n_ext = n_ext;
   ctx->kt_ready = true;
+  (void)rows_all;
   return PSIGPU_OK;
 }
 
@@ -3061,6 +3150,12 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     use_kt = ctx->lkt_ready && ctx->kt_ready;
     if (!had) EVREC(0, stream);      // a table build just ended: do not time it
   }
+  if (!ctx->more.empty() && n_reads && (flags & PSIGPU_ON_PATHS) && !use_kt) {
+    ctx->err = ctx->query_mode != PSIGPU_MODE_KMER_TABLE || ctx->index_k != k
+                   ? "an index in several parts is answered from the k-mer table only (PSIGPU_MODE_KMER_TABLE, the index's seed length)"
+                   : "the k-mer table of this index (several parts) does not fit the device";
+    return PSIGPU_ERR_STATE;
+  }
   const uint2* trav_loci = use_lkt ? ctx->lkt_res.as<uint2>() : ctx->loci.as<uint2>();
   const uint64_t n_trav_loci = use_lkt ? ctx->lkt_n_res : ctx->n_loci;
   pc.n_loci_traversed = (flags & PSIGPU_OFF_PATHS) ? n_trav_loci : 0;
@@ -3135,6 +3230,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   mv.sarec = fm.sarec; mv.sarec_rem = k - ctx->ftab_len;
   mv.node_id = ctx->node_id.as<uint64_t>(); mv.id_base = ctx->id_base; mv.id_affine = ctx->id_affine;
   mv.loci = ctx->loci.as<uint2>();
+  mv.on_pos = ctx->kt_onpos.as<uint2>();
   mv.saloc = ctx->have_saloc ? ctx->saloc.as<uint2>() : nullptr;
   TableView tb;
   tb.ht = ctx->w_ht.as<TableSlot>();
@@ -3469,6 +3565,7 @@ int psigpu_find_mems(psigpu_ctx* ctx, const char* bases, const uint64_t* read_of
     ctx->err = "MEM mode needs the whole suffix array and the text on the device (sa_rate 1)";
     return PSIGPU_ERR_STATE;
   }
+  if (!ctx->more.empty()) { ctx->err = "MEM mode is not available on an index in several parts"; return PSIGPU_ERR_STATE; }
   const uint64_t n_bases = read_off[n_reads];
   for (uint64_t r = 0; r < n_reads; ++r)
     if (read_off[r + 1] - read_off[r] >= 0xFFFFFFF0ull) { ctx->err = "read too long"; return PSIGPU_ERR_ARG; }

@@ -496,7 +496,7 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
 // Serialisation: one little-endian container `<prefix>.psigpu`.
 // ------------------------------------------------------------------------------------
 namespace {
-const char MAGIC[8] = { 'P', 'S', 'I', 'G', 'P', 'U', '0', '5' };
+const char MAGIC[8] = { 'P', 'S', 'I', 'G', 'P', 'U', '0', '6' };
 
 template <typename T> bool wr(FILE* f, const std::vector<T>& v)
 {
@@ -529,8 +529,31 @@ int save_index(const Index& x, const std::string& prefix)
   ok = ok && wr(f, x.blocks) && wr(f, x.samples) && wr(f, x.exc_row) && wr(f, x.exc_sa) &&
        wr(f, x.seg_start) && wr(f, x.seg_node) && wr(f, x.seg_noff) && wr(f, x.seg_dir) &&
        wr(f, x.loci_node) && wr(f, x.loci_off) && wr(f, x.ftab) && wr(f, x.text4);
+  // further parts: text length, C, interval-table length, then the part's arrays
+  uint64_t n_more = x.more.size();
+  ok = ok && fwrite(&n_more, 8, 1, f) == 1;
+  for (const Index& m : x.more) {
+    uint64_t ph[6] = { m.n, m.C[0], m.C[1], m.C[2], m.C[3], m.ftab_len };
+    ok = ok && fwrite(ph, 8, 6, f) == 6 && wr(f, m.blocks) && wr(f, m.samples) && wr(f, m.exc_row) && wr(f, m.exc_sa) &&
+         wr(f, m.seg_start) && wr(f, m.seg_node) && wr(f, m.seg_noff) && wr(f, m.seg_dir) && wr(f, m.ftab) && wr(f, m.text4);
+  }
   ok = (fclose(f) == 0) && ok;
   return ok ? PSIGPU_OK : PSIGPU_ERR_IO;
+}
+
+// every array length of a part follows from its text length
+static bool part_consistent(const Index& x, uint32_t sa_rate)
+{
+  const uint64_t n = x.n;
+  bool ok = n >= 1 && n < 0xFFFFFFF0ull && x.blocks.size() == n / BLOCK_SYMS + 1 &&
+            x.samples.size() == (n + sa_rate - 1) / sa_rate && x.exc_row.size() == x.exc_sa.size() &&
+            x.seg_start.size() == x.seg_node.size() + 1 && x.seg_noff.size() == x.seg_node.size() &&
+            x.seg_dir.size() == (n >> DIR_SHIFT) + 1 && x.ftab_len <= 16 &&
+            (x.ftab.empty() ? x.ftab_len == 0 : x.ftab.size() == (2ull << (2 * x.ftab_len))) &&
+            (x.text4.empty() || x.text4.size() == n / 16 + 2);
+  for (uint32_t d : x.seg_dir) ok = ok && d < x.seg_node.size();
+  for (size_t i = 0; ok && i + 1 < x.seg_start.size(); ++i) ok = x.seg_start[i] <= x.seg_start[i + 1];
+  return ok && (x.seg_start.empty() || x.seg_start.back() == n);
 }
 
 Index* load_index(const std::string& prefix, int* status)
@@ -554,22 +577,27 @@ Index* load_index(const std::string& prefix, int* status)
     ok = ok && rd(f, x->blocks) && rd(f, x->samples) && rd(f, x->exc_row) && rd(f, x->exc_sa) &&
          rd(f, x->seg_start) && rd(f, x->seg_node) && rd(f, x->seg_noff) && rd(f, x->seg_dir) &&
          rd(f, x->loci_node) && rd(f, x->loci_off) && rd(f, x->ftab) && rd(f, x->text4);
+    uint64_t n_more = 0;
+    ok = ok && fread(&n_more, 8, 1, f) == 1 && n_more < PSIGPU_MAX_PARTS;
+    for (uint64_t i = 0; ok && i < n_more; ++i) {
+      x->more.emplace_back();
+      Index& m = x->more.back();
+      uint64_t ph[6];
+      ok = fread(ph, 8, 6, f) == 6;
+      if (!ok) break;
+      m.n = ph[0]; m.sa_rate = x->sa_rate; m.ftab_len = (uint32_t)ph[5];
+      for (int c = 0; c < 4; ++c) m.C[c] = ph[1 + c];
+      ok = rd(f, m.blocks) && rd(f, m.samples) && rd(f, m.exc_row) && rd(f, m.exc_sa) && rd(f, m.seg_start) &&
+           rd(f, m.seg_node) && rd(f, m.seg_noff) && rd(f, m.seg_dir) && rd(f, m.ftab) && rd(f, m.text4);
+    }
   }
   fclose(f);
   // a corrupt or truncated file must not reach the device: every array length follows from the header
   if (ok) {
-    const uint64_t n = x->n;
-    ok = x->k >= 1 && x->k <= PSIGPU_MAX_SEED_LEN && x->sa_rate && !(x->sa_rate & (x->sa_rate - 1)) && n >= 1 &&
-         n < 0xFFFFFFF0ull && x->blocks.size() == n / BLOCK_SYMS + 1 && x->samples.size() == (n + x->sa_rate - 1) / x->sa_rate &&
-         x->exc_row.size() == x->exc_sa.size() && x->seg_start.size() == x->seg_node.size() + 1 &&
-         x->seg_noff.size() == x->seg_node.size() && x->seg_dir.size() == (n >> DIR_SHIFT) + 1 &&
-         x->loci_node.size() == x->loci_off.size() && x->ftab_len <= 16 &&
-         (x->ftab.empty() ? x->ftab_len == 0 : x->ftab.size() == (2ull << (2 * x->ftab_len))) &&
-         (x->text4.empty() || x->text4.size() == n / 16 + 2) && x->path_head.size() == x->paths.size() &&
-         x->path_tail.size() == x->paths.size();
-    for (uint32_t d : x->seg_dir) ok = ok && d < x->seg_node.size();
-    for (size_t i = 0; ok && i + 1 < x->seg_start.size(); ++i) ok = x->seg_start[i] <= x->seg_start[i + 1];
-    ok = ok && (x->seg_start.empty() || x->seg_start.back() == n);
+    ok = x->k >= 1 && x->k <= PSIGPU_MAX_SEED_LEN && x->sa_rate && !(x->sa_rate & (x->sa_rate - 1)) &&
+         part_consistent(*x, x->sa_rate) && x->loci_node.size() == x->loci_off.size() &&
+         x->path_head.size() == x->paths.size() && x->path_tail.size() == x->paths.size();
+    for (const Index& m : x->more) ok = ok && x->sa_rate == 1 && part_consistent(m, 1);
   }
   if (!ok) { delete x; *status = PSIGPU_ERR_FORMAT; return nullptr; }
   *status = PSIGPU_OK;

@@ -852,3 +852,68 @@ def test_find_mems_vs_brute(name, minlen, npaths, patched, gocc, max_mem):
     assert len(want) > 10
     assert _eq(got, want)
     f.close()
+
+
+# ---------------------------------------------------------------------------------------
+# an index in several parts (texts beyond the 32-bit row limit; forced here with a small part size)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('fname', ['hits_x_reads_n1000l100e0i0_k21_d1.npz', 'hits_m_sim104_k12_d12.npz',
+                                   'hits_multi_sim103_k31_d1.npz', 'hits_tiny_sim101_k10_d1.npz'])
+@pytest.mark.parametrize('npaths,patched', [(3, False), (6, True)])
+def test_index_in_several_parts(fname, npaths, patched, query_mode):
+    """The same hit set from an index cut into parts of a few hundred symbols: the k-mers of all parts are
+    tabulated together (occurrences of one k-mer in several parts, k-mers whose first part is not the
+    first).  Other query modes and MEM mode refuse such an index."""
+    z = np.load(os.path.join(GOLDEN, fname))
+    reads = [str(r) for r in z['reads']]
+    k, step = int(z['k']), int(z['step'])
+    g = _graph(str(z['graph']))
+    one = psi_amd.PathIndex.build(g, k, npaths, rng_seed=2, patched=patched)
+    longest = max(sum(int(g.label_off[v + 1] - g.label_off[v]) for v in p) for p in one.paths())
+    px = psi_amd.PathIndex.build(g, k, npaths, rng_seed=2, patched=patched,
+                                 max_part_text=max(longest + 40, one.text_len // 5))      # at most 8 parts
+    assert px.view.n_more_parts >= 1
+    assert [p.tolist() for p in px.paths()] == [p.tolist() for p in one.paths()] and px.trims() == one.trims()
+    assert px.loci[0].tolist() == one.loci[0].tolist() and px.loci[1].tolist() == one.loci[1].tolist()
+    f = psi_amd.SeedFinder(g, k)
+    f.set_path_index(px)
+    if not query_mode.startswith('kmer-table'):
+        with pytest.raises(psi_amd.PsiGpuError, match='several parts'):
+            f.seeds_all(reads, step=step)
+        f.close()
+        return
+    raw = f.seeds_all(reads, step=step)
+    assert _eq(psi_amd.sort_unique(raw), z['hits'])
+    # raw emission: every on-path occurrence once, as from the one-part index
+    f1 = psi_amd.SeedFinder(g, k)
+    f1.set_path_index(one)
+    raw1 = f1.seeds_all(reads, step=step)
+    assert len(raw) == len(raw1) and _eq(raw[np.lexsort(raw.T[::-1])], raw1[np.lexsort(raw1.T[::-1])])
+    su = f.seeds_all(reads, step=step, sort_unique=True)
+    want = z['hits'][np.lexsort((z['hits'][:, 1], z['hits'][:, 0], z['hits'][:, 3], z['hits'][:, 2]))]
+    assert _eq(su, want)
+    with pytest.raises(psi_amd.PsiGpuError, match='several parts'):
+        f.find_mems(reads[:3])
+    f.close(); f1.close()
+
+
+def test_index_parts_roundtrip_and_gocc(tmp_path, query_mode):
+    """Parts survive save / load; the gocc threshold counts a k-mer's occurrences over all parts."""
+    if not query_mode.startswith('kmer-table'):
+        pytest.skip('an index in several parts is answered from the k-mer table')
+    g, reads = _x_case()
+    k = 12
+    one = psi_amd.PathIndex.build(g, k, 5, rng_seed=1)
+    px = psi_amd.PathIndex.build(g, k, 5, rng_seed=1, max_part_text=2100)
+    assert px.view.n_more_parts >= 2
+    prefix = str(tmp_path / 'parts')
+    px.save(prefix)
+    py = psi_amd.PathIndex.load(prefix)
+    assert py.view.n_more_parts == px.view.n_more_parts and py.text_len == px.text_len
+    res = {}
+    for name, ix in (('one', one), ('parts', py)):
+        f = psi_amd.SeedFinder(g, k, gocc_threshold=3)
+        f.set_path_index(ix)
+        res[name] = psi_amd.sort_unique(f.seeds_all(reads[:300], step=3))
+        f.close()
+    assert len(res['one']) and _eq(res['one'], res['parts'])

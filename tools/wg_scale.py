@@ -26,6 +26,9 @@ def main():
     ap.add_argument('--reads', type=int, default=10_000_000)
     ap.add_argument('--k', type=int, default=21)
     ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--paths', type=int, default=1, help='walks per region (psikt -n)')
+    ap.add_argument('--patched', action='store_true', help="psikt's default indexing mode")
+    ap.add_argument('--context', type=int, default=0)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -46,10 +49,10 @@ def main():
     backbone, alt = sg.backbone, sg.alt
     del sg
     t = time.time()
-    px = psi_amd.PathIndex.build(g, args.k, 1, rng_seed=1, device=0)
+    px = psi_amd.PathIndex.build(g, args.k, args.paths, rng_seed=1, device=0, patched=args.patched, context=args.context)
     out['index_build_s'] = time.time() - t
     out.update(nodes=nodes, edges=edges, text_len=int(px.text_len), starting_loci=int(px.view.n_loci),
-               ftab_len=int(px.view.ftab_len))
+               ftab_len=int(px.view.ftab_len), index_parts=1 + int(px.view.n_more_parts), paths_in_index=len(px.trims()))
     log('index %.0f s: text %d, %d loci' % (out['index_build_s'], px.text_len, px.view.n_loci))
     t = time.time()
     f = psi_amd.SeedFinder(g, args.k, device=0)
