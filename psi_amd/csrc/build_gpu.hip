@@ -214,7 +214,7 @@ int scan_u32(uint32_t* in, uint32_t* out, size_t n, bool exclusive_sum, Buf& tmp
 // T: the text in builder coding (0 sentinel, 1 separator, 2..5 ACGT), sentinel last.
 // Fills x->blocks, samples, exc_row, exc_sa, C, ftab, text4 (and *sa_out when requested).
 int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, int device, Index* x,
-                 std::vector<int32_t>* sa_out, std::string* err)
+                 std::vector<int32_t>* sa_out, bool want_fm, std::string* err)
 {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -278,6 +278,9 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
     GB_CHK(hipMemcpy(sa_out->data(), sa_cur, (size_t)n * 4, hipMemcpyDeviceToHost));
   }
 
+  // ---- BWT rank blocks + exceptions (not for an index that is only ever tabulated: several parts, or
+  //      more separators than a block header can count) --------------------------------------------------
+  if (want_fm) {
   // ---- BWT rank blocks + exceptions ------------------------------------------------------------
   const uint32_t nblk = n / BLOCK_SYMS + 1;
   Buf cA, cC, cG, cE, cT, pA, pC, pG, pE, dblocks, dexc_row, dexc_sa;
@@ -315,6 +318,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
   x->C[2] = x->C[1] + totC;
   x->C[3] = x->C[2] + totG;
 
+  }
   // ---- SA samples ---------------------------------------------------------------------------------
   const uint64_t nsamp = ((uint64_t)n + sa_rate - 1) / sa_rate;
   x->samples.resize(nsamp);
@@ -328,6 +332,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
   }
 
   // ---- interval table --------------------------------------------------------------------------------
+  if (!want_fm) q = 0;
   x->ftab_len = q;
   x->ftab.clear();
   if (q) {

@@ -178,7 +178,7 @@ static void fill_view(const Index& x, const Index& first, psigpu_index_view* v)
   v->n_paths = (uint32_t)first.paths.size();
   v->text_len = x.n;
   v->n_blocks = x.blocks.size();
-  v->bwt_blocks = x.blocks.data();
+  v->bwt_blocks = x.blocks.empty() ? nullptr : x.blocks.data();      // none: an index that can only be tabulated
   for (int i = 0; i < 4; ++i) v->C[i] = x.C[i];
   v->n_samples = x.samples.size(); v->sa_samples = x.samples.data();
   v->n_exc = x.exc_row.size(); v->exc_row = x.exc_row.data(); v->exc_sa = x.exc_sa.data();

@@ -2261,6 +2261,7 @@ struct psigpu_ctx {
   DevBuf nodes, lite, node_id, lab2, labn, edge_to;
   // index
   bool have_index = false;
+  bool fm_ok = true;               // rank blocks present: FM search possible (false: k-mer table mode only)
   uint32_t index_k = 0, sa_rate = 0, context = 0, n_paths = 0;
   uint64_t text_len = 0, n_exc = 0, n_loci = 0, n_segs = 0;
   uint64_t C[4] = { 0, 0, 0, 0 };
@@ -2633,11 +2634,14 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
   if (x->text_len >= 0xFFFFFFF0ull) { ctx->err = "text too long for the 32-bit index layout"; return PSIGPU_ERR_ARG; }
   if (x->sa_rate == 0 || (x->sa_rate & (x->sa_rate - 1))) { ctx->err = "bad sa_rate"; return PSIGPU_ERR_ARG; }
   // nothing inconsistent reaches the kernels: every array length follows from the text length
+  // (no rank blocks: an index that can only be tabulated -- several parts, or too many separators)
+  const bool fm_ok = x->bwt_blocks != nullptr && x->n_blocks != 0;
   if (x->seed_len == 0 || x->seed_len > PSIGPU_MAX_SEED_LEN || x->text_len == 0 ||
-      x->n_blocks != x->text_len / BLOCK_SYMS + 1 || x->n_dir != (x->text_len >> DIR_SHIFT) + 1 ||
+      (fm_ok && x->n_blocks != x->text_len / BLOCK_SYMS + 1) || (!fm_ok && (x->n_exc || x->ftab_len)) ||
+      x->n_dir != (x->text_len >> DIR_SHIFT) + 1 ||
       x->n_samples != (x->text_len + x->sa_rate - 1) / x->sa_rate || (x->n_exc && (!x->exc_row || !x->exc_sa)) ||
-      (x->n_loci && (!x->loci_node || !x->loci_off)) || !x->bwt_blocks || !x->sa_samples || !x->seg_start ||
-      !x->seg_dir) {
+      (x->n_loci && (!x->loci_node || !x->loci_off)) || !x->sa_samples || !x->seg_start || !x->seg_dir ||
+      (!fm_ok && (x->sa_rate != 1 || !x->text4))) {
     ctx->err = "inconsistent index view";
     return PSIGPU_ERR_ARG;
   }
@@ -2650,7 +2654,8 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
   for (uint64_t i = 0; i < x->n_dir; ++i)
     if (x->seg_dir[i] >= x->n_segs + (x->n_segs == 0)) { ctx->err = "inconsistent index view"; return PSIGPU_ERR_ARG; }
   int st;
-  if ((st = upload(ctx, ctx->blocks, (const RankBlock*)x->bwt_blocks, x->n_blocks, 1))) return st;
+  ctx->fm_ok = fm_ok;
+  if ((st = upload(ctx, ctx->blocks, (const RankBlock*)x->bwt_blocks, fm_ok ? x->n_blocks : 0, 1))) return st;
   if ((st = upload(ctx, ctx->samples, x->sa_samples, x->n_samples, 1))) return st;
   if ((st = upload(ctx, ctx->exc_row, x->exc_row, x->n_exc, 1))) return st;
   ctx->have_text4 = false;
@@ -2729,8 +2734,8 @@ static int build_row_records(psigpu_ctx* ctx, uint32_t k)
       ctx->sarec.release();
     }
   }
-  if (ctx->sa_rate == 1 && ctx->n_segs && !no_sarec) {
-    // located suffix array: only when it is a small part of what is free (the tables come later)
+  if (ctx->sa_rate == 1 && ctx->n_segs && !no_sarec && ctx->fm_ok && ctx->more.empty()) {
+    // located suffix array (FM modes): only when it is a small part of what is free (the tables come later)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)n_rows * 8 * 6 < free_b &&
         ctx->saloc.ensure(n_rows * sizeof(uint2)) == hipSuccess) {
@@ -2790,10 +2795,10 @@ static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, c
   HIPCHK(ctx, hipMemcpy(h, d_cnt, 24, hipMemcpyDeviceToHost));
   const uint64_t n_ext = h[0], n_on = h[1], n_pos = h[2];
   if (n_ext >= 0xFFFFFFF0ull || n_pos >= 0xFFFFFFF0ull) return PSIGPU_ERR_NOMEM;
-  // slots: load 0.5 when there is room, down to 0.75 when there is not
+  // slots: load 0.5 when there is room, down to 0.85 when there is not
   uint64_t slots = 0;
   hipError_t e = hipErrorOutOfMemory;
-  for (uint64_t pct : { 200ull, 160ull, 133ull }) {
+  for (uint64_t pct : { 200ull, 160ull, 133ull, 118ull }) {
     slots = std::max<uint64_t>(1024, (n_on + n_off) * pct / 100);      // (an upper bound on the distinct k-mers)
     e = ctx->kt_ht.ensure(slots * sizeof(Slot16));
     if (e == hipSuccess) e = ctx->kt_ext.ensure((n_ext + 1) * sizeof(KmerSlot));
@@ -3150,10 +3155,11 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     use_kt = ctx->lkt_ready && ctx->kt_ready;
     if (!had) EVREC(0, stream);      // a table build just ended: do not time it
   }
-  if (!ctx->more.empty() && n_reads && (flags & PSIGPU_ON_PATHS) && !use_kt) {
+  if ((!ctx->more.empty() || !ctx->fm_ok) && n_reads && (flags & PSIGPU_ON_PATHS) && ctx->n_paths && !use_kt) {
     ctx->err = ctx->query_mode != PSIGPU_MODE_KMER_TABLE || ctx->index_k != k
-                   ? "an index in several parts is answered from the k-mer table only (PSIGPU_MODE_KMER_TABLE, the index's seed length)"
-                   : "the k-mer table of this index (several parts) does not fit the device";
+                   ? "an index in several parts (or without FM arrays) is answered from the k-mer table only "
+                     "(PSIGPU_MODE_KMER_TABLE, the index's seed length)"
+                   : "the k-mer table of this index (several parts / no FM arrays) does not fit the device";
     return PSIGPU_ERR_STATE;
   }
   const uint2* trav_loci = use_lkt ? ctx->lkt_res.as<uint2>() : ctx->loci.as<uint2>();

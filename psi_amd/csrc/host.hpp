@@ -42,6 +42,8 @@ struct Index {
   std::vector<std::vector<uint32_t>> paths;    // indexed paths (node ranks)
   std::vector<uint32_t> path_head, path_tail;  // per path: offset of its first indexed base in its first node; indexed
                                                // bases of its last node (0 = all) -- Path::left / right of a patch
+  bool fm_ok = true;                           // rank blocks / exceptions / interval table present (false: an index that
+                                               // can only be tabulated -- several parts, or >= 2^24 separators)
   uint32_t locus_step = 1;                     // psikt -e the starting loci were sampled with
   uint64_t graph_fp = 0;                       // fingerprint of the graph the index was made for
   uint64_t n = 0;                              // text length
@@ -81,7 +83,7 @@ int save_index(const Index& x, const std::string& prefix);
 
 // build_gpu.hip: suffix array + FM arrays on the device (same results as the host path)
 int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, int device, Index* x,
-                 std::vector<int32_t>* sa_out, std::string* err);
+                 std::vector<int32_t>* sa_out, bool want_fm, std::string* err);
 
 // build_gpu.hip: starting loci on the device, same result as find_starting_loci()
 int gpu_find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>& paths, uint32_t k, uint32_t step,

@@ -220,7 +220,7 @@ static inline int base_sym(char ch)
 
 // FM arrays + segment table over the concatenation of paths [p0, p1): one PART of the index (an index
 // is one part unless its text would pass the 32-bit row limit).  `head` / `tail`: per-path trimming.
-static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa_rate, bool keep, bool no_ftab,
+static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa_rate, bool keep, bool no_ftab_and_fm,
                       const std::vector<std::vector<uint32_t>>& paths, const std::vector<uint32_t>& head,
                       const std::vector<uint32_t>& tail, size_t p0, size_t p1, Index* x, std::string* err)
 {
@@ -265,6 +265,12 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
   T.push_back(SYM_END);
   const uint64_t n = T.size();
   x->n = n;
+  // rank blocks count the separators in front of them in 24 bits: a text with more of them (patched paths
+  // of a whole genome), like an index in several parts, has no FM arrays and is answered from the k-mer table
+  uint64_t n_sep = 0;
+  for (uint8_t c : T) n_sep += c == SYM_SEP;
+  const bool want_fm = !no_ftab_and_fm && n_sep + 2 < (1u << 24);
+  x->fm_ok = want_fm;
   if (ss.empty() || ss[0] != 0) {          // position 0 must belong to a segment
     ss.insert(ss.begin(), 0); sn.insert(sn.begin(), NO_NODE); so.insert(so.begin(), 0);
   }
@@ -288,7 +294,7 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
     const uint32_t q_max = opts.build_on_device ? 15 : 13;
     while (q < q_max && (1ull << (2 * q)) < n) ++q;
   }
-  if (q == 0xFFFFFFFFu || p0 == p1 || no_ftab) q = 0;
+  if (q == 0xFFFFFFFFu || p0 == p1 || !want_fm) q = 0;
   // (the host builder marks "no q-mer here" with a 32-bit all-ones code: 16-mers need the device builder)
   if (q > 16 || (q == 16 && !opts.build_on_device)) {
     *err = "ftab_len above 16 (15 for host builds)"; return PSIGPU_ERR_ARG;
@@ -297,7 +303,7 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
   std::vector<int32_t> SA;
   if (opts.build_on_device) {
     // suffix array, rank blocks, samples, exceptions, interval table, 4-bit text on the GPU
-    int st = gpu_build_fm(T, sa_rate, q, (int)opts.build_on_device - 1, x, keep ? &SA : nullptr, err);
+    int st = gpu_build_fm(T, sa_rate, q, (int)opts.build_on_device - 1, x, keep ? &SA : nullptr, want_fm, err);
     if (st != PSIGPU_OK) return st;
   } else {
   // ---- suffix array ----------------------------------------------------------------
@@ -338,9 +344,8 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
     B.cnt[0] = (uint32_t)cnt[0]; B.cnt[1] = (uint32_t)cnt[1]; B.cnt[2] = (uint32_t)cnt[2];
     B.exc = (uint32_t)(nexc << 8);
   }
-  if (nexc >= (1u << 24)) {
-    *err = "too many separators in the indexed text"; return PSIGPU_ERR_ARG;
-  }
+  if (!want_fm) { x->blocks.clear(); x->exc_row.clear(); x->exc_sa.clear(); }     // (small host builds: made, then dropped)
+  else if (nexc >= (1u << 24)) { *err = "too many separators in the indexed text"; return PSIGPU_ERR_ARG; }
   x->C[0] = 1 + nsep;
   x->C[1] = x->C[0] + cnt[0];
   x->C[2] = x->C[1] + cnt[1];
@@ -545,7 +550,7 @@ int save_index(const Index& x, const std::string& prefix)
 static bool part_consistent(const Index& x, uint32_t sa_rate)
 {
   const uint64_t n = x.n;
-  bool ok = n >= 1 && n < 0xFFFFFFF0ull && x.blocks.size() == n / BLOCK_SYMS + 1 &&
+  bool ok = n >= 1 && n < 0xFFFFFFF0ull && (x.blocks.empty() ? x.exc_row.empty() : x.blocks.size() == n / BLOCK_SYMS + 1) &&
             x.samples.size() == (n + sa_rate - 1) / sa_rate && x.exc_row.size() == x.exc_sa.size() &&
             x.seg_start.size() == x.seg_node.size() + 1 && x.seg_noff.size() == x.seg_node.size() &&
             x.seg_dir.size() == (n >> DIR_SHIFT) + 1 && x.ftab_len <= 16 &&
@@ -598,6 +603,8 @@ Index* load_index(const std::string& prefix, int* status)
          part_consistent(*x, x->sa_rate) && x->loci_node.size() == x->loci_off.size() &&
          x->path_head.size() == x->paths.size() && x->path_tail.size() == x->paths.size();
     for (const Index& m : x->more) ok = ok && x->sa_rate == 1 && part_consistent(m, 1);
+    x->fm_ok = !x->blocks.empty();
+    for (Index& m : x->more) m.fm_ok = !m.blocks.empty();
   }
   if (!ok) { delete x; *status = PSIGPU_ERR_FORMAT; return nullptr; }
   *status = PSIGPU_OK;
