@@ -448,8 +448,12 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
   {
     uint64_t cur = 1;
     for (size_t pi = 0; pi < paths.size(); ++pi) {
-      uint64_t len = 1;
+      uint64_t len = 1;                                   // the path's text (trimmed ends left out) + its separator
       for (uint32_t v : paths[pi]) len += g.node_len(v);
+      if (!paths[pi].empty()) {
+        len -= x->path_head[pi];
+        if (x->path_tail[pi]) len -= g.node_len(paths[pi].back()) - x->path_tail[pi];
+      }
       if (len + 1 >= hard_max) {
         *status = PSIGPU_ERR_ARG;
         *err = opts.build_on_device ? "one indexed path is too long for the 32-bit index layout"

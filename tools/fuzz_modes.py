@@ -60,6 +60,34 @@ def main():
                 if got_loci != brute.uncovered_loci(g, paths_ids, k, px.trims()):
                     print('LOCI MISMATCH', seed, k, npaths, patched, flush=True)
                     sys.exit(1)
+            if npaths >= 2 and rng.random() < 0.5:
+                # the same paths indexed in several parts (k-mer table only): hit set, raw multiplicities,
+                # gocc threshold over all parts
+                lens = [sum(len(g.seq[v]) for v in p) for p in paths_ids]
+                cut = max(max(lens) + 40, int(px.text_len) // rng.choice([2, 3, 4]))      # at most 8 parts
+                try:
+                    pp = psi_amd.PathIndex.build(pg, k, npaths, rng_seed=seed, patched=patched, context=px.view.context,
+                                                 device=rng.choice([None, 0]), max_part_text=cut)
+                except psi_amd.PsiGpuError as e:          # more than 8 parts (one long path sets the cut): not a case
+                    if 'too many parts' not in str(e):
+                        raise
+                    pp = None
+                if pp is not None and pp.view.n_more_parts:
+                    gocc = rng.choice([0, 0, 1, 3])
+                    res = []
+                    for ix in (px, pp):
+                        f = psi_amd.SeedFinder(pg, k, mode='kmer-table', gocc_threshold=gocc)
+                        f.set_path_index(ix)
+                        raw = f.seeds_all(reads, step=step)
+                        res.append(raw[np.lexsort(raw.T[::-1])])
+                        f.close()
+                    if not (res[0].shape == res[1].shape and (res[0] == res[1]).all()):
+                        print('PARTS MISMATCH', seed, k, step, npaths, patched, cut, gocc, flush=True)
+                        sys.exit(1)
+                    if gocc == 0 and not (psi_amd.sort_unique(res[1]).shape == want.shape and (psi_amd.sort_unique(res[1]) == want).all()):
+                        print('PARTS vs BRUTE MISMATCH', seed, k, step, npaths, flush=True)
+                        sys.exit(1)
+                    n_cases += 1
             for mode in ('kmer-table', 'locus-table', 'traverse'):
                 for cap in ((0,) if mode == 'traverse' else (0, 1, 3)):
                     f = psi_amd.SeedFinder(pg, k, mode=mode, walk_cap=cap)
@@ -90,6 +118,8 @@ def main():
                             sys.exit(1)
                     f.close()
                     n_cases += 1
+        if (seed - first) % 25 == 24:
+            print('.. through seed %d, %d finder runs' % (seed, n_cases), flush=True)
     print('ok: seeds %d..%d, %d finder runs' % (first, last, n_cases))
 
 
