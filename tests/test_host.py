@@ -429,6 +429,45 @@ def test_index_save_load_roundtrip(tmp_path, ref_data):
         psi_amd.PathIndex.load(str(tmp_path / 'missing'))
 
 
+@pytest.mark.parametrize('patched', [False, True])
+def test_index_in_several_parts_host(tmp_path, ref_data, patched):
+    """An index whose text would pass the row limit is cut into parts: consecutive groups of paths, each
+    with its own text / suffix array / segment table and no FM arrays (answered from the k-mer table).  Same
+    paths, trims and starting loci as the one-part index; the parts' segment tables tile the paths; the
+    container file carries the parts."""
+    b, g = _setup(ref_data, 'x')
+    k = 16
+    one = psi_amd.PathIndex.build(g, k, 4, rng_seed=3, patched=patched)
+    lens = [sum(int(g.label_off[v + 1] - g.label_off[v]) for v in p) for p in one.paths()]
+    px = psi_amd.PathIndex.build(g, k, 4, rng_seed=3, patched=patched, max_part_text=max(max(lens) + 40, one.text_len // 4))
+    n_more = px.view.n_more_parts
+    assert 1 <= n_more < 8
+    assert [p.tolist() for p in px.paths()] == [p.tolist() for p in one.paths()] and px.trims() == one.trims()
+    assert px.loci[0].tolist() == one.loci[0].tolist() and px.loci[1].tolist() == one.loci[1].tolist()
+    views = [px.view] + px.more_parts()
+    # no rank blocks / interval table in any part; whole suffix array and 4-bit text in every part
+    for v in views:
+        assert not v.bwt_blocks and v.n_blocks == 0 and v.ftab_len == 0 and v.sa_rate == 1 and v.text4
+    # the parts hold the paths in order: texts add up (the last separator of a part is its sentinel)
+    assert sum(v.text_len for v in views) == one.text_len
+    assert all(v.text_len <= max(max(lens) + 40, one.text_len // 4) for v in views)
+    prefix = str(tmp_path / 'parts')
+    px.save(prefix)
+    py = psi_amd.PathIndex.load(prefix)
+    assert py.view.n_more_parts == n_more and py.matches(g, k, 1)
+    for a, c in zip(views, [py.view] + py.more_parts()):
+        assert (a.text_len, a.n_paths, a.n_segs) == (c.text_len, c.n_paths, c.n_segs)
+        nt = a.text_len // 16 + 2
+        assert (px._arr(a.text4, nt, np.uint64) == py._arr(c.text4, nt, np.uint64)).all()
+        assert (px._arr(a.sa_samples, a.text_len, np.uint32) == py._arr(c.sa_samples, c.text_len, np.uint32)).all()
+    assert [p.tolist() for p in py.paths()] == [p.tolist() for p in one.paths()] and py.trims() == one.trims()
+    # more than PSIGPU_MAX_PARTS parts, or a sampled suffix array, are refused
+    with pytest.raises(psi_amd.PsiGpuError, match='too many parts'):
+        psi_amd.PathIndex.build(g, k, 40, rng_seed=3, max_part_text=max(lens) + 40)
+    with pytest.raises(psi_amd.PsiGpuError, match='several parts'):
+        psi_amd.PathIndex.build(g, k, 4, rng_seed=3, sa_rate=4, max_part_text=max(max(lens) + 40, one.text_len // 4))
+
+
 def test_index_argument_checks(ref_data):
     b, g = _setup(ref_data, 'tiny')
     with pytest.raises(psi_amd.PsiGpuError):
