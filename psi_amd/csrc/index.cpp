@@ -11,6 +11,7 @@
 // with the reference as hit SETS, never as suffix-array coordinates.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 
@@ -269,7 +270,9 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
   // of a whole genome), like an index in several parts, has no FM arrays and is answered from the k-mer table
   uint64_t n_sep = 0;
   for (uint8_t c : T) n_sep += c == SYM_SEP;
-  const bool want_fm = !no_ftab_and_fm && n_sep + 2 < (1u << 24);
+  uint64_t sep_limit = 1u << 24;
+  if (const char* e = getenv("PSIGPU_TEST_SEP_LIMIT")) sep_limit = std::min<uint64_t>(sep_limit, strtoull(e, nullptr, 10));   // tests
+  const bool want_fm = !no_ftab_and_fm && n_sep + 2 < sep_limit;
   x->fm_ok = want_fm;
   if (ss.empty() || ss[0] != 0) {          // position 0 must belong to a segment
     ss.insert(ss.begin(), 0); sn.insert(sn.begin(), NO_NODE); so.insert(so.begin(), 0);

@@ -897,6 +897,34 @@ def test_index_in_several_parts(fname, npaths, patched, query_mode):
     f.close(); f1.close()
 
 
+def test_index_without_fm_arrays(monkeypatch, query_mode):
+    """A text with more separators than a rank block header counts (2^24: the patches of a whole genome; here
+    the limit is lowered through the test hook) is indexed without rank blocks / interval table: answered
+    from the k-mer table, MEM mode included (it bisects the suffix array); the FM query modes refuse it."""
+    g, reads = _x_case()
+    k = 12
+    one = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3)
+    monkeypatch.setenv('PSIGPU_TEST_SEP_LIMIT', '3')
+    px = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3, device=0)
+    py = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3)
+    monkeypatch.delenv('PSIGPU_TEST_SEP_LIMIT')
+    for ix in (px, py):
+        assert ix.view.n_more_parts == 0 and not ix.view.bwt_blocks and ix.view.n_blocks == 0 and one.view.n_blocks > 0
+        assert ix.loci[0].tolist() == one.loci[0].tolist() and ix.loci[1].tolist() == one.loci[1].tolist()
+        f = psi_amd.SeedFinder(g, k)
+        f.set_path_index(ix)
+        f1 = psi_amd.SeedFinder(g, k)
+        f1.set_path_index(one)
+        if not query_mode.startswith('kmer-table'):
+            with pytest.raises(psi_amd.PsiGpuError, match='k-mer table only'):
+                f.seeds_all(reads[:50], step=3)
+        else:
+            a, b = f.seeds_all(reads[:400], step=3), f1.seeds_all(reads[:400], step=3)
+            assert len(a) and _eq(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+            assert _eq(f.find_mems(reads[:100]), f1.find_mems(reads[:100]))
+        f.close(); f1.close()
+
+
 def test_index_parts_roundtrip_and_gocc(tmp_path, query_mode):
     """Parts survive save / load; the gocc threshold counts a k-mer's occurrences over all parts."""
     if not query_mode.startswith('kmer-table'):
