@@ -1152,6 +1152,7 @@ struct PkPart {
   const uint32_t* sa; const SegRec* seg; const uint32_t* seg_rank; const uint32_t* seg_dir;
 };
 struct PkParts { PkPart p[PSIGPU_MAX_PARTS]; uint32_t n_parts; };
+constexpr uint32_t KT_DEDUP_MAX = 32;      // runs of up to this many occurrences are de-duplicated at build time
 
 // rows [first, first + count) of `key` in a part (count 0: not a k-mer of this part)
 __device__ __forceinline__ uint64_t pk_run(const PkPart& pt, uint64_t key, uint64_t* first)
@@ -1183,7 +1184,8 @@ template <bool FILL>
 __global__ void k_kt_direct_on(PkParts parts, uint32_t q, const uint64_t* __restrict__ okeys,
                                const uint32_t* __restrict__ ovals, uint64_t n_off, const uint2* __restrict__ loci,
                                Slot16* __restrict__ ht, uint64_t n_slots, KmerSlot* __restrict__ ext,
-                               uint2* __restrict__ on_pos, unsigned long long* __restrict__ cnt /* [0] EXT records, [1] path k-mers, [2] positions */)
+                               uint2* __restrict__ on_pos, unsigned long long* __restrict__ cnt /* [0] EXT records, [1] path k-mers, [2] positions */,
+                               bool dedup)
 {
   const PkPart& me = parts.p[q];
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1204,6 +1206,25 @@ __global__ void k_kt_direct_on(PkParts parts, uint32_t q, const uint64_t* __rest
   if (on_cnt == 1) {
     const uint2 at = pk_position(me, i);
     r.on_a = at.x; r.on_b = at.y; r.on_cnt = 1u | KT_INLINE;
+  } else if (dedup && on_cnt <= KT_DEDUP_MAX) {
+    // The same graph position on several indexed paths (full paths: nearly every k-mer) is one hit: kept
+    // once, and a k-mer whose occurrences are all one position stays in its slot like a single occurrence.
+    // (Not with a gocc threshold, which counts occurrences in the path text: index_iter.hpp:843-847.)
+    uint2 u[KT_DEDUP_MAX];
+    uint32_t n_u = 0;
+    for (uint32_t pr = q; pr < parts.n_parts; ++pr)
+      for (uint64_t t = 0; t < count[pr]; ++t) {
+        const uint2 at = pk_position(parts.p[pr], first[pr] + t);
+        bool seen = false;
+        for (uint32_t x = 0; x < n_u; ++x) seen = seen || (u[x].x == at.x && u[x].y == at.y);
+        if (!seen) u[n_u++] = at;
+      }
+    if (n_u == 1) { r.on_a = u[0].x; r.on_b = u[0].y; r.on_cnt = 1u | KT_INLINE; }
+    else {
+      const unsigned long long base = atomicAdd(&cnt[2], (unsigned long long)n_u);
+      if (FILL) for (uint32_t x = 0; x < n_u; ++x) on_pos[base + x] = u[x];
+      r.on_a = (uint32_t)base; r.on_cnt = n_u;
+    }
   } else {
     const unsigned long long base = atomicAdd(&cnt[2], (unsigned long long)on_cnt);
     if (FILL) {
@@ -2276,6 +2297,7 @@ struct psigpu_ctx {
   uint64_t id_base = 0;
   DevBuf blocks, samples, exc_row, exc_sa, seg, seg_dir, loci;
   uint32_t gocc_thr = 0;
+  bool kt_dedup = false;           // the k-mer table was built without a gocc threshold: one entry per graph position
   // locus k-mer table (built on first use for the index's seed length)
   uint32_t query_mode = PSIGPU_MODE_KMER_TABLE, walk_cap = 0;
   bool lkt_ready = false, lkt_failed = false;
@@ -2451,9 +2473,15 @@ const char* psigpu_last_error(const psigpu_ctx* ctx)
   return ctx ? ctx->err.c_str() : g_create_err.c_str();
 }
 
+static void lkt_release(psigpu_ctx* ctx);
+
 int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr)
 {
   if (!ctx) return PSIGPU_ERR_ARG;
+  if (thr && ctx->kt_ready && ctx->kt_dedup) {       // the table holds positions, the threshold counts occurrences: rebuilt
+    if (hipSetDevice(ctx->device) != hipSuccess) return PSIGPU_ERR_DEVICE;
+    lkt_release(ctx);
+  }
   ctx->gocc_thr = thr;
   return PSIGPU_OK;
 }
@@ -2759,6 +2787,8 @@ static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, c
                            unsigned long long* d_cnt /* room for four counters */)
 {
   const uint32_t n_parts = 1 + (uint32_t)ctx->more.size();
+  const bool dedup = ctx->gocc_thr == 0;
+  ctx->kt_dedup = dedup;
   TmpBuf pk[PSIGPU_MAX_PARTS];
   PkParts parts{};
   parts.n_parts = n_parts;
@@ -2789,7 +2819,7 @@ static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, c
   HIPCHK(ctx, hipMemset(d_cnt, 0, 32));
   for (uint32_t q = 0; q < n_parts; ++q)
     k_kt_direct_on<false><<<(unsigned)((parts.p[q].n + 255) / 256), 256>>>(parts, q, okeys, ovals, n_off, ctx->loci.as<uint2>(), nullptr, 0,
-                                                                          nullptr, nullptr, d_cnt);
+                                                                          nullptr, nullptr, d_cnt, dedup);
   if (n_off) k_kt_direct_off<false><<<grid_off, 256>>>(okeys, ovals, n_off, ctx->loci.as<uint2>(), parts, nullptr, 0, nullptr, d_cnt);
   unsigned long long h[3] = { 0, 0, 0 };
   HIPCHK(ctx, hipMemcpy(h, d_cnt, 24, hipMemcpyDeviceToHost));
@@ -2813,7 +2843,7 @@ static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, c
   for (uint32_t q = 0; q < n_parts; ++q)
     k_kt_direct_on<true><<<(unsigned)((parts.p[q].n + 255) / 256), 256>>>(parts, q, okeys, ovals, n_off, ctx->loci.as<uint2>(),
                                                                          ctx->kt_ht.as<Slot16>(), slots, ctx->kt_ext.as<KmerSlot>(),
-                                                                         ctx->kt_onpos.as<uint2>(), d_cnt);
+                                                                         ctx->kt_onpos.as<uint2>(), d_cnt, dedup);
   if (n_off)
     k_kt_direct_off<true><<<grid_off, 256>>>(okeys, ovals, n_off, ctx->loci.as<uint2>(), parts, ctx->kt_ht.as<Slot16>(), slots,
                                              ctx->kt_ext.as<KmerSlot>(), d_cnt);

@@ -897,6 +897,32 @@ def test_index_in_several_parts(fname, npaths, patched, query_mode):
     f.close(); f1.close()
 
 
+def test_positions_deduplicated_at_table_build(query_mode):
+    """Without a gocc threshold the k-mer table keeps one entry per graph position: a k-mer found at the
+    same position on several full paths is one hit, not one per path.  A threshold counts occurrences in the
+    path text (index_iter.hpp:843-847), so the table is then built (or rebuilt) with every occurrence."""
+    if not query_mode.startswith('kmer-table'):
+        pytest.skip('k-mer table build')
+    g, reads = _x_case()
+    k = 12
+    px = psi_amd.PathIndex.build(g, k, 4, rng_seed=1)           # 4 full paths
+    f = psi_amd.SeedFinder(g, k)
+    f.set_path_index(px)
+    on = f.seeds_on_paths(reads[:300], step=3)
+    f2 = psi_amd.SeedFinder(g, k, gocc_threshold=1 << 30)
+    f2.set_path_index(px)
+    on2 = f2.seeds_on_paths(reads[:300], step=3)
+    assert len(on) and len(on) < len(on2) and _eq(psi_amd.sort_unique(on), psi_amd.sort_unique(on2))
+    assert len(np.unique(on, axis=0)) == len(on)
+    # a threshold set after the table was built: same answer as a finder that had it from the start
+    psi_amd.lib().psigpu_set_gocc_threshold(f.ctx, 3)
+    f3 = psi_amd.SeedFinder(g, k, gocc_threshold=3)
+    f3.set_path_index(px)
+    a, b = f.seeds_all(reads[:300], step=3), f3.seeds_all(reads[:300], step=3)
+    assert len(a) == len(b) and _eq(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+    f.close(); f2.close(); f3.close()
+
+
 def test_index_without_fm_arrays(monkeypatch, query_mode):
     """A text with more separators than a rank block header counts (2^24: the patches of a whole genome; here
     the limit is lowered through the test hook) is indexed without rank blocks / interval table: answered
