@@ -1039,12 +1039,14 @@ k_lkt_probe(LktView lk, const uint64_t* __restrict__ seed_key, const uint64_t* _
 // ------------------------------------------------------------------------------------
 struct KmerSlot {           // the full description of a k-mer, 32 bytes: kept only for the few that need it (EXT)
   uint64_t key;             // KEY_INVALID: empty
-  uint32_t on_a, on_b;      // on_cnt & KT_INLINE: (node rank, offset) of the only occurrence; else on_a = first SA row
-  uint32_t off_a, off_b;    // off_cnt & KT_INLINE: (node rank, offset) of the only locus; else off_a = first locus entry
+  uint32_t on_a, on_b;      // on_cnt & KT_INLINE: (node rank, offset) of the only occurrence; else on_a = first entry of on_pos
+  uint32_t off_a, off_b;    // off_cnt & KT_INLINE: (node rank, offset) of the only locus; else off_a = first locus entry,
+                            // off_b = how many of the run's loci are at none of the on-path positions (those come first)
   uint32_t on_cnt, off_cnt; // occurrences on the indexed paths / starting loci with a k-walk spelling the k-mer
 };
 static_assert(sizeof(KmerSlot) == 32, "k-mer table slot must be 32 bytes");
 constexpr uint32_t KT_INLINE = 0x80000000u;
+constexpr uint32_t KT_OFFDUP = 0x40000000u;   // with KT_INLINE in off_cnt: the only locus is at one of the on-path positions
 
 // What the query probes is a table of 16-BYTE slots: a divergent 16-byte load is the unit the
 // memory pipeline charges for (two loads per probe cost twice: 27.9 G against 41.4 G probes/s,
@@ -1066,7 +1068,7 @@ __device__ __forceinline__ uint64_t kt_next(uint64_t h, uint64_t n_slots) { retu
 
 __device__ __forceinline__ uint64_t slot16_type(const KmerSlot& r)
 {
-  const bool on1 = r.on_cnt == (1u | KT_INLINE), off1 = r.off_cnt == (1u | KT_INLINE);
+  const bool on1 = r.on_cnt == (1u | KT_INLINE), off1 = (r.off_cnt & ~KT_OFFDUP) == (1u | KT_INLINE);
   if (on1 && r.off_cnt == 0) return K16_ON1;
   if (off1 && r.on_cnt == 0) return K16_OFF1;
   if (on1 && off1 && r.on_a == r.off_a && r.on_b == r.off_b) return K16_BOTH1;
@@ -1182,7 +1184,7 @@ __device__ __forceinline__ uint2 pk_position(const PkPart& pt, uint64_t row)
 // FILL = false: only count the k-mers that need a 32-byte record (EXT), the positions, the path k-mers.
 template <bool FILL>
 __global__ void k_kt_direct_on(PkParts parts, uint32_t q, const uint64_t* __restrict__ okeys,
-                               const uint32_t* __restrict__ ovals, uint64_t n_off, const uint2* __restrict__ loci,
+                               uint32_t* ovals, uint64_t n_off, const uint2* __restrict__ loci,
                                Slot16* __restrict__ ht, uint64_t n_slots, KmerSlot* __restrict__ ext,
                                uint2* __restrict__ on_pos, unsigned long long* __restrict__ cnt /* [0] EXT records, [1] path k-mers, [2] positions */,
                                bool dedup)
@@ -1203,15 +1205,18 @@ __global__ void k_kt_direct_on(PkParts parts, uint32_t q, const uint64_t* __rest
   if (j < n_off && okeys[j] == key) off_cnt = lower_bound_sh(okeys, j + 1, n_off, key + 1, 0) - j;
   KmerSlot r;
   r.key = key; r.on_a = r.on_b = r.off_a = r.off_b = 0;
+  uint2 u[KT_DEDUP_MAX];               // the k-mer's on-path positions, when they are few
+  uint32_t n_u = 0;
+  bool have_u = false;
   if (on_cnt == 1) {
     const uint2 at = pk_position(me, i);
     r.on_a = at.x; r.on_b = at.y; r.on_cnt = 1u | KT_INLINE;
+    u[0] = at; n_u = 1; have_u = true;
   } else if (dedup && on_cnt <= KT_DEDUP_MAX) {
     // The same graph position on several indexed paths (full paths: nearly every k-mer) is one hit: kept
     // once, and a k-mer whose occurrences are all one position stays in its slot like a single occurrence.
     // (Not with a gocc threshold, which counts occurrences in the path text: index_iter.hpp:843-847.)
-    uint2 u[KT_DEDUP_MAX];
-    uint32_t n_u = 0;
+    have_u = true;
     for (uint32_t pr = q; pr < parts.n_parts; ++pr)
       for (uint64_t t = 0; t < count[pr]; ++t) {
         const uint2 at = pk_position(parts.p[pr], first[pr] + t);
@@ -1234,8 +1239,31 @@ __global__ void k_kt_direct_on(PkParts parts, uint32_t q, const uint64_t* __rest
     }
     r.on_a = (uint32_t)base; r.on_cnt = (uint32_t)min(on_cnt, (uint64_t)0x3FFFFFFFu);
   }
-  if (off_cnt == 1) { const uint2 lc = loci[ovals[j]]; r.off_a = lc.x; r.off_b = lc.y; r.off_cnt = 1u | KT_INLINE; }
-  else { r.off_a = (uint32_t)j; r.off_cnt = (uint32_t)off_cnt; }
+  // A locus at one of the on-path positions gives the hit the path gives (the on-path k-walk from an
+  // uncovered locus): when the on-path occurrences are emitted it is left out -- loci of that kind go to
+  // the end of the k-mer's run, and the record says how many are in front of them.
+  auto on_path_position = [&](uint2 lc) {
+    bool seen = false;
+    for (uint32_t x = 0; x < n_u; ++x) seen = seen || (u[x].x == lc.x && u[x].y == lc.y);
+    return seen;
+  };
+  if (off_cnt == 1) {
+    const uint2 lc = loci[ovals[j]];
+    r.off_a = lc.x; r.off_b = lc.y; r.off_cnt = 1u | KT_INLINE;
+    if (have_u && on_path_position(lc)) r.off_cnt |= KT_OFFDUP;
+  } else {
+    uint64_t front = off_cnt;
+    if (have_u && off_cnt <= KT_DEDUP_MAX) {
+      front = 0;
+      for (uint64_t t = 0; t < off_cnt; ++t) {
+        const uint32_t v = ovals[j + t];
+        if (on_path_position(loci[v])) continue;
+        if (FILL && front != t) { ovals[j + t] = ovals[j + front]; ovals[j + front] = v; }
+        ++front;
+      }
+    }
+    r.off_a = (uint32_t)j; r.off_b = (uint32_t)front; r.off_cnt = (uint32_t)off_cnt;
+  }
   const uint64_t type = slot16_type(r);
   if (type == K16_EXT) {
     const unsigned long long e = atomicAdd(&cnt[0], 1ull);
@@ -1266,7 +1294,7 @@ __global__ void k_kt_direct_off(const uint64_t* __restrict__ okeys, const uint32
     const unsigned long long e = atomicAdd(&cnt[0], 1ull);
     if (FILL) {
       KmerSlot r;
-      r.key = key; r.on_a = r.on_b = 0; r.on_cnt = 0; r.off_a = (uint32_t)j; r.off_b = 0; r.off_cnt = (uint32_t)off_cnt;
+      r.key = key; r.on_a = r.on_b = 0; r.on_cnt = 0; r.off_a = (uint32_t)j; r.off_b = (uint32_t)off_cnt; r.off_cnt = (uint32_t)off_cnt;
       ext[e] = r;
       kt_place(ht, n_slots, key, K16_EXT, (uint32_t)e, 0);
     }
@@ -1304,12 +1332,15 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
           res.x = v.z; res.y = v.w;
           if (type == K16_EXT) {
             const uint4 e = reinterpret_cast<const uint4*>(kt.ext + v.z)[1];      // off_a, off_b, on_cnt, off_cnt
-            const uint32_t c_on = e.z & ~KT_INLINE, c_off = e.w & ~KT_INLINE;
-            res.z = RES_EXT | ((want_on && c_on <= gocc_thr) ? min(c_on, RES_CNT) : 0u);
-            res.w = want_off ? c_off : 0u;
+            const uint32_t c_on = e.z & ~KT_INLINE;
+            const bool on_emitted = want_on && c_on <= gocc_thr;
+            res.z = RES_EXT | (on_emitted ? min(c_on, RES_CNT) : 0u);
+            // loci at an on-path position are left out when the on-path occurrences are emitted
+            if (want_off) res.w = (e.w & KT_INLINE) ? ((on_emitted && (e.w & KT_OFFDUP)) ? 0u : 1u) : (on_emitted ? e.y : e.w);
           } else {
             if (want_on && type != K16_OFF1) res.z = 1u | RES_INLINE;
-            if (want_off && type != K16_ON1) res.w = 1u | RES_INLINE;
+            // (one occurrence and one locus at the same position, both phases asked for: one hit)
+            if (want_off && type != K16_ON1 && !(want_on && type == K16_BOTH1)) res.w = 1u | RES_INLINE;
           }
           break;
         }
@@ -2783,7 +2814,7 @@ static int build_row_records(psigpu_ctx* ctx, uint32_t k)
 // The k-mer table built straight into its 16-byte slots (see k_pk_encode), over all parts of the index.
 // `okeys` / `ovals`: the sorted (k-mer, locus) pairs.  Returns PSIGPU_ERR_NOMEM when it does not fit
 // (kt_ready stays false).
-static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, const uint32_t* ovals, uint64_t n_off,
+static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, uint32_t* ovals, uint64_t n_off,
                            unsigned long long* d_cnt /* room for four counters */)
 {
   const uint32_t n_parts = 1 + (uint32_t)ctx->more.size();
@@ -3057,7 +3088,7 @@ static int ensure_lkt(psigpu_ctx* ctx, uint32_t k, const GraphView& gv)
   spill_a.drop(); spill_b.drop();
   const uint64_t n_ent = n_pairs - n_dropped;
   const uint64_t* sorted_keys = keys_a.as<uint64_t>();
-  const uint32_t* sorted_vals = vals_a.as<uint32_t>();
+  uint32_t* sorted_vals = vals_a.as<uint32_t>();
   // the sorted loci stay: they are the locus runs the tables point into (LocusEnt)
   LKT_TRY(ctx->lkt_ent.ensure((n_pairs + 1) * sizeof(LocusEnt)));
   if (n_pairs) {

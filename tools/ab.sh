@@ -1,16 +1,4 @@
-#!/bin/bash
-# A/B of experiment builds on the GPU box, interleaved, serial kernels (PSIGPU_SERIAL=1).
-# usage: bash tools/ab.sh ROUNDS "bench args" lib1.so lib2.so ...
-ROUNDS=$1; shift; ARGS=$1; shift
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-for r in $(seq 1 $ROUNDS); do
-  for L in "$@"; do
-    for MODE in serial overlap; do
-      unset PSIGPU_SERIAL
-      if [ $MODE = serial ]; then export PSIGPU_SERIAL=1; fi
-      PSI_AMD_LIB=$R/psi_amd/$L python $R/bench.py --steps 8 --warmup 2 --cpu-reads 0 $ARGS 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_step']
-print('%-28s %-8s step %.3f  K1 %.3f K2 %.3f K4 %.3f pack %.3f' % ('$L','$MODE',d['ms_per_step'],k['k_fm_search'],k['k_fm_locate'],k['k_traverse'],k['k_table_insert']+k['k_seed_pack']))"
-    done
-  done
+for i in 1 2; do
+  PSI_AMD_LIB=$PWD/psi_amd/bin/libpsi_gpu_prev.so python bench.py --lean --no-check --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('prev', d['ms_per_step'], d['roofline']['kernel_ms_per_step'])"
+  python bench.py --lean --no-check --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('new ', d['ms_per_step'], d['roofline']['kernel_ms_per_step'])"
 done
