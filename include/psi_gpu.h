@@ -361,6 +361,8 @@ typedef struct psigpu_counters {
   float ms_probe;                              /* k-mer table / locus table probe */
   float ms_locus_table_build;                  /* one-off: building the tables (first query) */
   uint32_t search_launches, traverse_launches;
+  uint32_t sorted_in_place;                    /* PSIGPU_SORT_UNIQUE: sub-batches whose hits, emitted seed by seed, only needed
+                                                * the hits of each seed put in order (no radix sort) */
 } psigpu_counters;
 int psigpu_get_counters(const psigpu_ctx* ctx, psigpu_counters* out);
 

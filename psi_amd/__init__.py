@@ -82,7 +82,7 @@ class Counters(C.Structure):
                 ('ms_locate', C.c_float), ('ms_traverse', C.c_float), ('ms_sort', C.c_float),
                 ('ms_total', C.c_float), ('ms_probe', C.c_float), ('ms_locus_table_build', C.c_float),
                 ('search_launches', C.c_uint32),
-                ('traverse_launches', C.c_uint32)]
+                ('traverse_launches', C.c_uint32), ('sorted_in_place', C.c_uint32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

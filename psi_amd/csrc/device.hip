@@ -3569,22 +3569,44 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
 // PSIGPU_SORT_UNIQUE on the device: ctx->w_hits[0..n) -> dst[0..*n_out), on `stream`; one host
 // synchronisation for the count.  Returns PSIGPU_ERR_FORMAT (err untouched) when the records of this
 // chunk do not fit the sorter's 64-bit key: the caller falls back to the host sort.
+// Sorted, duplicate-free records of the n hits in w_hits: in `dst`, or -- *in_place -- in w_hits itself when
+// ordering the few hits of each seed was all there was to do (HitSorter::fix_grouped).
 static int device_sort_unique(psigpu_ctx* ctx, uint64_t n, uint64_t n_reads, uint64_t rec_offset, DevBuf& dst,
-                              hipStream_t stream, uint64_t* n_out)
+                              hipStream_t stream, uint64_t* n_out, bool* in_place)
 {
   *n_out = 0;
+  *in_place = false;
   if (n == 0) return PSIGPU_OK;
+  HIPCHK(ctx, ctx->w_count.ensure(64));
+  uint64_t* h_n = reinterpret_cast<uint64_t*>((char*)ctx->h_pinned + sizeof(DevCounters) + 16);
+  uint4* h_n_dev = reinterpret_cast<uint4*>((char*)ctx->h_pinned_dev + sizeof(DevCounters) + 16);
+  const bool no_grouped = getenv("PSIGPU_NO_GROUPED_SORT") != nullptr;      // tests: always the general path
+  if (ctx->last.traverse_launches == 0 && !no_grouped) {       // (the traverser's hits are not grouped by seed)
+    EVREC(11, stream);
+    int st = HitSorter::fix_grouped(ctx->w_hits.as<psigpu_hit>(), n, ctx->w_count.as<uint64_t>(), stream, &ctx->err);
+    if (st != PSIGPU_OK) return st;
+    EVREC(0, stream);
+    k_publish<<<1, 256, 0, stream>>>(ctx->w_count.as<uint4>(), h_n_dev, 1);
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    if (*h_n == 0) {
+      float t = 0;
+      (void)hipEventElapsedTime(&t, ctx->ev[11], ctx->ev[0]);
+      ctx->last.ms_sort = t;
+      ctx->last.n_hits = *n_out = n;
+      ctx->last.sorted_in_place = 1;
+      *in_place = true;
+      return PSIGPU_OK;
+    }
+  }
   if (!HitSorter::fits(n_reads, ctx->last_max_read_len, ctx->n_nodes, ctx->max_node_len)) return PSIGPU_ERR_FORMAT;
   HIPCHK(ctx, dst.ensure((n + 1) * sizeof(psigpu_hit)));
-  HIPCHK(ctx, ctx->w_count.ensure(64));
   EVREC(11, stream);
   int st = ctx->sorter.run(ctx->w_hits.as<psigpu_hit>(), n, rec_offset, n_reads, ctx->last_max_read_len, ctx->n_nodes,
                            ctx->max_node_len, ctx->id_affine, ctx->id_base, ctx->ids_sorted.as<uint64_t>(),
                            dst.as<psigpu_hit>(), ctx->w_count.as<uint64_t>(), stream, &ctx->err);
   if (st != PSIGPU_OK) return st;
   EVREC(0, stream);                 // (event 0 is free again once run_pipeline has read its times)
-  uint64_t* h_n = reinterpret_cast<uint64_t*>((char*)ctx->h_pinned + sizeof(DevCounters) + 16);
-  k_publish<<<1, 256, 0, stream>>>(ctx->w_count.as<uint4>(), reinterpret_cast<uint4*>((char*)ctx->h_pinned_dev + sizeof(DevCounters) + 16), 1);
+  k_publish<<<1, 256, 0, stream>>>(ctx->w_count.as<uint4>(), h_n_dev, 1);
   HIPCHK(ctx, hipStreamSynchronize(stream));
   *n_out = *h_n;
   float t = 0;
@@ -3609,10 +3631,11 @@ int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_
   *d_hits = ctx->w_hits.as<psigpu_hit>();
   *n_hits = n;
   if (flags & PSIGPU_SORT_UNIQUE) {
-    st = device_sort_unique(ctx, n, n_reads, rec_offset, ctx->w_sorted[0], (hipStream_t)stream, &n);
+    bool in_place = false;
+    st = device_sort_unique(ctx, n, n_reads, rec_offset, ctx->w_sorted[0], (hipStream_t)stream, &n, &in_place);
     if (st == PSIGPU_ERR_FORMAT) { ctx->err = "hit records of this chunk do not fit the device sorter's 64-bit key"; return PSIGPU_ERR_ARG; }
     if (st != PSIGPU_OK) return st;
-    *d_hits = n ? ctx->w_sorted[0].as<psigpu_hit>() : ctx->w_hits.as<psigpu_hit>();
+    *d_hits = (n && !in_place) ? ctx->w_sorted[0].as<psigpu_hit>() : ctx->w_hits.as<psigpu_hit>();
     *n_hits = n;
   }
   return PSIGPU_OK;
@@ -4046,10 +4069,11 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     float ms_sort = 0.f;
     if (want_sort && !host_sort && n) {
       uint64_t nu = 0;
-      st = device_sort_unique(ctx, n, nr, rec_offset + r0, ctx->w_sorted[i & 1], sc, &nu);
+      bool in_place = false;
+      st = device_sort_unique(ctx, n, nr, rec_offset + r0, ctx->w_sorted[i & 1], sc, &nu, &in_place);
       if (st == PSIGPU_ERR_FORMAT) host_sort = true;
       else if (st != PSIGPU_OK) return fail(st);
-      else { n = nu; src = ctx->w_sorted[i & 1].as<psigpu_hit>(); ms_sort = ctx->last.ms_sort; }
+      else { n = nu; if (!in_place) src = ctx->w_sorted[i & 1].as<psigpu_hit>(); ms_sort = ctx->last.ms_sort; }
     }
     if (n) {
       // extrapolate from the reads seen so far when the reservation turns out too small
@@ -4082,6 +4106,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     acc.ms_pack += pc.ms_pack; acc.ms_table += pc.ms_table; acc.ms_search += pc.ms_search; acc.ms_locate += pc.ms_locate;
     acc.ms_traverse += pc.ms_traverse; acc.ms_probe += pc.ms_probe; acc.ms_total += pc.ms_total + ms_sort; acc.ms_sort += ms_sort;
     acc.search_launches += pc.search_launches; acc.traverse_launches += pc.traverse_launches;
+    acc.sorted_in_place += ctx->last.sorted_in_place;
   }
   if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }
   else if (hipStreamSynchronize(ctx->s_out) != hipSuccess) { ctx->err = "hipStreamSynchronize (copy-out stream)"; return fail(PSIGPU_ERR_DEVICE); }

@@ -72,6 +72,45 @@ k_hits_expand(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ n_
   dst[1] = make_ulonglong2(L.rec_offset + key, roff);
 }
 
+constexpr uint32_t GROUP_MAX = 32;
+
+// One thread per hit; the thread of the first hit of a group (hits of one seed: equal read id and read
+// offset) checks that the group follows the one before it, and orders the group by (node id, node offset).
+__global__ void __launch_bounds__(256)
+k_hits_fix_groups(psigpu_hit* __restrict__ hits, uint64_t n, uint64_t* __restrict__ flag)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ulonglong2 b = reinterpret_cast<const ulonglong2*>(hits + i)[1];        // (read_id, read_offset)
+  if (i) {
+    const ulonglong2 pb = reinterpret_cast<const ulonglong2*>(hits + i - 1)[1];
+    if (pb.x == b.x && pb.y == b.y) return;                                      // not the first of its group
+    if (pb.x > b.x || (pb.x == b.x && pb.y > b.y)) { *flag = 1; return; }
+  }
+  uint64_t j = i + 1;
+  while (j < n && j - i <= GROUP_MAX) {
+    const ulonglong2 nb = reinterpret_cast<const ulonglong2*>(hits + j)[1];
+    if (nb.x != b.x || nb.y != b.y) break;
+    ++j;
+  }
+  const uint32_t len = (uint32_t)(j - i);
+  if (len == 1) return;
+  if (len > GROUP_MAX) { *flag = 1; return; }
+  ulonglong2 a[GROUP_MAX];
+  bool moved = false;
+  for (uint32_t t = 0; t < len; ++t) {                                           // insertion sort
+    const ulonglong2 v = reinterpret_cast<const ulonglong2*>(hits + i + t)[0];   // (node_id, node_offset)
+    uint32_t p = t;
+    while (p && (a[p - 1].x > v.x || (a[p - 1].x == v.x && a[p - 1].y > v.y))) { a[p] = a[p - 1]; --p; }
+    a[p] = v;
+    moved = moved || p != t;
+  }
+  for (uint32_t t = 1; t < len; ++t)
+    if (a[t].x == a[t - 1].x && a[t].y == a[t - 1].y) { *flag = 1; return; }     // a duplicate: the general path drops it
+  if (moved)
+    for (uint32_t t = 0; t < len; ++t) reinterpret_cast<ulonglong2*>(hits + i + t)[0] = a[t];
+}
+
 inline uint32_t bits_for(uint64_t max_value)      // bits needed to hold 0..max_value (at least 1)
 {
   uint32_t b = 1;
@@ -92,6 +131,18 @@ bool HitSorter::fits(uint64_t n_reads, uint64_t max_read_len, uint64_t n_nodes, 
 {
   return bits_for(n_reads ? n_reads - 1 : 0) + bits_for(max_read_len) + bits_for(n_nodes ? n_nodes - 1 : 0) +
              bits_for(max_node_len) <= 64;
+}
+
+int HitSorter::fix_grouped(psigpu_hit* d_hits, uint64_t n, uint64_t* d_flag, void* stream_, std::string* err)
+{
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(d_flag, 0, 8, stream);
+  if (e == hipSuccess && n) {
+    k_hits_fix_groups<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_hits, n, d_flag);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) { *err = std::string("k_hits_fix_groups: ") + hipGetErrorString(e); return PSIGPU_ERR_DEVICE; }
+  return PSIGPU_OK;
 }
 
 int HitSorter::run(const psigpu_hit* d_in, uint64_t n, uint64_t rec_offset, uint64_t n_reads, uint64_t max_read_len,

@@ -111,6 +111,12 @@ struct HitSorter {
   int run(const psigpu_hit* d_in, uint64_t n, uint64_t rec_offset, uint64_t n_reads, uint64_t max_read_len,
           uint64_t n_nodes, uint64_t max_node_len, bool id_affine, uint64_t id_base, const uint64_t* d_ids_sorted,
           psigpu_hit* d_out, uint64_t* d_count, void* stream, std::string* err);
+  // Hits that come out seed by seed are in (read, read offset) order already: only the hits of one seed
+  // -- one or two, almost always -- can be out of order or equal.  Sorts every such group of up to 32 in
+  // place and leaves 0 in *d_flag when the array is then sorted and duplicate-free (the answer of run(),
+  // without the radix sort), non-zero when it is not (a longer group, a duplicate, hits not grouped by
+  // seed): the caller falls back to run().  Asynchronous on `stream`.
+  static int fix_grouped(psigpu_hit* d_hits, uint64_t n, uint64_t* d_flag, void* stream, std::string* err);
 };
 Index* load_index(const std::string& prefix, int* status);
 

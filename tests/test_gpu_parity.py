@@ -70,9 +70,55 @@ def test_golden(fname, npaths):
     su = f.seeds_all(reads, step=step, sort_unique=True)
     want = z['hits'][np.lexsort((z['hits'][:, 1], z['hits'][:, 0], z['hits'][:, 3], z['hits'][:, 2]))]
     assert _eq(su, want)
+    # ... by either route: ordering the hits of each seed in place, or the radix sort
+    os.environ['PSIGPU_NO_GROUPED_SORT'] = '1'
+    try:
+        su2 = f.seeds_all(reads, step=step, sort_unique=True)
+    finally:
+        os.environ.pop('PSIGPU_NO_GROUPED_SORT')
+    assert _eq(su2, want) and f.counters()['sorted_in_place'] == 0
     f.close()
 
 
+def test_sort_unique_in_place_and_fallback(query_mode):
+    """Hits come out seed by seed, so sort-unique is usually only the ordering of each seed's hits
+    (HitSorter::fix_grouped, counted in sorted_in_place); a seed with more than 32 hits, a duplicate, or
+    the traverser's unordered hits take the radix sort.  Same records either way."""
+    g, reads = _x_case()
+    k = 12
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(2, rng_seed=3, patched=True)
+    raw = f.seeds_all(reads[:500], step=5)
+    want = psi_amd.sort_unique(raw)
+    want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
+    su = f.seeds_all(reads[:500], step=5, sort_unique=True)
+    c = f.counters()
+    assert _eq(su, want)
+    if query_mode.startswith('traverse'):
+        assert c['sorted_in_place'] == 0
+    elif len(raw) == len(want):                       # no duplicate in the raw stream: nothing but group order to fix
+        assert c['sorted_in_place'] >= 1
+    f.close()
+    # a k-mer with more than 32 occurrences: the group is left to the radix sort
+    labels = [('ACGT' * 60), 'TTGACCA', ('ACGT' * 50)]
+    label_off = np.cumsum([0] + [len(x) for x in labels])
+    rg = psi_amd.Graph.from_csr([5, 6, 9], label_off, ''.join(labels).encode(), [0, 1, 2, 2], [1, 2], paths=[[0, 1, 2]])
+    f = psi_amd.SeedFinder(rg, k)
+    f.create_path_index(1)
+    rr = ['ACGTACGTACGTACGTAC', 'GACCAACGTACGTACGT', 'TTGACCAACGTAC']
+    raw = f.seeds_all(rr, step=2)
+    want = psi_amd.sort_unique(raw)
+    want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
+    su = f.seeds_all(rr, step=2, sort_unique=True)
+    assert len(raw) > 100 and _eq(su, want) and f.counters()['sorted_in_place'] == 0
+    # the last read alone has one hit per seed: in place
+    su = f.seeds_all(rr[2:], step=1, sort_unique=True)
+    in_place = f.counters()['sorted_in_place']
+    w1 = psi_amd.sort_unique(f.seeds_all(rr[2:], step=1))
+    assert _eq(su, w1[np.lexsort((w1[:, 1], w1[:, 0], w1[:, 3], w1[:, 2]))])
+    if not query_mode.startswith('traverse'):
+        assert in_place == 1
+    f.close()
 def test_traverser_truth_table():
     """test/src/test_traverser.cpp:81-82 through the GPU traverser (no path index)."""
     truth = [(1, 0), (1, 1), (9, 4), (9, 17), (16, 0), (17, 0), (20, 0), (20, 31), (20, 38), (20, 38)]
