@@ -140,6 +140,7 @@ struct DevCounters {
   PaddedCounter n_defer;         // seeds k_fm_search_direct left to the quad kernel
   PaddedCounter n_seeds_true;    // the scan's seed count (comes back to the host with the counters)
   StripedCounter max_read_len;   // longest read of the chunk, a running maximum per stripe (the hit sorter sizes its key fields with it)
+  PaddedCounter not_grouped;     // sort-unique asked for: set when ordering each seed's hits in place was not enough
   PaddedCounter dbg0, dbg1;      // diagnostics (builds with -DTRAV_STATS)
 };
 
@@ -2365,6 +2366,8 @@ struct psigpu_ctx {
   uint64_t max_node_len = 0;
   DevBuf ids_sorted;               // node ids in increasing order (only when they are not rank + id_base)
   HitSorter sorter;
+  int grouped_state = 0;           // last run_pipeline: 0 groups not looked at, 1 each seed's hits ordered in place and that
+                                   // makes the array sorted and duplicate-free, 2 it does not
   DevBuf w_sorted[2], w_count;
   // host entry point: sub-batches of a chunk pipelined through two slots (H2D | kernels | D2H)
   struct Slot {
@@ -3161,6 +3164,11 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
                         uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t rec_offset,
                         uint32_t flags, hipStream_t stream, uint64_t* n_hits_out)
 {
+  // PSIGPU_SORT_UNIQUE here: the caller will sort -- when the hits come out seed by seed, order each seed's
+  // hits in place before the counters go back, so that the answer to "was that enough?" comes with them
+  const bool want_sorted = (flags & PSIGPU_SORT_UNIQUE) != 0;
+  flags &= ~PSIGPU_SORT_UNIQUE;
+  ctx->grouped_state = 0;
   if (step == 0) step = k;                       // src/psikt.cpp:469
   if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..31)"; return PSIGPU_ERR_ARG; }
   if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
@@ -3525,9 +3533,16 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
                                                 &ctr->n_hits_tab.v, d_hits, cap);
       }
     }
+    const bool fix_groups = want_sorted && !off_paths && cap != 0;
+    if (fix_groups) {
+      EVREC(11, stream);
+      int fs = HitSorter::fix_grouped(d_hits, cap, &ctr->n_hits_tab.v, (uint64_t*)&ctr->not_grouped.v, stream, &ctx->err);
+      if (fs != PSIGPU_OK) return fs;
+    }
     EVREC(8, stream);
     k_publish<<<1, 256, 0, stream>>>(reinterpret_cast<const uint4*>(ctr), reinterpret_cast<uint4*>(ctx->h_pinned_dev), (uint32_t)(sizeof(DevCounters) / 16));
     HIPCHK(ctx, hipStreamSynchronize(stream));
+    ctx->grouped_state = fix_groups ? (h.not_grouped.v ? 2 : 1) : 0;
     true_seeds = h.n_seeds_true.v;
     ctx->last_max_read_len = 0;
     for (int i = 0; i < STRIPES; ++i) ctx->last_max_read_len = std::max<uint64_t>(ctx->last_max_read_len, h.max_read_len.s[i].v);
@@ -3558,9 +3573,10 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   pc.ms_search = on_paths ? ms(3, 10) : 0.f;          // K1
   // table probe + the scan of the per-wave totals
   pc.ms_probe = kprobe ? ms(1, 4) : (probe ? ms(10, 4) : 0.f);
-  pc.ms_locate = (on_paths || probe || kprobe) ? ((kprobe && !off_paths) ? ms(4, 8) : ms(4, 5)) : 0.f;
+  pc.ms_locate = (on_paths || probe || kprobe) ? ((kprobe && !off_paths) ? ms(4, ctx->grouped_state ? 11 : 8) : ms(4, 5)) : 0.f;
   pc.ms_traverse = off_paths ? ms(6, 7) : 0.f;        // runs beside K1/K2 on the second stream
   pc.ms_total = ms(0, 8);
+  if (ctx->grouped_state) { pc.ms_sort = ms(11, 8); pc.ms_total -= pc.ms_sort; }     // (added back by the caller with the sort's time)
   *n_hits_out = total_hits;
 
   return PSIGPU_OK;
@@ -3581,9 +3597,15 @@ static int device_sort_unique(psigpu_ctx* ctx, uint64_t n, uint64_t n_reads, uin
   uint64_t* h_n = reinterpret_cast<uint64_t*>((char*)ctx->h_pinned + sizeof(DevCounters) + 16);
   uint4* h_n_dev = reinterpret_cast<uint4*>((char*)ctx->h_pinned_dev + sizeof(DevCounters) + 16);
   const bool no_grouped = getenv("PSIGPU_NO_GROUPED_SORT") != nullptr;      // tests: always the general path
-  if (ctx->last.traverse_launches == 0 && !no_grouped) {       // (the traverser's hits are not grouped by seed)
+  if (ctx->grouped_state == 1 && !no_grouped) {                // run_pipeline ordered the groups, and that was all
+    ctx->last.n_hits = *n_out = n;
+    ctx->last.sorted_in_place = 1;
+    *in_place = true;
+    return PSIGPU_OK;
+  }
+  if (ctx->grouped_state == 0 && ctx->last.traverse_launches == 0 && !no_grouped) {       // (the traverser's hits are not grouped by seed)
     EVREC(11, stream);
-    int st = HitSorter::fix_grouped(ctx->w_hits.as<psigpu_hit>(), n, ctx->w_count.as<uint64_t>(), stream, &ctx->err);
+    int st = HitSorter::fix_grouped(ctx->w_hits.as<psigpu_hit>(), n, nullptr, ctx->w_count.as<uint64_t>(), stream, &ctx->err);
     if (st != PSIGPU_OK) return st;
     EVREC(0, stream);
     k_publish<<<1, 256, 0, stream>>>(ctx->w_count.as<uint4>(), h_n_dev, 1);
@@ -3625,8 +3647,7 @@ int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if ((flags & PSIGPU_ALL) == 0) flags |= PSIGPU_ALL;
   uint64_t n = 0;
-  int st = run_pipeline(ctx, d_bases, d_read_off, n_reads, n_bases, k, step, rec_offset, flags & ~PSIGPU_SORT_UNIQUE,
-                        (hipStream_t)stream, &n);
+  int st = run_pipeline(ctx, d_bases, d_read_off, n_reads, n_bases, k, step, rec_offset, flags, (hipStream_t)stream, &n);
   if (st != PSIGPU_OK) return st;
   *d_hits = ctx->w_hits.as<psigpu_hit>();
   *n_hits = n;
@@ -4060,7 +4081,8 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     uint64_t n = 0;
     if (trace) { tr.push_back(now_ms() - t_call); tmark(sc); }
     k_publish<<<64, 256, 0, sc>>>(reinterpret_cast<const uint4*>(sl.h_stage_dev), sl.off.as<uint4>(), (uint32_t)(((nr + 1) * 8 + 15) / 16));
-    int st = run_pipeline(ctx, sl.bases.as<char>(), sl.off.as<uint64_t>(), nr, nb, k, step, rec_offset + r0, flags, sc, &n);
+    int st = run_pipeline(ctx, sl.bases.as<char>(), sl.off.as<uint64_t>(), nr, nb, k, step, rec_offset + r0,
+                          flags | ((want_sort && !host_sort && getenv("PSIGPU_NO_GROUPED_SORT") == nullptr) ? PSIGPU_SORT_UNIQUE : 0u), sc, &n);
     if (st != PSIGPU_OK) return fail(st);
     if (trace) tr.push_back(now_ms() - t_call);
     consumed.store(i + 1, std::memory_order_release);

@@ -77,9 +77,11 @@ constexpr uint32_t GROUP_MAX = 32;
 // One thread per hit; the thread of the first hit of a group (hits of one seed: equal read id and read
 // offset) checks that the group follows the one before it, and orders the group by (node id, node offset).
 __global__ void __launch_bounds__(256)
-k_hits_fix_groups(psigpu_hit* __restrict__ hits, uint64_t n, uint64_t* __restrict__ flag)
+k_hits_fix_groups(psigpu_hit* __restrict__ hits, uint64_t n, const unsigned long long* __restrict__ n_ptr,
+                  uint64_t* __restrict__ flag)
 {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_ptr != nullptr) n = min((uint64_t)*n_ptr, n);          // the count is still on the device: n is the capacity
   if (i >= n) return;
   const ulonglong2 b = reinterpret_cast<const ulonglong2*>(hits + i)[1];        // (read_id, read_offset)
   if (i) {
@@ -133,12 +135,13 @@ bool HitSorter::fits(uint64_t n_reads, uint64_t max_read_len, uint64_t n_nodes, 
              bits_for(max_node_len) <= 64;
 }
 
-int HitSorter::fix_grouped(psigpu_hit* d_hits, uint64_t n, uint64_t* d_flag, void* stream_, std::string* err)
+int HitSorter::fix_grouped(psigpu_hit* d_hits, uint64_t n, const unsigned long long* d_n, uint64_t* d_flag, void* stream_,
+                           std::string* err)
 {
   hipStream_t stream = (hipStream_t)stream_;
-  hipError_t e = hipMemsetAsync(d_flag, 0, 8, stream);
+  hipError_t e = d_n ? hipSuccess : hipMemsetAsync(d_flag, 0, 8, stream);      // (with d_n: the caller's counters, zeroed with them)
   if (e == hipSuccess && n) {
-    k_hits_fix_groups<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_hits, n, d_flag);
+    k_hits_fix_groups<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(d_hits, n, d_n, d_flag);
     e = hipGetLastError();
   }
   if (e != hipSuccess) { *err = std::string("k_hits_fix_groups: ") + hipGetErrorString(e); return PSIGPU_ERR_DEVICE; }

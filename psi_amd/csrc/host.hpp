@@ -115,8 +115,10 @@ struct HitSorter {
   // -- one or two, almost always -- can be out of order or equal.  Sorts every such group of up to 32 in
   // place and leaves 0 in *d_flag when the array is then sorted and duplicate-free (the answer of run(),
   // without the radix sort), non-zero when it is not (a longer group, a duplicate, hits not grouped by
-  // seed): the caller falls back to run().  Asynchronous on `stream`.
-  static int fix_grouped(psigpu_hit* d_hits, uint64_t n, uint64_t* d_flag, void* stream, std::string* err);
+  // seed): the caller falls back to run().  Asynchronous on `stream`.  With `d_n` the number of hits is
+  // min(*d_n, n) (a count that is still on the device) and *d_flag is expected to be zero already.
+  static int fix_grouped(psigpu_hit* d_hits, uint64_t n, const unsigned long long* d_n, uint64_t* d_flag, void* stream,
+                         std::string* err);
 };
 Index* load_index(const std::string& prefix, int* status);
 
