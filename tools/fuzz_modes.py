@@ -81,6 +81,8 @@ def main():
                         raw = f.seeds_all(reads, step=step)
                         res.append(raw[np.lexsort(raw.T[::-1])])
                         f.close()
+                    if px.view.sa_rate != 1:       # (the one-part index is then answered by the FM modes, which emit every
+                        res = [psi_amd.sort_unique(r) for r in res]      # occurrence: compare the sets)
                     if not (res[0].shape == res[1].shape and (res[0] == res[1]).all()):
                         print('PARTS MISMATCH', seed, k, step, npaths, patched, cut, gocc, flush=True)
                         sys.exit(1)
