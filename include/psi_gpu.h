@@ -284,8 +284,11 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k);
 #define PSIGPU_OFF_PATHS 2u     /* SeedFinder::seeds_off_paths (seed_finder.hpp:1703-1722) */
 #define PSIGPU_ALL 3u           /* SeedFinder::seeds_all       (seed_finder.hpp:1724-1732) */
 #define PSIGPU_SORT_UNIQUE 4u   /* return sort-unique hits ordered by (read_id, read_offset,
-                                   node_id, node_offset) instead of the raw emission stream;
-                                   sorted on the device (64-bit packed keys, radix sort) */
+                                   node_id, node_offset) instead of the raw emission stream (which
+                                   may hold a hit more than once, like the reference's: a position
+                                   on several indexed paths, found on a path and from a locus);
+                                   done on the device: the hits of each seed ordered in place when
+                                   they come out seed by seed, else 64-bit packed keys + radix sort */
 
 /* One chunk of psikt's loop: get_seeds + index_reads + seeds_all (src/psikt.cpp:195-204).
  * `bases`/`read_off` are HOST buffers (read i = bases[read_off[i] .. read_off[i+1])),
@@ -331,7 +334,7 @@ void psigpu_host_free(void* p);
  * `d_read_off` are DEVICE pointers; `stream` is a hipStream_t (NULL = default stream).
  * On return *d_hits points at library-owned device memory holding *n_hits records, valid
  * until the next call on this context.  The call is asynchronous up to the final count
- * read-back (one stream synchronise; one more with PSIGPU_SORT_UNIQUE). */
+ * read-back (one stream synchronise; one more with PSIGPU_SORT_UNIQUE when the radix sort is needed). */
 int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off,
                              uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step,
                              uint64_t rec_offset, uint32_t flags, void* stream,
