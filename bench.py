@@ -469,6 +469,7 @@ def main():
             'raw_hits_ms_per_step': t_raw * 1e3, 'hits_per_step_raw': int(n_raw),
             'pageable_reads_ms_per_step': t_pg * 1e3,
             'device_ms_per_step': float(c_e['ms_total']), 'device_sort_ms_per_step': float(c_e['ms_sort']),
+            'sub_batches_sorted_in_place': int(c_e['sorted_in_place']),      # (of the last call: no radix sort needed)
             'roofline': {'bound': 'pcie', 'achieved': max(bytes_in, bytes_out) / t_su / 1e9, 'peak': PCIE_PEAK_GBS,
                          'unit': 'GB/s', 'frac': pcie_bound_ms / (t_su * 1e3), 'bytes_in': bytes_in, 'bytes_out': bytes_out,
                          'note': 'full duplex: the bound is max(bytes in, bytes out) / one-direction rate'},
