@@ -1,5 +1,5 @@
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, psi_amd
 from psi_amd import synth
 sg = synth.snv_graph(51_000_000, 1_100_000, n_block=11_000_000, seed=11)
