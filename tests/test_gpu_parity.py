@@ -516,7 +516,7 @@ def test_properties_at_scale():
 @pytest.mark.parametrize('query_mode', ['kmer-table'], indirect=True)
 def test_query_modes_agree_at_full_size(query_mode):
     """BASELINE.json configs[1] at full size (51 Mbp, 1.1 M SNVs, 1 M x 150 bp reads, k = 21): the
-    three query modes return the same 8.28 M records, every seed is found where it was sampled."""
+    three query modes return the same 7.0 M sort-unique records, every seed is found where it was sampled."""
     k = 21
     sg = synth.snv_graph(51_000_000, 1_100_000, n_block=11_000_000, seed=11)
     g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to,
