@@ -2859,10 +2859,21 @@ static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, u
   HIPCHK(ctx, hipMemcpy(h, d_cnt, 24, hipMemcpyDeviceToHost));
   const uint64_t n_ext = h[0], n_on = h[1], n_pos = h[2];
   if (n_ext >= 0xFFFFFFF0ull || n_pos >= 0xFFFFFFF0ull) return PSIGPU_ERR_NOMEM;
-  // slots: load 0.5 when there is room, down to 0.85 when there is not
+  // slots: the probe is fastest at a load of 1/6 or less (chr22-like: 0.235 ms against 0.255 at load 0.5 --
+  // fewer second looks; 1/8 and 1/16 are no faster), so a table that stays small beside the free memory
+  // gets 6x (4x, 3x) the k-mers; otherwise load 0.5 when there is room, down to 0.85 when there is not
   uint64_t slots = 0;
   hipError_t e = hipErrorOutOfMemory;
-  for (uint64_t pct : { 200ull, 160ull, 133ull, 118ull }) {
+  std::vector<uint64_t> pcts;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    if (const char* ev = getenv("PSIGPU_KT_PCT")) pcts.push_back(std::max<uint64_t>(101, strtoull(ev, nullptr, 10)));      // (experiments)
+    for (uint64_t pct : { 600ull, 400ull, 300ull })
+      if ((n_on + n_off) * pct / 100 * sizeof(Slot16) <= free_b / 4) pcts.push_back(pct);
+    for (uint64_t pct : { 200ull, 160ull, 133ull, 118ull }) pcts.push_back(pct);
+  }
+  for (uint64_t pct : pcts) {
     slots = std::max<uint64_t>(1024, (n_on + n_off) * pct / 100);      // (an upper bound on the distinct k-mers)
     e = ctx->kt_ht.ensure(slots * sizeof(Slot16));
     if (e == hipSuccess) e = ctx->kt_ext.ensure((n_ext + 1) * sizeof(KmerSlot));
