@@ -1065,7 +1065,18 @@ constexpr uint32_t RES_INLINE = 0x80000000u, RES_EXT = 0x40000000u, RES_CNT = 0x
 // any number of slots (the whole-genome table has to fit): slot = hash * n_slots / 2^64
 struct KmerTableView { const Slot16* ht; uint64_t n_slots; const KmerSlot* ext; };
 __device__ __forceinline__ uint64_t kt_home(uint64_t key, uint64_t n_slots) { return __umul64hi(mix64(key), n_slots); }
-__device__ __forceinline__ uint64_t kt_next(uint64_t h, uint64_t n_slots) { return h + 1 < n_slots ? h + 1 : 0; }
+// Probe sequence: the four slots of the home slot's 64-byte sector first (cyclically, from the home slot),
+// then the next sector's in the same order, and so on -- a second or third look costs no second sector
+// (n_slots is a multiple of 4; t counts the looks so far).
+__device__ __forceinline__ uint64_t kt_next(uint64_t h, uint32_t& t, uint64_t n_slots)
+{
+  ++t;
+  const uint64_t in_sector = (h + 1) & 3ull;
+  if (t & 3u) return (h & ~3ull) | in_sector;
+  uint64_t b = (h & ~3ull) + 4;
+  if (b >= n_slots) b = 0;
+  return b | in_sector;
+}
 
 __device__ __forceinline__ uint64_t slot16_type(const KmerSlot& r)
 {
@@ -1142,10 +1153,11 @@ __device__ __forceinline__ void kt_place(Slot16* __restrict__ ht, uint64_t n_slo
 {
   const unsigned long long payload = (unsigned long long)a | ((unsigned long long)b << 32);
   uint64_t h = kt_home(key, n_slots);
+  uint32_t t = 0;
   while (true) {
     unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&ht[h].a), ~0ull, payload);
     if (prev == ~0ull) { ht[h].kt = key | (type << 62); return; }
-    h = kt_next(h, n_slots);
+    h = kt_next(h, t, n_slots);
   }
 }
 
@@ -1324,6 +1336,7 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
     uint4 res = make_uint4(0, 0, 0, 0);
     if (key != KEY_INVALID) {
       uint64_t h = kt_home(key, kt.n_slots);
+      uint32_t t = 0;
       while (true) {
         const uint4 v = *reinterpret_cast<const uint4*>(kt.ht + h);
         const uint64_t w = (uint64_t)v.x | ((uint64_t)v.y << 32);
@@ -1346,7 +1359,7 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
           break;
         }
         if (empty) break;
-        h = kt_next(h, kt.n_slots);
+        h = kt_next(h, t, kt.n_slots);
       }
     }
     seed_res[seed] = res;
@@ -2859,9 +2872,10 @@ static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, u
   HIPCHK(ctx, hipMemcpy(h, d_cnt, 24, hipMemcpyDeviceToHost));
   const uint64_t n_ext = h[0], n_on = h[1], n_pos = h[2];
   if (n_ext >= 0xFFFFFFF0ull || n_pos >= 0xFFFFFFF0ull) return PSIGPU_ERR_NOMEM;
-  // slots: the probe is fastest at a load of 1/6 or less (chr22-like: 0.235 ms against 0.255 at load 0.5 --
-  // fewer second looks; 1/8 and 1/16 are no faster), so a table that stays small beside the free memory
-  // gets 6x (4x, 3x) the k-mers; otherwise load 0.5 when there is room, down to 0.85 when there is not
+  // slots: with looks that stay inside a sector (kt_next) the probe is as fast at load 1/3 as at 1/6 or 1/16
+  // (chr22-like, one box, medians of three: 0.237 ms; 0.246 at load 0.5; 0.251 at 0.5 with plain linear
+  // probing), so a table that stays small beside the free memory gets 3x the k-mers; otherwise load 0.5
+  // when there is room, down to 0.85 when there is not
   uint64_t slots = 0;
   hipError_t e = hipErrorOutOfMemory;
   std::vector<uint64_t> pcts;
@@ -2869,12 +2883,11 @@ static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, u
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
     if (const char* ev = getenv("PSIGPU_KT_PCT")) pcts.push_back(std::max<uint64_t>(101, strtoull(ev, nullptr, 10)));      // (experiments)
-    for (uint64_t pct : { 600ull, 400ull, 300ull })
-      if ((n_on + n_off) * pct / 100 * sizeof(Slot16) <= free_b / 4) pcts.push_back(pct);
+    if ((n_on + n_off) * 3 * sizeof(Slot16) <= free_b / 4) pcts.push_back(300);
     for (uint64_t pct : { 200ull, 160ull, 133ull, 118ull }) pcts.push_back(pct);
   }
   for (uint64_t pct : pcts) {
-    slots = std::max<uint64_t>(1024, (n_on + n_off) * pct / 100);      // (an upper bound on the distinct k-mers)
+    slots = (std::max<uint64_t>(1024, (n_on + n_off) * pct / 100) + 3) & ~3ull;      // (an upper bound on the distinct k-mers; whole sectors)
     e = ctx->kt_ht.ensure(slots * sizeof(Slot16));
     if (e == hipSuccess) e = ctx->kt_ext.ensure((n_ext + 1) * sizeof(KmerSlot));
     if (e == hipSuccess) e = ctx->kt_onpos.ensure((n_pos + 1) * sizeof(uint2));
