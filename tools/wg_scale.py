@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--nblock', type=int, default=150_000_000)
     ap.add_argument('--reads', type=int, default=10_000_000)
     ap.add_argument('--k', type=int, default=21)
+    ap.add_argument('--host-entry', action='store_true', help='also run the chunk through psigpu_find_seeds and compare')
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--paths', type=int, default=1, help='walks per region (psikt -n)')
     ap.add_argument('--patched', action='store_true', help="psikt's default indexing mode")
@@ -89,6 +90,36 @@ def main():
     first = labels[lo[rank] + hits[:200000, 1].astype(np.int64)]
     seed_first = bases[(hits[:200000, 2] * np.uint64(150) + hits[:200000, 3]).astype(np.int64)]
     out['first_base_agrees'] = bool((first == seed_first).all())
+    if args.host_entry:
+        # the same chunk through the host entry point (pageable reads staged by the helper thread, ~100
+        # sub-batches, sort-unique on the device, 2+ GB of records into pinned host memory): same records
+        want = psi_amd.sort_unique(hits)
+        want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
+        del hits, found
+        t = time.perf_counter()
+        su = f.seeds_all((bases, off), step=args.k, sort_unique=True)
+        out['host_entry_first_call_ms'] = (time.perf_counter() - t) * 1e3       # (cold pinned pool: 2+ GB of hipHostMalloc)
+        out['host_entry_records'] = int(len(su))
+        import ctypes as C
+        pin = (psi_amd.pinned_copy(bases), psi_amd.pinned_copy(off.astype(np.uint64)))
+        h = psi_amd.Hits()
+        L = psi_amd.lib()
+        call = (f.ctx, psi_amd._ptr(pin[0].array), psi_amd._ptr(pin[1].array), args.reads, args.k, args.k, 0,
+                psi_amd.ALL | psi_amd.SORT_UNIQUE, C.byref(h))
+        ts = []
+        for _ in range(3):                        # reads in pinned memory, records left in the library's pinned buffer
+            t = time.perf_counter()
+            assert L.psigpu_find_seeds(*call) == 0
+            ts.append((time.perf_counter() - t) * 1e3)
+            n_rec = h.n
+            L.psigpu_free_hits(C.byref(h))
+        out['host_entry_ms'] = min(ts)
+        out['host_entry_ms_all'] = ts
+        out['host_entry_seeds_per_s'] = args.reads * per_read / (min(ts) * 1e-3)
+        assert n_rec == len(su)
+        out['host_entry_equals_device_entry'] = bool(su.shape == want.shape and (su == want).all())
+        out['host_entry_sub_batches_sorted_in_place'] = int(f.counters()['sorted_in_place'])
+        log('host entry %.0f ms (first call %.0f), %d records, equal: %s' % (out['host_entry_ms'], out['host_entry_first_call_ms'], len(su), out['host_entry_equals_device_entry']))
     f.close()
     print(json.dumps(out), flush=True)
 
