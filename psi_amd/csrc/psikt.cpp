@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <future>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -267,6 +268,9 @@ double seconds_since( std::chrono::steady_clock::time_point t0 )
 
 int run( Options const& o, Logger& log )
 {
+  /* the HIP runtime takes a few hundred milliseconds to come up: let it do so while the graph file is parsed */
+  std::thread warm( [] { void* p = psigpu_host_alloc( 4096 ); if ( p != nullptr ) psigpu_host_free( p ); } );
+  struct Joiner { std::thread& t; ~Joiner() { if ( t.joinable() ) t.join(); } } warm_guard{ warm };
   log.info( "Loading input graph from file '" + o.graph_path + "'..." );
   Graph graph( o.graph_path );
   log.info( "Number of nodes: " + std::to_string( graph.get_node_count() ) + ", edges: " +
@@ -278,8 +282,14 @@ int run( Options const& o, Logger& log )
   if ( out == nullptr ) throw std::runtime_error( "cannot open file '" + o.output_path + "'" );
 
   typedef SeedFinder< NoStats > finder_type;
+  warm.join();
   finder_type finder( graph, o.seed_len, o.gocc_threshold, o.max_mem, o.devices[ 0 ] );
   finder.set_query_mode( o.query_mode );
+  /* the first chunk of reads is parsed (into page-locked memory) while the index is loaded or made */
+  auto chunk = finder.create_readrecord();
+  std::future< bool > first_chunk;
+  if ( !o.indexonly )
+    first_chunk = std::async( std::launch::async, [ & ] { return readRecords( chunk, reads_iss, o.chunk_size ); } );
   log.info( "Looking for an existing path index..." );
   auto t0 = std::chrono::steady_clock::now();
   if ( finder.load_path_index( o.pindex_path, o.context, o.step_size, o.dindex_min_ris, o.dindex_max_ris ) ) {
@@ -326,7 +336,6 @@ int run( Options const& o, Logger& log )
   }
   if ( !more.empty() ) log.info( "Index copied to " + std::to_string( o.devices.size() ) + " devices." );
 
-  auto chunk = finder.create_readrecord();
   SeedsRecord seeds;
   auto traverser = finder.create_traverser();
   log.info( "Finding seeds..." );
@@ -335,7 +344,7 @@ int run( Options const& o, Logger& log )
   while ( true ) {
     log.info( "Loading a read chunk..." );
     auto t_load = std::chrono::steady_clock::now();
-    if ( !readRecords( chunk, reads_iss, o.chunk_size ) ) break;
+    if ( !( first_chunk.valid() ? first_chunk.get() : readRecords( chunk, reads_iss, o.chunk_size ) ) ) break;
     log.info( "Fetched " + std::to_string( chunk.size() ) + " reads with total length of " +
               std::to_string( chunk.length_sum() ) + "bp in " + std::to_string( seconds_since( t_load ) ) + " s." );
     finder.get_seeds( seeds, chunk, o.distance );
