@@ -2,6 +2,7 @@
 // include/psi_gpu.h for what each one replaces in the reference.
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -132,7 +133,11 @@ psigpu_index* psigpu_index_build(const psigpu_graph* g, const psigpu_index_opts*
   else if (o.context == 0) o.context = o.seed_len;
   std::vector<std::vector<uint32_t>> paths;
   std::vector<uint32_t> head, tail;
+  const auto t_pick = std::chrono::steady_clock::now();
   pick_paths(g->g, o.n_per_region, o.patched != 0, o.context, o.rng_seed, paths, head, tail);
+  if (getenv("PSIGPU_TRACE"))
+    fprintf(stderr, "[psigpu] index build: path picking %.2f s (%zu paths / patches)\n",
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pick).count(), paths.size());
   int st; std::string err;
   Index* x = build_index(g->g, o, paths, head, tail, &st, &err);
   return wrap_index(x, st, err, status);

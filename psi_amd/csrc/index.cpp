@@ -10,6 +10,7 @@
 // The data layout produced here is this library's own; results are compared
 // with the reference as hit SETS, never as suffix-array coordinates.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -469,6 +470,14 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
     cuts.push_back(paths.size());
   }
   const size_t n_parts = cuts.size() - 1;
+  const bool trace = getenv("PSIGPU_TRACE") != nullptr;
+  auto t_mark = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[psigpu] index build: %s %.2f s\n", what, std::chrono::duration<double>(now - t_mark).count());
+    t_mark = now;
+  };
   if (n_parts > 1 && (sa_rate != 1 || keep)) {
     *status = PSIGPU_ERR_ARG; *err = "an index in several parts needs sa_rate 1 (and cannot keep its text)"; delete x; return nullptr;
   }
@@ -484,6 +493,7 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
     }
   }
 
+  lap("text, suffix array and tables of the parts");
   // the device routine tracks coverage with one bit per path: full, simple (no node twice) paths, at most 64
   bool bits_suffice = !trimmed && paths.size() <= 64;
   if (bits_suffice && opts.build_on_device) {
@@ -500,6 +510,7 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
   } else {
     find_starting_loci(g, paths, x->path_head, x->path_tail, k, step, x->loci_node, x->loci_off);
   }
+  lap("starting loci");
   *status = PSIGPU_OK;
   return x;
 }

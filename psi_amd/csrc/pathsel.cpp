@@ -36,11 +36,29 @@ constexpr uint32_t END = 0xFFFFFFFFu;
 // has no other node between q's first and last rank -- q is a contiguous run of the walk.
 struct Walk {
   std::vector<uint32_t> sorted;       // node ranks, increasing
+  std::vector<uint64_t> bits;         // the same set as a bit per node (the reference's Haplotype path is a bit vector too)
+  bool bit(uint32_t v) const { return (bits[v >> 6] >> (v & 63)) & 1ull; }
   bool contains(const uint32_t* q, size_t n) const
   {
     if (n == 0) return false;
     const uint32_t b = q[0], e = q[n - 1];
     if (e < b) return false;
+    if (!bits.empty() && e - b < 4096) {
+      // the usual case, ranks close together: q is the walk's node set in [b, e] iff its ranks increase, all
+      // lie on the walk and the walk has exactly n nodes there -- no binary search over a 300 M-node walk
+      if (!bit(b) || !bit(e)) return false;
+      for (size_t i = 1; i < n; ++i)
+        if (q[i] <= q[i - 1] || !bit(q[i])) return false;
+      uint64_t cnt = 0;
+      const uint32_t wb = b >> 6, we = e >> 6;
+      for (uint32_t w = wb; w <= we; ++w) {
+        uint64_t x = bits[w];
+        if (w == wb) x &= ~0ull << (b & 63);
+        if (w == we) x &= ~0ull >> (63 - (e & 63));
+        cnt += (uint64_t)__builtin_popcountll(x);
+      }
+      return cnt == n;
+    }
     auto lo = std::lower_bound(sorted.begin(), sorted.end(), b);
     auto hi = std::upper_bound(sorted.begin(), sorted.end(), e);
     if (lo == sorted.end() || *lo != b || (size_t)(hi - lo) != n) return false;
@@ -115,6 +133,8 @@ public:
     w.sorted = current_;
     std::sort(w.sorted.begin(), w.sorted.end());
     w.sorted.erase(std::unique(w.sorted.begin(), w.sorted.end()), w.sorted.end());
+    w.bits.assign((g_.n_nodes() >> 6) + 1, 0);
+    for (uint32_t v : w.sorted) w.bits[v >> 6] |= 1ull << (v & 63);
     visited_.push_back(std::move(w));
     setback_ = (unsigned)visited_.size();
     rewind();
@@ -181,7 +201,8 @@ struct Patch { size_t first, last; uint32_t head, tail; };      // nodes walk[fi
 
 // maximal runs of `context`-base windows of `walk` whose node sequence none of `earlier` contains
 std::vector<Patch> cut_patches(const Graph& g, const std::vector<uint32_t>& walk,
-                               const std::vector<std::vector<uint32_t>>& earlier, uint32_t context)
+                               const std::vector<std::vector<uint32_t>>& earlier, uint32_t context,
+                               std::vector<uint32_t>& at /* one entry per node, all NO_NODE; left so */)
 {
   const size_t m = walk.size();
   std::vector<Patch> out;
@@ -193,16 +214,16 @@ std::vector<Patch> cut_patches(const Graph& g, const std::vector<uint32_t>& walk
   // run[i]: the longest j - i + 1 such that walk[i..j] is a contiguous run of some earlier walk
   std::vector<uint32_t> run(m, 0), cur(m, 0);
   for (const auto& V : earlier) {
-    std::unordered_map<uint32_t, uint32_t> at;      // node -> its (first) position in V
-    at.reserve(V.size() * 2);
-    for (uint32_t q = 0; q < V.size(); ++q) at.emplace(V[q], q);
+    // node -> its (first) position in V: a plain array over the nodes (a hash map of a whole-genome walk's
+    // 300 M nodes took longer than everything else in the index build)
+    for (size_t q = V.size(); q-- > 0;) at[V[q]] = (uint32_t)q;
     for (size_t i = m; i-- > 0;) {
-      auto it = at.find(walk[i]);
-      if (it == at.end()) { cur[i] = 0; continue; }
-      const uint32_t q = it->second;
-      cur[i] = (i + 1 < m && q + 1 < V.size() && V[q + 1] == walk[i + 1] && cur[i + 1]) ? cur[i + 1] + 1 : 1;
+      const uint32_t q = at[walk[i]];
+      if (q == NO_NODE) { cur[i] = 0; continue; }
+      cur[i] = (i + 1 < m && (size_t)q + 1 < V.size() && V[q + 1] == walk[i + 1] && cur[i + 1]) ? cur[i + 1] + 1 : 1;
       run[i] = std::max(run[i], cur[i]);
     }
+    for (uint32_t v : V) at[v] = NO_NODE;
   }
   // Windows start at x in [0, x_max]; the one starting in node i at x ends in the node holding base
   // x + c - 1, and is uncovered iff that node lies behind walk[i + run[i] - 1]
@@ -245,10 +266,12 @@ void pick_paths(const Graph& g, uint32_t n_per_region, bool patched, uint32_t co
   out.clear(); head.clear(); tail.clear();
   if (n_per_region == 0) return;
   Haplotyper hp(g, rng_seed);
+  std::vector<uint32_t> at;                        // cut_patches' node -> position array, made on first use
   for (size_t r = 0; r < g.paths.size(); ++r) {
     if (g.paths[r].empty()) continue;
     hp.reset(g.paths[r][0]);                       // the region's walks start where its embedded path starts (:1159-1160)
     std::vector<std::vector<uint32_t>> walks;      // this region's walks so far (whole, also when patches are kept)
+    if (patched && n_per_region > 1 && at.empty()) at.assign(g.n_nodes(), NO_NODE);
     for (uint32_t i = 0; i < n_per_region; ++i) {
       std::vector<uint32_t> walk = full_walk(g, hp);
       hp.save();
@@ -256,7 +279,7 @@ void pick_paths(const Graph& g, uint32_t n_per_region, bool patched, uint32_t co
       if (!patched || walks.empty()) {             // get_uniq_patched_haplotype: level 0 gives a full haplotype (:568-571)
         out.push_back(walk); head.push_back(0); tail.push_back(0);
       } else {
-        for (const Patch& p : cut_patches(g, walk, walks, context)) {
+        for (const Patch& p : cut_patches(g, walk, walks, context, at)) {
           out.emplace_back(walk.begin() + p.first, walk.begin() + p.last + 1);
           head.push_back(p.head); tail.push_back(p.tail);
         }
