@@ -2338,6 +2338,7 @@ struct psigpu_ctx {
   bool have_saloc = false;
   DevBuf sarec;                    // per-row records for seed length sarec_k (sa_rate 1, interval table, text resident)
   uint32_t sarec_k = 0;
+  bool rows_tried = false;         // build_row_records has run for this index (the records exist, or do not fit / apply)
   bool id_affine = false;          // external node id = rank + id_base
   uint64_t id_base = 0;
   DevBuf blocks, samples, exc_row, exc_sa, seg, seg_dir, loci;
@@ -2774,7 +2775,10 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
   }
   ctx->index_k = x->seed_len; ctx->sa_rate = x->sa_rate; ctx->context = x->context;
   ctx->n_paths = x->n_paths; ctx->text_len = x->text_len; ctx->n_exc = x->n_exc; ctx->n_segs = x->n_segs;
-  if ((st = build_row_records(ctx, x->seed_len))) return st;
+  // (the per-row records of the FM modes are made when an FM mode first answers a chunk: the default mode
+  // never reads them, and at whole-genome size they are 70 GB)
+  ctx->sarec.release(); ctx->saloc.release();
+  ctx->sarec_k = 0; ctx->have_saloc = false; ctx->rows_tried = false;
   ctx->index_k = x->seed_len; ctx->sa_rate = x->sa_rate; ctx->context = x->context;
   ctx->n_paths = x->n_paths; ctx->text_len = x->text_len; ctx->n_exc = x->n_exc;
   ctx->n_loci = x->n_loci;
@@ -3137,15 +3141,13 @@ static int ensure_lkt(psigpu_ctx* ctx, uint32_t k, const GraphView& gv)
       (void)hipGetLastError();
       ctx->kt_ht.release(); ctx->kt_ext.release();
       const bool had_rows = ctx->sarec_k != 0 || ctx->have_saloc;
-      const uint32_t sarec_k_was = ctx->sarec_k ? ctx->sarec_k : ctx->index_k;
       ctx->sarec.release(); ctx->saloc.release();
-      ctx->sarec_k = 0; ctx->have_saloc = false;
+      ctx->sarec_k = 0; ctx->have_saloc = false; ctx->rows_tried = false;
       st = had_rows ? build_kt_direct(ctx, k, sorted_keys, sorted_vals, n_ent, d_dropped) : PSIGPU_ERR_NOMEM;
       if (st == PSIGPU_ERR_NOMEM) {
         (void)hipGetLastError();
         ctx->kt_ht.release(); ctx->kt_ext.release();
         ctx->lkt_note = "k-mer table does not fit the device: path k-mers stay with the FM index";
-        if (had_rows) { int rs = build_row_records(ctx, sarec_k_was); if (rs != PSIGPU_OK) return rs; }
         st = PSIGPU_OK;
       }
     }
@@ -3247,6 +3249,13 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     use_lkt = ctx->lkt_ready && want_off;
     use_kt = ctx->lkt_ready && ctx->kt_ready;
     if (!had) EVREC(0, stream);      // a table build just ended: do not time it
+  }
+  // the per-row records of the FM search / locate kernels, the first time an FM mode answers on-path seeds
+  if (!use_kt && n_reads && (flags & PSIGPU_ON_PATHS) && ctx->n_paths && ctx->fm_ok && ctx->more.empty() && !ctx->rows_tried) {
+    int st = build_row_records(ctx, ctx->index_k);
+    if (st != PSIGPU_OK) return st;
+    ctx->rows_tried = true;
+    EVREC(0, stream);
   }
   if ((!ctx->more.empty() || !ctx->fm_ok) && n_reads && (flags & PSIGPU_ON_PATHS) && ctx->n_paths && !use_kt) {
     ctx->err = ctx->query_mode != PSIGPU_MODE_KMER_TABLE || ctx->index_k != k
@@ -3780,10 +3789,17 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k)
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..31)"; return PSIGPU_ERR_ARG; }
   if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
-  if (ctx->query_mode == PSIGPU_MODE_TRAVERSE) return PSIGPU_OK;          // nothing is tabulated in this mode
   if (ctx->index_k != k) return PSIGPU_OK;                                // tables exist for the index's seed length only
-  if (ctx->n_loci == 0 && !(ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->n_paths)) return PSIGPU_OK;
-  return ensure_lkt(ctx, k, graph_view(ctx));
+  int st = PSIGPU_OK;
+  if (ctx->query_mode != PSIGPU_MODE_TRAVERSE &&                           // (nothing is tabulated in traverse mode)
+      !(ctx->n_loci == 0 && !(ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->n_paths)))
+    st = ensure_lkt(ctx, k, graph_view(ctx));
+  // the FM modes' per-row records (the k-mer table mode never reads them)
+  if (st == PSIGPU_OK && !(ctx->lkt_ready && ctx->kt_ready) && ctx->n_paths && ctx->fm_ok && ctx->more.empty() && !ctx->rows_tried) {
+    st = build_row_records(ctx, ctx->index_k);
+    ctx->rows_tried = st == PSIGPU_OK;
+  }
+  return st;
 }
 
 void* psigpu_host_alloc(uint64_t bytes)
