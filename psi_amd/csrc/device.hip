@@ -2691,11 +2691,16 @@ static int upload_segments(psigpu_ctx* ctx, const psigpu_index_view* x, const st
                            DevBuf& seg_dir, DevBuf& seg_rank)
 {
   std::vector<SegRec> segs(x->n_segs + 1);
-  for (uint64_t i = 0; i < x->n_segs; ++i) {
-    uint32_t v = x->seg_node[i];
-    if (v != NO_NODE && v >= ctx->n_nodes) { ctx->err = "index does not belong to this graph"; return PSIGPU_ERR_ARG; }
-    segs[i] = SegRec{ x->seg_start[i], x->seg_noff[i], v == NO_NODE ? 0 : ids[v] };
-  }
+  std::atomic<bool> foreign{ false };
+  const uint64_t n_nodes = ctx->n_nodes;
+  parallel_for(x->n_segs, 1u << 16, [&](uint64_t i0, uint64_t i1) {      // (300 M segments at whole-genome size)
+    for (uint64_t i = i0; i < i1; ++i) {
+      uint32_t v = x->seg_node[i];
+      if (v != NO_NODE && v >= n_nodes) { foreign = true; v = NO_NODE; }
+      segs[i] = SegRec{ x->seg_start[i], x->seg_noff[i], v == NO_NODE ? 0 : ids[v] };
+    }
+  });
+  if (foreign) { ctx->err = "index does not belong to this graph"; return PSIGPU_ERR_ARG; }
   segs[x->n_segs] = SegRec{ x->seg_start[x->n_segs], 0, 0 };
   int st;
   if ((st = upload(ctx, seg, segs.data(), segs.size(), 1))) return st;
@@ -2722,13 +2727,23 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
     return PSIGPU_ERR_ARG;
   }
   if (!ctx->have_graph) { ctx->err = "load the graph before the index"; return PSIGPU_ERR_STATE; }
-  for (uint64_t i = 0; i < x->n_loci; ++i)
-    if (x->loci_node[i] >= ctx->n_nodes || x->loci_off[i] >= ctx->max_node_len) {
-      ctx->err = "starting locus outside the graph: the index does not belong to this graph";
-      return PSIGPU_ERR_ARG;
-    }
-  for (uint64_t i = 0; i < x->n_dir; ++i)
-    if (x->seg_dir[i] >= x->n_segs + (x->n_segs == 0)) { ctx->err = "inconsistent index view"; return PSIGPU_ERR_ARG; }
+  {
+    std::atomic<bool> bad_locus{ false }, bad_dir{ false };
+    const uint64_t n_nodes = ctx->n_nodes, max_len = ctx->max_node_len;
+    parallel_for(x->n_loci, 1u << 16, [&](uint64_t i0, uint64_t i1) {       // (1.3 G loci at whole-genome size)
+      bool bad = false;
+      for (uint64_t i = i0; i < i1; ++i) bad = bad || x->loci_node[i] >= n_nodes || x->loci_off[i] >= max_len;
+      if (bad) bad_locus = true;
+    });
+    if (bad_locus) { ctx->err = "starting locus outside the graph: the index does not belong to this graph"; return PSIGPU_ERR_ARG; }
+    const uint64_t seg_lim = x->n_segs + (x->n_segs == 0);
+    parallel_for(x->n_dir, 1u << 16, [&](uint64_t i0, uint64_t i1) {
+      bool bad = false;
+      for (uint64_t i = i0; i < i1; ++i) bad = bad || x->seg_dir[i] >= seg_lim;
+      if (bad) bad_dir = true;
+    });
+    if (bad_dir) { ctx->err = "inconsistent index view"; return PSIGPU_ERR_ARG; }
+  }
   int st;
   ctx->fm_ok = fm_ok;
   if ((st = upload(ctx, ctx->blocks, (const RankBlock*)x->bwt_blocks, fm_ok ? x->n_blocks : 0, 1))) return st;
@@ -2769,9 +2784,14 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
     if ((st = upload_segments(ctx, m, ids, fp.seg, fp.seg_dir, fp.seg_rank))) return st;
   }
   {
-    std::vector<uint2> lc(x->n_loci);
-    for (uint64_t i = 0; i < x->n_loci; ++i) lc[i] = make_uint2(x->loci_node[i], x->loci_off[i]);
-    if ((st = upload(ctx, ctx->loci, lc.data(), x->n_loci, 1))) return st;
+    // (pages first touched by the threads that fill them: 10 GB at whole-genome size)
+    std::unique_ptr<uint2, void (*)(void*)> lc((uint2*)malloc((x->n_loci + 1) * sizeof(uint2)), free);
+    if (!lc) { ctx->err = "out of host memory"; return PSIGPU_ERR_NOMEM; }
+    uint2* lcp = lc.get();
+    parallel_for(x->n_loci, 1u << 16, [&](uint64_t i0, uint64_t i1) {
+      for (uint64_t i = i0; i < i1; ++i) lcp[i] = make_uint2(x->loci_node[i], x->loci_off[i]);
+    });
+    if ((st = upload(ctx, ctx->loci, lcp, x->n_loci, 1))) return st;
   }
   ctx->index_k = x->seed_len; ctx->sa_rate = x->sa_rate; ctx->context = x->context;
   ctx->n_paths = x->n_paths; ctx->text_len = x->text_len; ctx->n_exc = x->n_exc; ctx->n_segs = x->n_segs;
