@@ -482,6 +482,12 @@ class SeedFinder:
         if st:
             raise PsiGpuError('psigpu error %d: %s' % (st, lib().psigpu_last_error(self.ctx).decode()))
 
+    def set_gocc_threshold(self, thr: int) -> None:
+        """SeedFinder gocc_threshold (seed_finder.hpp:939): on-path k-mers with more than `thr` occurrences
+        in the path text are skipped; 0 = unlimited.  May be changed at any time (a k-mer table built
+        without a threshold is rebuilt by the next query)."""
+        self._chk(lib().psigpu_set_gocc_threshold(self.ctx, thr))
+
     # -- index ------------------------------------------------------------------------
     def create_path_index(self, n: int, patched: bool = False, context: int = 0, step_size: int = 1,
                           sa_rate: int = 0, rng_seed: int = 0, ftab_len: int = 0,

@@ -453,6 +453,77 @@ def test_gocc_threshold_vs_oracle():
     f.close()
 
 
+def _graph_arrays(g):
+    return (np.asarray(g.node_id), np.asarray(g.label_off), np.frombuffer(bytes(g.labels), np.uint8),
+            np.asarray(g.edge_off), np.asarray(g.edge_to))
+
+
+@pytest.mark.parametrize('k,npaths', [(8, 1), (10, 4), (12, -4), (9, -4)])
+@pytest.mark.parametrize('thr', [1, 2, 3])
+def test_gocc_threshold_all_phases_vs_oracle_x(k, npaths, thr):
+    """psikt -r T with seeds_all (BOTH phases): an on-path k-mer with more than T occurrences in the
+    path text is skipped by seeds_on_paths (index_iter.hpp:826-847) while the traverser is not
+    thresholded -- so a starting locus at an on-path position still gives that hit.  The product
+    leaves such loci out of the tables when the on-path occurrences are emitted and must keep them
+    for the k-mers over the threshold (KT_OFFDUP): compared with the oracle's seeds_all( gocc_thr = T )
+    on the reference's graph x, 1 / 4 full / 4 patched paths (npaths < 0), threshold given to the
+    constructor (before the tables exist) and set after prepare() (tables rebuilt)."""
+    g, reads = _x_case()
+    reads = reads[:400]
+    bases, off = psi_amd.pack_reads(reads)
+    step = 3
+    base = psi_amd.SeedFinder(g, k)
+    base.create_path_index(abs(npaths), rng_seed=7, patched=npaths < 0, context=k + 2 if npaths < 0 else 0)
+    px = base.pindex
+    want0 = _oracle_hits(_graph_arrays(g), base, bases, off, k, step)
+    want = _oracle_hits(_graph_arrays(g), base, bases, off, k, step, gocc=thr)
+    assert len(want) <= len(want0) and (thr > 1 or len(want) < len(want0))      # the threshold bites
+    base.close()
+    # threshold known before the tables are made
+    f = psi_amd.SeedFinder(g, k, gocc_threshold=thr)
+    f.set_path_index(px)
+    f.prepare()
+    assert _eq(psi_amd.sort_unique(f.seeds_all((bases, off), step=step)), want)
+    f.close()
+    # threshold set after prepare(): the tables were made without one
+    f = psi_amd.SeedFinder(g, k)
+    f.set_path_index(px)
+    f.prepare()
+    assert _eq(psi_amd.sort_unique(f.seeds_all((bases, off), step=step)), want0)
+    f.set_gocc_threshold(thr)
+    assert _eq(psi_amd.sort_unique(f.seeds_all((bases, off), step=step)), want)
+    su = f.seeds_all((bases, off), step=step, sort_unique=True)
+    assert _eq(su, want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))])
+    f.set_gocc_threshold(0)
+    assert _eq(psi_amd.sort_unique(f.seeds_all((bases, off), step=step)), want0)
+    f.close()
+
+
+@pytest.mark.parametrize('npaths', [1, 3, -3])
+def test_gocc_threshold_all_phases_vs_oracle_snv(npaths):
+    """The same on the synthetic SNV graph (60 kbp, 1500 bubbles), k = 8: nearly every k-mer repeats on the
+    path, and the uncovered loci around the bubbles sit at on-path positions."""
+    sg = synth.snv_graph(60_000, 1500, seed=3)
+    g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to,
+                               paths=[sg.ref_path])
+    arrays = (sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to)
+    k = 8
+    bases, off = synth.sim_reads_snv(sg, 300, 60, seed=5)
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(abs(npaths), rng_seed=5, patched=npaths < 0, context=k + 4 if npaths < 0 else 0)
+    f.prepare()
+    prev = None
+    for thr in (1, 2, 3, 0):
+        f.set_gocc_threshold(thr)
+        got = psi_amd.sort_unique(f.seeds_all((bases, off), step=k))
+        want = _oracle_hits(arrays, f, bases, off, k, k, gocc=thr)
+        assert _eq(got, want)
+        if prev is not None:
+            assert len(want) >= prev
+        prev = len(want)
+    f.close()
+
+
 # ---------------------------------------------------------------------------------------
 # device-resident entry point, and size-independent properties at a larger size
 # ---------------------------------------------------------------------------------------
