@@ -213,15 +213,23 @@ uint64_t psigpu_index_path(const psigpu_index* x, uint64_t i, uint32_t* out, uin
 int psigpu_index_path_trim(const psigpu_index* x, uint64_t i, uint32_t* head_off, uint32_t* tail_len);
 /* Was this index made for this graph, seed length and locus step?  (load_path_index recomputes the
  * starting loci when its loci file does not match: seed_finder.hpp:1396-1413, utils.hpp:521-566;
- * here a mismatch means "no valid index": the caller builds a new one.)  1 = yes. */
+ * here a mismatch means "no valid index": the caller builds a new one.)  1 = yes.  The graph is
+ * recognised by a fingerprint over its ids, label bytes and edges, and the index's paths, trims and loci
+ * are checked against it (nodes exist, consecutive nodes are joined by an edge, offsets inside the nodes). */
 int psigpu_index_matches(const psigpu_index* x, const psigpu_graph* g, uint32_t seed_len, uint32_t locus_step);
 uint32_t psigpu_index_locus_step(const psigpu_index* x);
+/* The index's starting loci recomputed for another locus step (psikt -e) from its own paths and trims
+ * (add_uncovered_loci( step ), seed_finder.hpp:1481-1541): what load_path_index does when the loci file of
+ * the wanted step is missing (:1396-1413).  The index must have been made for `g`. */
+int psigpu_index_set_locus_step(psigpu_index* x, const psigpu_graph* g, uint32_t locus_step);
 /* The reference's own starting-loci file `<prefix>_loci_e<E>l<K>` (SeedFinder::save_starts /
  * open_starts, seed_finder.hpp:1640-1679; container serialisation utils.hpp:521-588): u64 count, then
  * raw psi::Position<> records { node id (external), offset } -- 8 + 8 bytes each, gum's id and offset
  * types (gum is not in the reference tree; a file that does not have this size is rejected).
  * save writes the index's loci for its (k, locus step); load replaces the index's loci by the file
- * made for (index k, locus_step) -- e.g. one written by the reference for the same paths. */
+ * made for (index k, locus_step) -- e.g. one written by the reference for the same paths.  The file carries
+ * nothing that ties it to a graph or to the indexed paths: loading one is the caller's explicit decision
+ * (SeedFinder::load_path_index never does it by itself; it recomputes: psigpu_index_set_locus_step). */
 int psigpu_loci_save(const psigpu_index* x, const psigpu_graph* g, const char* prefix);
 int psigpu_loci_load(psigpu_index* x, const psigpu_graph* g, const char* prefix, uint32_t locus_step);
 const uint8_t* psigpu_index_text(const psigpu_index* x);      /* NULL unless kept */

@@ -108,6 +108,7 @@ ABI = [
     ('psigpu_index_path_trim', C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ('psigpu_index_matches', C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
     ('psigpu_index_locus_step', C.c_uint32, [_P]),
+    ('psigpu_index_set_locus_step', C.c_int, [_P, _P, C.c_uint32]),
     ('psigpu_loci_save', C.c_int, [_P, _P, C.c_char_p]),
     ('psigpu_loci_load', C.c_int, [_P, _P, C.c_char_p, C.c_uint32]),
     ('psigpu_index_free', None, [_P]),
@@ -423,6 +424,17 @@ class PathIndex:
             raise PsiGpuError('cannot read the loci file (%d): %s' % (st, _host_err()))
         lib().psigpu_index_view_get(self.h, C.byref(self.view))
 
+    def set_locus_step(self, g: Graph, step: int) -> None:
+        """Starting loci recomputed for another locus step (psikt -e) from the index's own paths and trims."""
+        st = lib().psigpu_index_set_locus_step(self.h, g.h, step)
+        if st:
+            raise PsiGpuError('cannot recompute the starting loci: ' + _host_err())
+        lib().psigpu_index_view_get(self.h, C.byref(self.view))
+
+    @property
+    def locus_step(self) -> int:
+        return lib().psigpu_index_locus_step(self.h)
+
     def matches(self, g: Graph, k: int, step: int = 1) -> bool:
         return bool(lib().psigpu_index_matches(self.h, g.h, k, step))
 
@@ -512,7 +524,11 @@ class SeedFinder:
         except PsiGpuError:
             return False
         if not px.matches(self.graph, self.seed_len, step_size):
-            return False
+            # same graph and seed length, another locus step: the paths are good, the loci are recomputed
+            # from them (never taken from a `_loci_e<E>l<K>` file found beside the index: it names no graph)
+            if not px.matches(self.graph, self.seed_len, px.locus_step):
+                return False
+            px.set_locus_step(self.graph, step_size)
         self.set_path_index(px)
         return True
 

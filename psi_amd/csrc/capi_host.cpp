@@ -157,6 +157,13 @@ psigpu_index* psigpu_index_build_patches(const psigpu_graph* g, const psigpu_ind
 {
   if (!g || !opts || (n_paths && (!path_off || !path_nodes))) { if (status) *status = PSIGPU_ERR_ARG; return nullptr; }
   std::vector<std::vector<uint32_t>> paths;
+  // (the caller guarantees that path_nodes holds path_off[n_paths] entries: the API cannot bound it)
+  for (uint64_t p = 0; p < n_paths; ++p)
+    if (path_off[p + 1] < path_off[p]) {
+      g_host_err = "path offsets must not decrease";
+      if (status) *status = PSIGPU_ERR_ARG;
+      return nullptr;
+    }
   for (uint64_t p = 0; p < n_paths; ++p) {
     std::vector<uint32_t> nodes(path_nodes + path_off[p], path_nodes + path_off[p + 1]);
     for (uint32_t v : nodes)
@@ -243,10 +250,29 @@ int psigpu_index_matches(const psigpu_index* h, const psigpu_graph* g, uint32_t 
 {
   if (!h || !g) return 0;
   if (locus_step == 0) locus_step = 1;
-  return h->x.k == seed_len && h->x.locus_step == locus_step && h->x.graph_fp == graph_fingerprint(g->g);
+  return h->x.k == seed_len && h->x.locus_step == locus_step && h->x.graph_fp == graph_fingerprint(g->g) &&
+         index_fits_graph(h->x, g->g);
 }
 
 uint32_t psigpu_index_locus_step(const psigpu_index* h) { return h ? h->x.locus_step : 0; }
+
+// The starting loci for another locus step, recomputed from the index's own paths and trims: nothing that
+// lies beside the index file is trusted for this (a `<prefix>_loci_e<E>l<K>` file carries no graph
+// fingerprint and no trace of the paths it was made for).
+int psigpu_index_set_locus_step(psigpu_index* h, const psigpu_graph* g, uint32_t locus_step)
+{
+  if (!h || !g) return PSIGPU_ERR_ARG;
+  if (locus_step == 0) locus_step = 1;
+  Index& x = h->x;
+  if (x.graph_fp != graph_fingerprint(g->g) || !index_fits_graph(x, g->g)) {
+    g_host_err = "the index was not made for this graph";
+    return PSIGPU_ERR_ARG;
+  }
+  if (x.locus_step == locus_step) return PSIGPU_OK;
+  find_starting_loci(g->g, x.paths, x.path_head, x.path_tail, x.k, locus_step, x.loci_node, x.loci_off);
+  x.locus_step = locus_step;
+  return PSIGPU_OK;
+}
 
 // `<prefix>_loci_e<E>l<K>`: the reference's starting-loci file (SeedFinder::save_starts / open_starts,
 // seed_finder.hpp:1640-1679; get_sloci_filepath; psi::serialize of a container, utils.hpp:521-588):

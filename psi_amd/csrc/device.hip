@@ -2324,6 +2324,7 @@ struct psigpu_ctx {
   // graph
   bool have_graph = false;
   uint64_t n_nodes = 0;
+  std::vector<uint32_t> node_len;   // label length per node (host): a loaded index's loci are checked against it
   DevBuf nodes, lite, node_id, lab2, labn, edge_to;
   // index
   bool have_index = false;
@@ -2671,7 +2672,11 @@ int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
   ctx->id_affine = true;
   for (uint64_t v = 0; v < n && ctx->id_affine; ++v) ctx->id_affine = g->node_id[v] == ctx->id_base + v;
   ctx->max_node_len = 0;
-  for (uint64_t v = 0; v < n; ++v) ctx->max_node_len = std::max<uint64_t>(ctx->max_node_len, g->label_off[v + 1] - g->label_off[v]);
+  ctx->node_len.resize(n);
+  for (uint64_t v = 0; v < n; ++v) {
+    ctx->node_len[v] = (uint32_t)(g->label_off[v + 1] - g->label_off[v]);
+    ctx->max_node_len = std::max<uint64_t>(ctx->max_node_len, ctx->node_len[v]);
+  }
   ctx->ids_sorted.release();
   if (!ctx->id_affine) {
     // the hit sorter orders by node id: keys hold a node's position among the sorted ids
@@ -2729,10 +2734,11 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
   if (!ctx->have_graph) { ctx->err = "load the graph before the index"; return PSIGPU_ERR_STATE; }
   {
     std::atomic<bool> bad_locus{ false }, bad_dir{ false };
-    const uint64_t n_nodes = ctx->n_nodes, max_len = ctx->max_node_len;
+    const uint64_t n_nodes = ctx->n_nodes;
+    const uint32_t* node_len = ctx->node_len.data();
     parallel_for(x->n_loci, 1u << 16, [&](uint64_t i0, uint64_t i1) {       // (1.3 G loci at whole-genome size)
       bool bad = false;
-      for (uint64_t i = i0; i < i1; ++i) bad = bad || x->loci_node[i] >= n_nodes || x->loci_off[i] >= max_len;
+      for (uint64_t i = i0; i < i1; ++i) bad = bad || x->loci_node[i] >= n_nodes || x->loci_off[i] >= node_len[x->loci_node[i]];
       if (bad) bad_locus = true;
     });
     if (bad_locus) { ctx->err = "starting locus outside the graph: the index does not belong to this graph"; return PSIGPU_ERR_ARG; }

@@ -41,14 +41,25 @@ struct RawGraph {
   void add_node(uint64_t id, const std::string& s) { add_node(id, s.data(), s.size()); }
 };
 
+inline bool parse_u64(const char* p, size_t n, uint64_t* out)
+{
+  if (n == 0) return false;
+  uint64_t x = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (p[i] < '0' || p[i] > '9') return false;
+    x = x * 10 + (uint64_t)(p[i] - '0');
+  }
+  *out = x;
+  return true;
+}
+
 bool strip_orient(const std::string& tok, uint64_t* id, bool* rev)
 {
   if (tok.size() < 2) return false;
   char o = tok.back();
   if (o != '+' && o != '-') return false;
   *rev = (o == '-');
-  *id = strtoull(tok.substr(0, tok.size() - 1).c_str(), nullptr, 10);
-  return true;
+  return parse_u64(tok.data(), tok.size() - 1, id);
 }
 
 // Orientation handling: the reference traverser follows `to` ids only and ignores the link
@@ -80,18 +91,6 @@ struct Fields {
   }
 };
 
-inline bool parse_u64(const char* p, size_t n, uint64_t* out)
-{
-  if (n == 0) return false;
-  uint64_t x = 0;
-  for (size_t i = 0; i < n; ++i) {
-    if (p[i] < '0' || p[i] > '9') return false;
-    x = x * 10 + (uint64_t)(p[i] - '0');
-  }
-  *out = x;
-  return true;
-}
-
 bool parse_gfa(const std::string& path, RawGraph& rg, std::string* err)
 {
   FILE* f = fopen(path.c_str(), "rb");
@@ -105,6 +104,10 @@ bool parse_gfa(const std::string& path, RawGraph& rg, std::string* err)
     size_t got = buf.empty() ? 0 : fread(&buf[0], 1, buf.size(), f);
     fclose(f);
     if (got != buf.size()) { *err = "cannot read " + path; return false; }
+  }
+  if (buf.size() >= 2 && (unsigned char)buf[0] == 0x1F && (unsigned char)buf[1] == 0x8B) {
+    *err = path + " is gzip-compressed: decompress it first (GFA is read as plain text)";
+    return false;
   }
   rg.seqbuf.reserve(buf.size() / 2);
   const char* p = buf.data();
@@ -121,7 +124,8 @@ bool parse_gfa(const std::string& path, RawGraph& rg, std::string* err)
       fl.cut(p, e, 5);            // S id seq [tags...]  |  GFA 2: S id len seq [tags...]
       if (fl.count < 3) { *err = "bad S line"; return false; }
       uint64_t id, len2;
-      if (!parse_u64(fl.p[1], fl.n[1], &id)) id = strtoull(std::string(fl.p[1], fl.n[1]).c_str(), nullptr, 10);
+      // (gum addresses nodes by integer ids, as vg does; a named segment cannot be mapped to one)
+      if (!parse_u64(fl.p[1], fl.n[1], &id)) { *err = "non-numeric segment id '" + std::string(fl.p[1], fl.n[1]) + "'"; return false; }
       // the 5th "field" is the rest of the line: cut the 4th at its own tab
       size_t n3 = fl.count >= 4 ? fl.n[3] : 0;
       if (fl.count >= 4 && parse_u64(fl.p[2], fl.n[2], &len2) && memchr(fl.p[3], ':', n3) == nullptr)
@@ -132,8 +136,7 @@ bool parse_gfa(const std::string& path, RawGraph& rg, std::string* err)
       fl.cut(p, e, 6);
       if (fl.count < 5) { *err = "bad L line"; return false; }
       uint64_t a, b;
-      if (!parse_u64(fl.p[1], fl.n[1], &a)) a = strtoull(std::string(fl.p[1], fl.n[1]).c_str(), nullptr, 10);
-      if (!parse_u64(fl.p[3], fl.n[3], &b)) b = strtoull(std::string(fl.p[3], fl.n[3]).c_str(), nullptr, 10);
+      if (!parse_u64(fl.p[1], fl.n[1], &a) || !parse_u64(fl.p[3], fl.n[3], &b)) { *err = "non-numeric segment id on an L line"; return false; }
       if (!add_edge(rg, a, fl.n[2] == 1 && fl.p[2][0] == '-', b, fl.n[4] == 1 && fl.p[4][0] == '-', err)) return false;
     } else if (t == 'E') {
       fl.cut(p, e, 5);

@@ -72,6 +72,7 @@ void pick_paths(const Graph& g, uint32_t n_per_region, bool patched, uint32_t co
                 std::vector<std::vector<uint32_t>>& out, std::vector<uint32_t>& head, std::vector<uint32_t>& tail);
 // index.cpp
 uint64_t graph_fingerprint(const Graph& g);
+bool index_fits_graph(const Index& x, const Graph& g);
 Index* build_index(const Graph& g, const psigpu_index_opts& opts,
                    const std::vector<std::vector<uint32_t>>& paths, const std::vector<uint32_t>& head,
                    const std::vector<uint32_t>& tail, int* status, std::string* err);

@@ -395,15 +395,70 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
 
 uint64_t graph_fingerprint(const Graph& g)
 {
-  // node count, total label length, edge count and the node ids: enough to tell that an index file
-  // was made for another graph (load_path_index then rebuilds, as the reference does when its loci
-  // file does not match: seed_finder.hpp:1396-1413)
+  // node count, total label length, edge count, node ids, label offsets, edge targets and the label bytes:
+  // enough to tell that an index file was made for another graph -- other sequences or other edges under
+  // the same ids included (load_path_index then rebuilds, as the reference does when its loci file does
+  // not match: seed_finder.hpp:1396-1413).  Blocks are hashed in parallel and combined in order.
+  auto mix = [](uint64_t h, uint64_t x) { h ^= x; h *= 0x100000001b3ull; h ^= h >> 29; return h; };
   uint64_t h = 0xcbf29ce484222325ull;
-  auto mix = [&](uint64_t x) { h ^= x; h *= 0x100000001b3ull; h ^= h >> 29; };
-  mix(g.n_nodes()); mix(g.labels.size()); mix(g.edge_to.size());
-  for (uint64_t id : g.node_id) mix(id);
-  for (uint64_t v = 0; v < g.n_nodes(); v += 97) mix(g.label_off[v + 1]);
+  h = mix(h, g.n_nodes()); h = mix(h, g.labels.size()); h = mix(h, g.edge_to.size());
+  auto hash_range = [&](auto get, uint64_t n) {
+    const uint64_t BLK = 1u << 20, nb = (n + BLK - 1) / BLK;
+    std::vector<uint64_t> part(nb);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t b = 0; b < (int64_t)nb; ++b) {
+      uint64_t x = 0x9e3779b97f4a7c15ull ^ (uint64_t)b;
+      const uint64_t e = std::min<uint64_t>(n, ((uint64_t)b + 1) * BLK);
+      for (uint64_t i = (uint64_t)b * BLK; i < e; ++i) x = mix(x, get(i));
+      part[b] = x;
+    }
+    for (uint64_t x : part) h = mix(h, x);
+  };
+  hash_range([&](uint64_t i) { return g.node_id[i]; }, g.n_nodes());
+  hash_range([&](uint64_t i) { return g.label_off[i + 1]; }, g.n_nodes());
+  hash_range([&](uint64_t i) { return g.edge_off[i + 1]; }, g.n_nodes());
+  hash_range([&](uint64_t i) { return (uint64_t)g.edge_to[i]; }, g.edge_to.size());
+  // label bytes, eight at a time
+  const uint64_t nw = g.labels.size() / 8;
+  hash_range([&](uint64_t i) { uint64_t w; memcpy(&w, g.labels.data() + 8 * i, 8); return w; }, nw);
+  for (uint64_t i = nw * 8; i < g.labels.size(); ++i) h = mix(h, (uint8_t)g.labels[i]);
   return h;
+}
+
+// Do the index's paths, trims and starting loci lie inside this graph?  (An index file is tied to its
+// graph by the fingerprint; this is the structural check behind it: path nodes exist and follow edges,
+// head offsets / tail lengths fit their nodes, every starting locus is a base of its node.)
+bool index_fits_graph(const Index& x, const Graph& g)
+{
+  const uint64_t n = g.n_nodes();
+  if (x.path_head.size() > x.paths.size() || x.path_tail.size() > x.paths.size()) return false;
+  bool ok = true;
+#pragma omp parallel for schedule(dynamic, 64) reduction(&& : ok)
+  for (int64_t pi = 0; pi < (int64_t)x.paths.size(); ++pi) {
+    const auto& P = x.paths[pi];
+    bool good = true;
+    for (size_t i = 0; good && i < P.size(); ++i) {
+      good = P[i] < n;
+      if (good && i) {
+        const uint32_t u = P[i - 1];
+        bool edge = false;
+        for (uint64_t e = g.edge_off[u]; e < g.edge_off[u + 1] && !edge; ++e) edge = g.edge_to[e] == P[i];
+        good = edge;
+      }
+    }
+    if (good && !P.empty()) {
+      const uint32_t hd = (size_t)pi < x.path_head.size() ? x.path_head[pi] : 0;
+      const uint32_t tl = (size_t)pi < x.path_tail.size() ? x.path_tail[pi] : 0;
+      good = hd <= g.node_len(P.front()) && tl <= g.node_len(P.back());
+    }
+    ok = ok && good;
+  }
+  if (!ok || x.loci_node.size() != x.loci_off.size()) return false;
+  bool lok = true;
+#pragma omp parallel for reduction(&& : lok)
+  for (int64_t i = 0; i < (int64_t)x.loci_node.size(); ++i)
+    lok = lok && x.loci_node[i] < n && x.loci_off[i] < g.node_len(x.loci_node[i]);
+  return lok;
 }
 
 Index* build_index(const Graph& g, const psigpu_index_opts& opts,

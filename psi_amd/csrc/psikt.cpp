@@ -374,7 +374,11 @@ int run( Options const& o, Logger& log )
           catch ( std::exception const& ex ) { err[ r ] = ex.what(); }
         } );
       for ( auto& t : th ) t.join();
-      for ( size_t r = 0; r < nd; ++r ) if ( !err[ r ].empty() ) throw std::runtime_error( "device " + std::to_string( o.devices[ r ] ) + ": " + err[ r ] );
+      for ( size_t r = 0; r < nd; ++r )
+        if ( !err[ r ].empty() ) {
+          for ( auto& h : part ) psigpu_free_hits( &h );      /* what the other devices returned (pinned memory) */
+          throw std::runtime_error( "device " + std::to_string( o.devices[ r ] ) + ": " + err[ r ] );
+        }
       st = finder.get_stats();
       for ( size_t r = 0; r < nd; ++r ) {
         found += part[ r ].n;

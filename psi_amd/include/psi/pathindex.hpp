@@ -202,6 +202,15 @@ namespace psi {
       return true;
     }
 
+    /** The starting loci recomputed for another locus step from the index's own paths and trims
+     *  (SeedFinder::add_uncovered_loci( step ), seed_finder.hpp:1481-1541). */
+    bool set_locus_step( unsigned int step_size )
+    {
+      if ( !h_ || !graph_ptr || psigpu_index_set_locus_step( h_, graph_ptr->handle(), step_size ) != PSIGPU_OK ) return false;
+      psigpu_index_view_get( h_, &view_ );
+      return true;
+    }
+
     psigpu_index_view const& view() const { return view_; }
     psigpu_index const* handle() const { return h_; }
     void clear() { reset( nullptr ); paths_set.clear(); }

@@ -134,11 +134,13 @@ namespace psi {
     {
       if ( !pindex.load( prefix ) ) return false;
       if ( !psigpu_index_matches( pindex.handle(), graph_ptr->handle(), seed_len, step_size ) ) {
-        /* same graph and seed length, other locus step: the paths are still good when a loci file
-         * for this step lies beside the index (open_starts, reference :1640-1657) */
+        /* same graph and seed length, other locus step: the paths are still good, and the loci for this
+         * step are recomputed from them (the reference recomputes too when open_starts finds no file for
+         * the step, :1396-1413).  A `_loci_e<E>l<K>` file that happens to lie beside the index is NOT
+         * used here: it names no graph and no paths, a stale one would silently lose off-path hits. */
         bool ok = psigpu_index_matches( pindex.handle(), graph_ptr->handle(), seed_len,
                                         psigpu_index_locus_step( pindex.handle() ) ) &&
-                  pindex.load_loci( prefix, step_size );
+                  pindex.set_locus_step( step_size );
         if ( !ok ) { pindex.clear(); return false; }
       }
       check( psigpu_load_index( ctx, &pindex.view() ) );

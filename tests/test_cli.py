@@ -82,16 +82,27 @@ def test_output_bytes_match_golden(tmp_path):
     # context shorter than the seed: the reference's runtime error (seed_finder.hpp:1434-1437)
     p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '2', '-t', '6', '-o', str(tmp_path / 'o2'), '-Q')
     assert p.returncode == 1 and 'seed length should not be larger than context size' in p.stderr
-    # an index file made with another locus step (-e) is not reused
+    # an index file made with another locus step (-e): its paths are reused, the starting loci are recomputed
+    # for this run's step from them -- also when a stale loci sidecar for that step lies beside the file
+    # (it carries nothing that ties it to the graph or the paths, so it is never trusted); this run also goes
+    # through the destructors (PSIKT_CLEAN_EXIT) instead of ending the process once the records are written
     pre2 = str(tmp_path / 'stale')
     p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '1', '-e', '3', '-I', pre2, '-o', str(tmp_path / 'o4'), '-Q')
     assert p.returncode == 0, p.stderr
     out = str(tmp_path / 'o5')
-    p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '1', '-I', pre2, '-o', out, '-L', str(tmp_path / 'psi2.log'))
+    stale = np.array([1, 3, 0], dtype=np.uint64)              # one locus, (node 3, offset 0): not this index's loci
+    stale.tofile(pre2 + '_loci_e1l10')
+    p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '1', '-I', pre2, '-o', out, '-L', str(tmp_path / 'psi2.log'),
+            env=dict(os.environ, PSIKT_CLEAN_EXIT='1'))
     assert p.returncode == 0, p.stderr
-    assert 'No valid path index found' in open(str(tmp_path / 'psi2.log')).read()
+    assert 'The path index has been found and loaded.' in open(str(tmp_path / 'psi2.log')).read()
     got = _records(out)
     assert got.shape == want.shape and (got == want).all()
+    # ... while a file made for another seed length is not a valid index for this run
+    p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '9', '-d', '10', '-n', '1', '-I', pre2, '-o', str(tmp_path / 'o6'),
+            '-L', str(tmp_path / 'psi3.log'))
+    assert p.returncode == 0, p.stderr
+    assert 'No valid path index found' in open(str(tmp_path / 'psi3.log')).read()
     p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '0', '--query-mode', 'nope', '-o', str(tmp_path / 'o3'), '-Q')
     assert p.returncode == 1 and 'query mode' in p.stderr
 

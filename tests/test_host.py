@@ -368,6 +368,42 @@ def test_index_file_is_tied_to_graph_seed_length_and_step(tmp_path, ref_data):
         psi_amd.PathIndex.load(prefix)
 
 
+def test_other_locus_step_recomputes_and_ignores_stale_sidecar(tmp_path, ref_data):
+    """An index loaded for another locus step gets its loci RECOMPUTED from its own paths and trims
+    (psigpu_index_set_locus_step; reference load_path_index recomputes when open_starts finds nothing,
+    seed_finder.hpp:1396-1413); a stale `<prefix>_loci_e<E>l<K>` file beside it -- it carries no graph
+    fingerprint and no paths -- is never picked up on the way.  Also: the fingerprint tells graphs apart
+    that share ids and lengths but differ in one base or one edge target."""
+    b, g = _setup(ref_data, 'x')
+    px = psi_amd.PathIndex.build(g, 12, 2, step=3, patched=True, context=14, rng_seed=4)
+    prefix = str(tmp_path / 'ix')
+    px.save(prefix)
+    want = psi_amd.PathIndex.build_paths(g, 12, [p.tolist() for p in px.paths()], step=1, context=14,
+                                         head=[h for h, _ in px.trims()], tail=[t for _, t in px.trims()]).loci
+    # a stale sidecar for step 1: loci of another path set
+    other = psi_amd.PathIndex.build(g, 12, 1, step=1, rng_seed=9)
+    other.save_loci(g, prefix)
+    assert os.path.exists(prefix + '_loci_e1l12')
+    assert len(other.loci[0]) != len(want[0])
+    py = psi_amd.PathIndex.load(prefix)
+    assert py.locus_step == 3 and not py.matches(g, 12, 1)
+    py.set_locus_step(g, 1)
+    assert py.matches(g, 12, 1) and py.locus_step == 1
+    assert py.loci[0].tolist() == want[0].tolist() and py.loci[1].tolist() == want[1].tolist()
+    # the C++ shim's load_path_index goes the same way (tests/cpp/pathindex_api.cpp covers the call itself)
+    _, g2 = _setup(ref_data, 'multi')
+    with pytest.raises(psi_amd.PsiGpuError):
+        py.set_locus_step(g2, 2)
+    # same ids, same lengths, one base / one edge target changed: another graph
+    labels = bytearray(bytes(g.labels))
+    labels[len(labels) // 2] = ord('A') if labels[len(labels) // 2] != ord('A') else ord('C')
+    g_base = psi_amd.Graph.from_csr(g.node_id, g.label_off, bytes(labels), g.edge_off, g.edge_to, paths=g.paths())
+    et = np.array(g.edge_to).copy()
+    et[len(et) // 2] = (et[len(et) // 2] + 1) % g.n_nodes
+    g_edge = psi_amd.Graph.from_csr(g.node_id, g.label_off, bytes(g.labels), g.edge_off, et, paths=[])
+    assert px.matches(g, 12, 3) and not px.matches(g_base, 12, 3) and not px.matches(g_edge, 12, 3)
+
+
 def test_reference_loci_file_format(tmp_path, ref_data):
     """`<prefix>_loci_e<E>l<K>` (reference SeedFinder::save_starts / open_starts, seed_finder.hpp:1640-1679;
     utils.hpp:521-588): u64 count + raw { node id, offset } records with external ids."""

@@ -4,7 +4,8 @@ random graphs (cycles, N runs, empty-ish nodes, out-degree up to 6) x random k /
 indexed paths -- full or PATCHED with a random context -- / SA rate / interval table, every query mode
 and walk caps 0 / 1 / 3, device index build on and off, against the brute-force definition; the host
 entry point with a random sub-batch size and sort-unique on the device; the starting loci against the
-brute-force definition over the (trimmed) paths; MEM mode against brute.find_mems.
+brute-force definition over the (trimmed) paths; MEM mode against brute.find_mems; a gocc threshold over
+both phases against the oracle's seeds_all.
 `python tools/fuzz_modes.py FIRST LAST [low]`."""
 import os
 import random
@@ -98,6 +99,22 @@ def main():
                     if not (got.shape == want.shape and (got == want).all()):
                         print('MISMATCH', seed, k, step, npaths, mode, cap, got.shape, want.shape, flush=True)
                         sys.exit(1)
+                    if rng.random() < 0.5:
+                        # psikt -r T over BOTH phases against the oracle's seeds_all( gocc_thr = T ): on-path k-mers
+                        # over the threshold skipped, the traverser not thresholded (index_iter.hpp:826-847);
+                        # set on the live finder, i.e. after its tables were made without one
+                        thr = rng.choice([1, 1, 2, 3])
+                        rb, ro = psi_amd.pack_reads([r.upper() for r in reads])
+                        arrays = (np.array(g.ids), label_off, np.frombuffer(labels, np.uint8), edge_off,
+                                  np.array(edge_to, dtype=np.uint64))
+                        wg = T._oracle_hits(arrays, f, rb, ro, k, step, gocc=thr)
+                        f.set_gocc_threshold(thr)
+                        gg = psi_amd.sort_unique(f.seeds_all(reads, step=step))
+                        f.set_gocc_threshold(0)
+                        if not (gg.shape == wg.shape and (gg == wg).all()):
+                            print('GOCC MISMATCH', seed, k, step, npaths, patched, mode, cap, thr, gg.shape, wg.shape, flush=True)
+                            sys.exit(1)
+                        n_cases += 1
                     if cap == 0:
                         # host entry point in pieces, sorted on the device
                         os.environ['PSIGPU_SUB_BYTES'] = str(rng.choice([16, 200, 3000, 1 << 30]))
