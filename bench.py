@@ -37,8 +37,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_PEAK_GBS = 63.0           # PCIe Gen5 x16, one direction (64 GT/s x 16 lanes, 128b/130b)
 BLOCK = 64                     # bytes per rank block / HBM sector
-PROFILE_ROUND = 'r02'
-TRAFFIC_FILES = {'kmer-table': '%s_k_traffic.json', 'locus-table': '%s_l_traffic.json', 'traverse': '%s_t_traffic.json'}
+PROFILE_ROUND = 'r03'
+TRAFFIC_FILES = {'kmer-table': '%s_k_traffic.json', 'locus-table': '%s_l_traffic.json', 'traverse': '%s_t_traffic.json',
+                 # the fm-lf series (tools/profile.sh f1 / f2 / f3): locus-table mode with the LF kernels doing the work
+                 'fm-lf/after_ftab': '%s_f1_traffic.json', 'fm-lf/no_ftab': '%s_f2_traffic.json',
+                 'fm-lf/sa32': '%s_f3_traffic.json'}
 
 
 def log(*a):
@@ -52,9 +55,9 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
         # per N-free seed one 8-byte interval-table entry; per LF step actually needed two rank
         # probes (one 64-byte block each, not discounted when both ends share a block); per SA row
         # finished against its record 16 bytes (row record) -- 12 when finished against the text
-        if ftab_len and k >= ftab_len:
+        if ftab_len and ftab_len != 0xFFFFFFFF and k >= ftab_len:
             return 8.0 * c['n_seeds_valid'] + 2.0 * BLOCK * c['n_lf_steps'] + 12.0 * c['n_rows_verified']
-        return 2.0 * k * BLOCK * c['n_seeds_valid']
+        return 2.0 * k * BLOCK * c['n_seeds_valid']        # SURVEY 8(d) verbatim: 2 k B per seed
     if kernel == 'k_table_insert':
         # per N-free seed one 16-byte table slot and one 4-byte bitmap word, both read-modify-write
         return 2.0 * (16 + 4) * c['n_seeds_valid']
@@ -66,6 +69,10 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
         # SA-order sampling at rate s: expected s-1 LF steps (one block each) + the 4-byte
         # sample, two 64-byte segment-table probes, one 32-byte record out; hits that come from the
         # locus k-mer table: one 16-byte entry in, one 32-byte record out
+        if sa_rate > 1:
+            # SURVEY 8(d) verbatim: locate (s/2) B + 8, map 2 B, emit 32 per on-path hit (the walk itself is longer:
+            # SA-order sampling, as sdsl's default, ends a walk with probability 1/s per step -- n_locate_steps)
+            return (sa_rate / 2.0 * BLOCK + 8 + 2 * BLOCK + 32) * c['n_hits_on_path'] + (16 + 32.0) * c['n_hits_table']
         return ((sa_rate - 1) * BLOCK + 4 + 2 * BLOCK + 32) * c['n_hits_on_path'] + (16 + 32.0) * c['n_hits_table']
     if kernel in ('k_kmer_probe', 'k_lkt_probe'):
         # per seed its 8-byte key in and 16 bytes of results out to K2; per N-free seed one 16-byte slot in
@@ -185,7 +192,10 @@ def main():
     ap.add_argument('--step', type=int, default=0, help='seed distance (psikt -d); 0 = k')
     ap.add_argument('--paths', type=int, default=1, help='indexed paths per region (psikt -n)')
     ap.add_argument('--sa-rate', type=int, default=1)
-    ap.add_argument('--ftab', type=int, default=0, help='interval-table length (0 = auto)')
+    ap.add_argument('--ftab', type=int, default=0, help='interval-table length (0 = auto, -1 = none)')
+    ap.add_argument('--tune', type=int, default=0, help='psigpu_set_tuning flags of the main finder (1 no direct K1, 2 no text '
+                                                        'verification, 4 no row records, 8 lock-step LF kernel, 16 one seed per quad)')
+    ap.add_argument('--series', default='', help="label of a roofline_by_mode['fm-lf'] point this run reproduces (traffic lookup)")
     ap.add_argument('--host-build', action='store_true', help='build the index on the host (SA-IS) instead of the GPU')
     ap.add_argument('--backbone', type=int, default=51_000_000)
     ap.add_argument('--snvs', type=int, default=1_100_000)
@@ -240,10 +250,13 @@ def main():
     nb = max(1, args.batches)
     batches = [synth.sim_reads_snv(sg, args.reads, args.read_len, seed=13 + 100 * b + rank) for b in range(nb)]
     t_ix = time.time()
-    px = psi_amd.PathIndex.build(g, k, args.paths, sa_rate=args.sa_rate, rng_seed=1, ftab_len=args.ftab,
+    px = psi_amd.PathIndex.build(g, k, args.paths, sa_rate=args.sa_rate, rng_seed=1,
+                                 ftab_len=psi_amd.NO_FTAB if args.ftab < 0 else args.ftab,
                                  device=None if args.host_build else local_rank)
     t_ix = time.time() - t_ix
     finder = psi_amd.SeedFinder(g, k, device=local_rank, mode=args.mode)
+    if args.tune:
+        finder.set_tuning(args.tune)
     finder.set_path_index(px)
     t_prep = time.time()
     finder.prepare()                      # the tables of the query mode: index load time, not query time
@@ -307,17 +320,29 @@ def main():
         c['n_hits_table'] = c['n_hits_off_path'] if c['n_locus_kmers'] and not c['n_loci_traversed'] else 0
         return {'elapsed': elapsed, 'kern': kern, 'seeds': seeds, 'hits': hits, 'c': c, 'steps': steps}
 
-    def roofline_of(res, mode, kernel=None):
+    rand_peak = {}
+
+    def random_load_peak(quad):
+        """Independent random loads / s this device retires now -- 16 bytes per lane (the table probe) or one
+        64-byte sector per quad (a rank block) -- on a 4 GiB scratch table, as many loads as a step has seeds
+        (x 8 for the sector series: the LF steps of a seed); measured once per run, before the timed loops."""
+        if quad not in rand_peak:
+            n = args.reads * max(1, (args.read_len - k) // step + 1)
+            rand_peak[quad] = finder.measure_random_loads(4 << 30, n * (8 if quad else 1), quad)
+        return rand_peak[quad]
+
+    def roofline_of(res, mode, kernel=None, ix=None, traffic_key=None):
         """Roofline object of one kernel of a mode (default: the one with the largest summed event time)."""
         kern, c, steps = res['kern'], res['c'], res['steps']
+        ix = ix or px
         dom = kernel or max(kern, key=lambda n: kern[n])
         avg_ms = kern[dom] / steps
-        abytes = algorithmic_bytes(dom, c, k, args.sa_rate, int(px.view.ftab_len))
+        abytes = algorithmic_bytes(dom, c, k, int(ix.view.sa_rate), int(ix.view.ftab_len))
         achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM-side traffic per launch from separate rocprofv3 --pmc passes over this same command
         # (tools/profile.sh -> profiles/<round>_*_traffic.json, committed); null when not collected
         traffic, src = None, None
-        tname = TRAFFIC_FILES[mode] % PROFILE_ROUND
+        tname = TRAFFIC_FILES[traffic_key or mode] % PROFILE_ROUND
         tpath = os.path.join(ROOT, 'profiles', tname)
         if os.path.exists(tpath) and world == 1 and args.reads == 1_000_000 and k == 21 and step == 21 and args.paths == 1:
             tj = json.load(open(tpath))
@@ -328,7 +353,7 @@ def main():
                      'k_seed_pack': ['k_seed_pack'], 'k_table_insert': ['k_table_insert']}.get(dom, [dom])
             for nme in names:
                 t = pl.get(nme)
-                if t and tj.get('mode') == mode:
+                if t and tj.get('mode') == mode and tj.get('series', '') == (traffic_key or '').partition('/')[2]:
                     traffic = t.get('fetch_size_bytes', 0.0) + t.get('write_size_bytes', 0.0)
                     src = 'profiles/' + tname + ':' + nme
                     break
@@ -341,19 +366,31 @@ def main():
             # the same secondary bound for K1: its divergent loads per launch -- interval-table entry per
             # N-free seed, the locus-table slot probed beside it (locus-table mode), one 16-byte row record
             # per row verified, two rank blocks per LF step still executed
-            loads = c['n_seeds_valid'] * (2 if mode == 'locus-table' else 1) + c['n_rows_verified'] + 2 * c['n_lf_steps']
+            has_ftab = int(ix.view.ftab_len) not in (0, 0xFFFFFFFF)
+            loads = c['n_seeds_valid'] * ((1 if has_ftab else 0) + (1 if mode == 'locus-table' and res.get('probe_in_k1', True) else 0)) + \
+                c['n_rows_verified'] + 2 * c['n_lf_steps']
             out['random_loads_per_launch'] = float(loads)
             out['random_loads_per_s'] = loads / (avg_ms * 1e-3)
-            out['random_load_peak_per_s'] = 41.4e9
+            out['random_load_peak_per_s'] = random_load_peak(True)
+            out['random_load_peak_source'] = 'psigpu_measure_random_loads (64-byte sector per quad, 4 GiB table), this run'
+            out['lf_steps_per_launch'] = int(c['n_lf_steps'])
         if dom == 'k_kmer_probe':
             # secondary bound: divergent 16-byte loads per second against the rate
             # tools/rand_sector2.hip measures on this part for a table of this size
             out['random_loads_per_s'] = c['n_seeds_valid'] / (avg_ms * 1e-3) if avg_ms > 0 else None
-            out['random_load_peak_per_s'] = 41.4e9
+            out['random_load_peak_per_s'] = random_load_peak(False)
+            out['random_load_peak_source'] = 'psigpu_measure_random_loads (16 bytes per lane, 4 GiB table), this run'
             # SURVEY's price for the search this probe replaces (2*k*64 B per seed)
             out['survey_8d_bytes_per_launch'] = algorithmic_bytes('k_fm_search', c, k, args.sa_rate, 0)
+        if dom == 'k_fm_locate' and int(ix.view.sa_rate) > 1:
+            out['lf_steps_per_launch'] = int(c['n_locate_steps'])
+            out['random_loads_per_s'] = (c['n_locate_steps'] + 2.0 * c['n_hits_on_path']) / (avg_ms * 1e-3) if avg_ms > 0 else None
+            out['random_load_peak_per_s'] = random_load_peak(True)
         return out
 
+    if rank == 0 and not lean:
+        random_load_peak(False); random_load_peak(True)
+        time.sleep(0.3)                   # (4 GiB of scratch just freed: see above)
     main_res = time_mode(finder, args.steps, args.warmup, args.mode, True)
     elapsed = main_res['elapsed']
     seeds_total, hits_total = float(main_res['seeds']), float(main_res['hits'])
@@ -426,8 +463,11 @@ def main():
                 'lf_steps_per_step': int(c['n_lf_steps']), 'rows_verified_per_step': int(c['n_rows_verified']),
                 'parallelism': 'reads sharded x%d, index replicated' % world,
             },
-            'roofline': roofline_of(main_res, args.mode),
+            'roofline': roofline_of(main_res, args.mode, traffic_key=('fm-lf/' + args.series) if args.series else None),
         }
+        if args.tune or args.series:
+            out['config']['tune'] = args.tune
+            out['config']['series'] = args.series
         if gather:
             out['gather_hits'] = gather
     if world == 1 and not lean:
@@ -514,6 +554,32 @@ def main():
             if m == 'traverse':
                 e['k_traverse'] = roofline_of(res, m, 'k_traverse')
             rbm[m] = e
+        # ---- the LF / rank kernels doing the work (north_star: "FM-index backward-search (LF-mapping via rank
+        # over the path-set BWT)"): in the modes above the interval table + the rows' records answer nearly every
+        # seed without an LF step.  Three points in locus-table mode: (after_ftab) the interval table, then every
+        # remaining base by an LF step; (no_ftab) all k bases by LF steps -- fmindex.hpp:851-869 as written;
+        # (sa32) SA sampled at 32 in SA order, as sdsl's csa_wt< wt_huff<>, 32, 64 > is: K2 walks to a sample.
+        lf = {}
+        NO_DV = psi_amd.TUNE_NO_DIRECT | psi_amd.TUNE_NO_VERIFY
+        for label, kw, tune in (('after_ftab', None, NO_DV),
+                                ('no_ftab', dict(ftab_len=psi_amd.NO_FTAB), NO_DV),
+                                ('sa32', dict(sa_rate=32), 0)):
+            ix = px if kw is None else psi_amd.PathIndex.build(g, k, args.paths, rng_seed=1, device=local_rank, **kw)
+            f2 = psi_amd.SeedFinder(g, k, device=local_rank, mode='locus-table')
+            f2.set_tuning(tune)
+            f2.set_path_index(ix)
+            f2.prepare()
+            res = time_mode(f2, 10, 3, 'locus-table', False)
+            res['probe_in_k1'] = False
+            f2.close()
+            key = 'fm-lf/' + label
+            lf[label] = {'ms_per_step': res['elapsed'] / res['steps'] * 1e3, 'seeds_per_s': res['seeds'] / res['elapsed'],
+                         'hits_per_step': int(res['c']['n_hits']), 'ftab_len': int(ix.view.ftab_len) if int(ix.view.ftab_len) != psi_amd.NO_FTAB else 0,
+                         'sa_rate': int(ix.view.sa_rate), 'tune': tune,
+                         'k_fm_search': roofline_of(res, 'locus-table', 'k_fm_search', ix, key),
+                         'k_fm_locate': roofline_of(res, 'locus-table', 'k_fm_locate', ix, key)}
+            del ix
+        rbm['fm-lf'] = lf
         out['roofline_by_mode'] = rbm
 
         # ---- CPU baseline + parity gate -------------------------------------------------------------

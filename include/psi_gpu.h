@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSIGPU_ABI_VERSION 3
+#define PSIGPU_ABI_VERSION 4
 #define PSIGPU_MAX_SEED_LEN 31u   /* seeds are 2-bit packed into one 64-bit word */
 #define PSIGPU_MAX_PARTS 8u       /* parts of an index whose text passes the 32-bit row limit */
 
@@ -279,6 +279,17 @@ int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr);
 #define PSIGPU_MODE_LOCUS_TABLE 2u
 int psigpu_set_query_mode(psigpu_ctx* ctx, uint32_t mode, uint32_t walk_cap);
 
+/* Measurement switches: A/B runs behind bench.py's roofline series (which kernel answers the on-path phase
+ * of the FM modes).  The hit set never depends on them.  No counterpart in the reference. */
+#define PSIGPU_TUNE_NO_DIRECT 1u     /* K1 by the quad LF kernel only (k_fm_search_lf): no lane-per-seed kernel that finishes a
+                                        seed from its interval-table entry and the rows' records */
+#define PSIGPU_TUNE_NO_VERIFY 2u     /* every base of a seed by an LF step (fmindex.hpp:851-869 as written): small intervals
+                                        are not finished by comparing the rows with the text */
+#define PSIGPU_TUNE_NO_ROWRECS 4u    /* no per-row records (SaRec, located suffix array): locate through SA + segment table */
+#define PSIGPU_TUNE_LF_LOCKSTEP 8u   /* the LF kernel of rounds 1-2 (16 quads of a wave in step) */
+#define PSIGPU_TUNE_LF_ONE 16u       /* decoupled quads, one seed in flight per quad (default: two) */
+int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags);
+
 /* Builds the tables of the current query mode for seed length k now (index load time) instead of
  * inside the first query: the k-walks of the starting loci enumerated by the traverser kernel, the
  * path k-mers read off the suffix array, sorted and hashed.  Blocks until the device is idle (it
@@ -374,8 +385,18 @@ typedef struct psigpu_counters {
   uint32_t search_launches, traverse_launches;
   uint32_t sorted_in_place;                    /* PSIGPU_SORT_UNIQUE: sub-batches whose hits, emitted seed by seed, only needed
                                                 * the hits of each seed put in order (no radix sort) */
+  uint32_t reserved0;
+  uint64_t n_locate_steps;                     /* LF steps K2 walked from occurrences to sampled suffix-array rows (sa_rate > 1) */
 } psigpu_counters;
 int psigpu_get_counters(const psigpu_ctx* ctx, psigpu_counters* out);
+
+/* The secondary bound SURVEY 8(d) asks to be reported beside the HBM roofline -- "random-access efficiency
+ * (achievable fraction of peak at 64-B granularity)" -- measured on this device, now: `n_loads` independent loads
+ * at random addresses of a scratch table of `table_bytes`, launched as the query kernels are (8192 workgroups);
+ * quad_sectors = 0: every lane loads 16 bytes from a sector of its own (the k-mer table probe's access),
+ * 1: the four lanes of a quad load one 64-byte sector (a rank block, a segment record).  Best of five launches. */
+int psigpu_measure_random_loads(psigpu_ctx* ctx, uint64_t table_bytes, uint64_t n_loads, uint32_t quad_sectors,
+                                double* loads_per_s);
 
 uint32_t psigpu_abi_version(void);
 /* Text of the last host-side (graph / index) failure on this thread. */

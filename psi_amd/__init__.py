@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get('PSI_AMD_LIB') or os.path.join(_HERE, 'libpsi_gpu.so')
 
 ALL, ON_PATHS, OFF_PATHS, SORT_UNIQUE = 3, 1, 2, 4
 MAX_SEED_LEN = 31
+TUNE_NO_DIRECT, TUNE_NO_VERIFY, TUNE_NO_ROWRECS, TUNE_LF_LOCKSTEP, TUNE_LF_ONE = 1, 2, 4, 8, 16
 
 
 class PsiGpuError(RuntimeError):
@@ -82,7 +83,8 @@ class Counters(C.Structure):
                 ('ms_locate', C.c_float), ('ms_traverse', C.c_float), ('ms_sort', C.c_float),
                 ('ms_total', C.c_float), ('ms_probe', C.c_float), ('ms_locus_table_build', C.c_float),
                 ('search_launches', C.c_uint32),
-                ('traverse_launches', C.c_uint32), ('sorted_in_place', C.c_uint32)]
+                ('traverse_launches', C.c_uint32), ('sorted_in_place', C.c_uint32), ('reserved0', C.c_uint32),
+                ('n_locate_steps', C.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -126,6 +128,8 @@ ABI = [
     ('psigpu_load_graph', C.c_int, [_P, C.POINTER(GraphView)]),
     ('psigpu_load_index', C.c_int, [_P, C.POINTER(IndexView)]),
     ('psigpu_set_gocc_threshold', C.c_int, [_P, C.c_uint32]),
+    ('psigpu_set_tuning', C.c_int, [_P, C.c_uint32]),
+    ('psigpu_measure_random_loads', C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     ('psigpu_set_query_mode', C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ('psigpu_find_seeds', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                     C.c_uint32, C.POINTER(Hits)]),
@@ -493,6 +497,17 @@ class SeedFinder:
     def _chk(self, st: int) -> None:
         if st:
             raise PsiGpuError('psigpu error %d: %s' % (st, lib().psigpu_last_error(self.ctx).decode()))
+
+    def set_tuning(self, flags: int) -> None:
+        """Measurement switches (TUNE_*): which kernel answers the on-path phase of the FM modes."""
+        self._chk(lib().psigpu_set_tuning(self.ctx, flags))
+
+    def measure_random_loads(self, table_bytes: int, n_loads: int, quad_sectors: bool = False) -> float:
+        """Independent random loads per second this device retires right now (16 bytes per lane, or one 64-byte
+        sector per quad) on a scratch table of `table_bytes`: the bound of the table probe / of an LF step."""
+        r = C.c_double()
+        self._chk(lib().psigpu_measure_random_loads(self.ctx, table_bytes, n_loads, int(quad_sectors), C.byref(r)))
+        return r.value
 
     def set_gocc_threshold(self, thr: int) -> None:
         """SeedFinder gocc_threshold (seed_finder.hpp:939): on-path k-mers with more than `thr` occurrences

@@ -137,6 +137,7 @@ struct DevCounters {
   PaddedCounter n_hits_off;      // records in those chunks (scan total)
   StripedCounter n_lf_steps;     // LF steps K1 executed (per seed)
   StripedCounter n_rows_verified; // SA rows K1 checked against the text
+  StripedCounter n_locate_steps; // LF steps K2 walked to sampled rows (sa_rate > 1)
   PaddedCounter n_defer;         // seeds k_fm_search_direct left to the quad kernel
   PaddedCounter n_seeds_true;    // the scan's seed count (comes back to the host with the counters)
   StripedCounter max_read_len;   // longest read of the chunk, a running maximum per stripe (the hit sorter sizes its key fields with it)
@@ -710,6 +711,131 @@ k_fm_search(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __
       n_live += keep;
       wsum += keep ? cnt : 0u;
       if (listed && keep) atomicAdd((unsigned long long*)&wave_total[seed / per_wave], (unsigned long long)cnt);
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    n_live += __shfl_down(n_live, d); wsum += __shfl_down(wsum, d);
+    n_steps += __shfl_down(n_steps, d); n_rows += __shfl_down(n_rows, d);
+  }
+  if (lane_id() == 0) {
+    if (!listed) wave_total[wave] = wsum;
+    if (n_live) ctr->n_live.add((unsigned long long)n_live);
+    if (n_steps) ctr->n_lf_steps.add((unsigned long long)n_steps);
+    if (n_rows) ctr->n_rows_verified.add((unsigned long long)n_rows);
+  }
+}
+
+// The same search with the quads of a wave decoupled and NS seeds in flight per quad.  The kernel above keeps
+// its 16 quads in step: a round of 16 seeds lasts as long as its longest seed, and a quad whose seed died after
+// two steps (a read with an error, an N) idles for the rest of it.  Here every quad owns the seeds
+// start + 16 t of the wave's range, keeps NS of them in flight -- their rank blocks are requested together,
+// 2 NS independent 64-byte sectors per quad before the first popcount -- and takes the next seed the
+// moment one is finished.  What an LF step costs is the sector request (one per step once both interval
+// ends share a block), so the kernel's job is to keep the memory system's queue full and nothing else.
+template <int NS>
+__global__ void __launch_bounds__(256)
+k_fm_search_lf(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
+               uint64_t seeds_cap, uint32_t per_wave,
+               uint32_t k, uint32_t gocc_thr, uint32_t* __restrict__ iv_lo, uint32_t* __restrict__ iv_cnt,
+               uint32_t* __restrict__ iv_aux, uint64_t* __restrict__ wave_total, DevCounters* ctr,
+               const uint32_t* __restrict__ list, const unsigned long long* __restrict__ n_list)
+{
+  const bool can_verify = fm.text4 != nullptr && fm.sa != nullptr;
+  const bool listed = list != nullptr;
+  const uint32_t ql = threadIdx.x & 3, quad = (threadIdx.x & 63) >> 2;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_seeds = min(params[0], seeds_cap);
+  const uint64_t s0 = listed ? wave * 16 : wave * per_wave;
+  const uint64_t s1 = listed ? min((uint64_t)*n_list, seeds_cap) : min(n_seeds, s0 + per_wave);
+  const uint64_t stride = listed ? ((uint64_t)gridDim.x * blockDim.x >> 6) * 16 : 16;
+  const bool use_ftab = fm.ftab != nullptr && k >= fm.ftab_len;
+  const uint32_t j0 = use_ftab ? fm.ftab_len : 0u;
+  const uint64_t qmask = use_ftab ? ((1ull << (2 * j0)) - 1ull) : 0ull;
+  uint32_t n_live = 0, n_steps = 0, n_rows = 0;
+  uint64_t wsum = 0;
+  uint64_t next = s0 + quad;                     // this quad's next item
+  uint64_t key[NS], seed[NS];
+  uint32_t l[NS], r[NS], jq[NS];
+  bool act[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { act[s] = false; key[s] = 0; seed[s] = 0; l[s] = r[s] = jq[s] = 0; }
+  while (true) {
+    // ---- take new seeds into the free slots; a seed that is over at once (N, empty interval-table entry,
+    //      k <= q) is finished in `fin` below like any other ------------------------------------------
+    bool fin[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      fin[s] = false;
+      if (!act[s] && next < s1) {
+        seed[s] = listed ? list[next] : next;
+        next += stride;
+        key[s] = seed_key[seed[s]];
+        l[s] = 0; r[s] = fm.n; jq[s] = j0;
+        bool alive = key[s] != KEY_INVALID;
+        if (alive && use_ftab) {
+          const uint2 iv = fm.ftab[key[s] & qmask];
+          l[s] = iv.x; r[s] = iv.y;
+          alive = r[s] > l[s];
+        }
+        if (!alive) { l[s] = r[s] = 0; }
+        act[s] = true;
+        fin[s] = !alive || jq[s] >= k || (can_verify && (r[s] - l[s]) <= VERIFY_ROWS && (k - jq[s]) <= 16u);
+      }
+    }
+    bool any_act = false;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) any_act = any_act || act[s];
+    if (!__any(any_act)) break;
+    // ---- one LF step for every slot that is still searching: all blocks requested, then all ranks -------
+    uint4 vl[NS], vr[NS];
+    bool stp[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      stp[s] = act[s] && !fin[s];
+      vl[s] = make_uint4(0, 0, 0, 0); vr[s] = vl[s];
+      if (stp[s]) {
+        const uint32_t bl = l[s] / BLOCK_SYMS, br = r[s] / BLOCK_SYMS;
+        vl[s] = fm.blocks[(uint64_t)bl * 4 + ql];
+        vr[s] = vl[s];
+        if (br != bl) vr[s] = fm.blocks[(uint64_t)br * 4 + ql];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (stp[s]) {
+        const uint32_t c = (uint32_t)(key[s] >> (2 * jq[s])) & 3u;
+        const uint32_t nl = fm.C[c] + quad_rank(fm, vl[s], ql, c, l[s]);
+        const uint32_t nr = fm.C[c] + quad_rank(fm, vr[s], ql, c, r[s]);
+        l[s] = nl; r[s] = nr;
+        ++jq[s];
+        n_steps += ql == 0;
+        const bool alive = r[s] > l[s];
+        fin[s] = !alive || jq[s] >= k || (can_verify && (r[s] - l[s]) <= VERIFY_ROWS && (k - jq[s]) <= 16u);
+      }
+    }
+    // ---- finished seeds: rows against the text (the quad's lanes take them four at a time), results out ---
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (!__any(fin[s])) continue;
+      const bool alive = fin[s] && r[s] > l[s];
+      uint32_t cnt = alive ? r[s] - l[s] : 0u, aux = 0, mask = 0;
+      const bool verify = alive && jq[s] < k;
+      const uint32_t rem = k - jq[s];
+      if (verify)
+        for (uint32_t t = ql; t < r[s] - l[s]; t += 4)
+          if (text_matches(fm.text4, fm.sa[l[s] + t], rem, key[s], k)) mask |= 1u << t;
+      mask = quad_sum(mask);                       // disjoint bits: sum == or
+      if (verify) { n_rows += ql == 0 ? r[s] - l[s] : 0u; cnt = (uint32_t)__popc(mask); aux = (rem << 8) | mask; }
+      const bool keep = cnt != 0 && cnt <= gocc_thr;        // index_iter.hpp:843-847
+      if (fin[s] && ql == 0) {
+        iv_lo[seed[s]] = l[s];
+        iv_cnt[seed[s]] = keep ? cnt : 0u;
+        iv_aux[seed[s]] = aux;
+        n_live += keep;
+        wsum += keep ? cnt : 0u;
+        if (listed && keep) atomicAdd((unsigned long long*)&wave_total[seed[s] / per_wave], (unsigned long long)cnt);
+      }
+      if (fin[s]) act[s] = false;
     }
   }
   for (int d = 32; d > 0; d >>= 1) {
@@ -1540,13 +1666,15 @@ k_fm_locate(FMView fm, MapView mv, const uint32_t* __restrict__ iv_lo, const uin
             const uint32_t* __restrict__ off_noff,
             const LocusEnt* __restrict__ ent, const uint64_t* __restrict__ wave_off, const uint64_t* __restrict__ params, uint64_t seeds_cap,
             uint32_t per_wave,
-            const uint2* __restrict__ seed_info, uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap)
+            const uint2* __restrict__ seed_info, uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap,
+            DevCounters* ctr)
 {
   const uint32_t ql = threadIdx.x & 3, quad = (threadIdx.x & 63) >> 2;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t n_items = min(params[0], seeds_cap);
   const uint64_t s0 = wave * per_wave, s1 = min(n_items, s0 + per_wave);
   uint64_t woff = s0 < s1 ? wave_off[wave] : 0;       // first output slot of this wave
+  uint32_t n_walk = 0;
   for (uint64_t base = s0; base < s1; base += 16) {
     const uint64_t item = base + quad;
     const bool have = item < s1;
@@ -1627,6 +1755,7 @@ k_fm_locate(FMView fm, MapView mv, const uint32_t* __restrict__ iv_lo, const uin
             } else {
               row = fm.C[sym] + quad_rank(fm, v, ql, sym, row);
               ++steps;
+              n_walk += ql == 0;
             }
           }
         }
@@ -1642,6 +1771,8 @@ k_fm_locate(FMView fm, MapView mv, const uint32_t* __restrict__ iv_lo, const uin
       }
     }
   }
+  for (int d = 32; d > 0; d >>= 1) n_walk += __shfl_down(n_walk, d);
+  if (lane_id() == 0 && n_walk) ctr->n_locate_steps.add((unsigned long long)n_walk);
 }
 
 // One hit of a seed: occurrence `occ` of its `con` on-path rows, or entry occ - con of its run in
@@ -2276,6 +2407,28 @@ __global__ void k_mem_counts(const MemGroup* __restrict__ groups, uint64_t n, ui
 }
 
 // ------------------------------------------------------------------------------------
+// The part's random-access rate, measured in place (psigpu_measure_random_loads): what the probe of the k-mer
+// table (one divergent 16-byte load per lane) and the LF / locate kernels (one 64-byte sector per quad) are
+// bounded by.  QUAD = false: every lane loads 16 bytes from a sector of its own; QUAD = true: the four lanes
+// of a quad load the four 16-byte pieces of one sector.  Addresses come from a hash of the thread and the
+// iteration; `iters` loads per thread, each depending on nothing.
+// ------------------------------------------------------------------------------------
+template <bool QUAD>
+__global__ void __launch_bounds__(256) k_rand_loads(const uint4* __restrict__ t, uint64_t n_sectors, uint32_t iters, uint32_t* out)
+{
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t x = (QUAD ? (tid >> 2) : tid) * 0x9E3779B97F4A7C15ull + 12345;
+  uint32_t acc = 0;
+  for (uint32_t i = 0; i < iters; ++i) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 29;
+    const uint64_t sct = __umul64hi(x, n_sectors);
+    const uint4 a = t[sct * 4 + (QUAD ? (tid & 3) : ((x >> 5) & 3))];
+    acc ^= a.x + a.w;
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+// ------------------------------------------------------------------------------------
 // Host-side plumbing
 // ------------------------------------------------------------------------------------
 struct DevBuf {
@@ -2344,6 +2497,7 @@ struct psigpu_ctx {
   uint64_t id_base = 0;
   DevBuf blocks, samples, exc_row, exc_sa, seg, seg_dir, loci;
   uint32_t gocc_thr = 0;
+  uint32_t tune = 0;               // PSIGPU_TUNE_* measurement switches (psigpu_set_tuning)
   bool kt_dedup = false;           // the k-mer table was built without a gocc threshold: one entry per graph position
   // locus k-mer table (built on first use for the index's seed length)
   uint32_t query_mode = PSIGPU_MODE_KMER_TABLE, walk_cap = 0;
@@ -2552,6 +2706,18 @@ int psigpu_set_query_mode(psigpu_ctx* ctx, uint32_t mode, uint32_t walk_cap)
   if (mode != ctx->query_mode || walk_cap != ctx->walk_cap) lkt_release(ctx);
   ctx->query_mode = mode;
   ctx->walk_cap = walk_cap;
+  return PSIGPU_OK;
+}
+
+int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags)
+{
+  if (!ctx) return PSIGPU_ERR_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return PSIGPU_ERR_DEVICE;
+  if ((flags ^ ctx->tune) & PSIGPU_TUNE_NO_ROWRECS) {      // the per-row records are made (or dropped) by the next FM query
+    ctx->sarec.release(); ctx->saloc.release();
+    ctx->sarec_k = 0; ctx->have_saloc = false; ctx->rows_tried = false;
+  }
+  ctx->tune = flags;
   return PSIGPU_OK;
 }
 
@@ -2823,7 +2989,8 @@ static int build_row_records(psigpu_ctx* ctx, uint32_t k)
   ctx->sarec.release();
   ctx->have_saloc = false;
   ctx->saloc.release();
-  static const bool no_sarec = getenv("PSIGPU_NO_SAREC") != nullptr;         // A/B
+  static const bool env_no_sarec = getenv("PSIGPU_NO_SAREC") != nullptr;     // A/B (process-wide; per context: psigpu_set_tuning)
+  const bool no_sarec = env_no_sarec || (ctx->tune & PSIGPU_TUNE_NO_ROWRECS);
   const uint64_t n_rows = (ctx->text_len + ctx->sa_rate - 1) / ctx->sa_rate;
   if (ctx->sa_rate == 1 && ctx->have_text4 && ctx->ftab_len && k >= ctx->ftab_len && k - ctx->ftab_len <= 29 &&
       ctx->n_segs && !no_sarec) {
@@ -3353,7 +3520,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   for (int i = 0; i < 4; ++i) fm.C[i] = (uint32_t)ctx->C[i];
   fm.ftab = ctx->ftab_len ? ctx->ftab.as<uint2>() : nullptr;
   fm.ftab_len = ctx->ftab_len;
-  static const bool no_verify = getenv("PSIGPU_NO_VERIFY") != nullptr;     // A/B: LF steps only
+  static const bool env_no_verify = getenv("PSIGPU_NO_VERIFY") != nullptr;   // A/B: LF steps only
+  const bool no_verify = env_no_verify || (ctx->tune & PSIGPU_TUNE_NO_VERIFY);
   fm.text4 = (ctx->have_text4 && !no_verify) ? ctx->text4.as<uint64_t>() : nullptr;
   fm.sa = ctx->sa_rate == 1 ? ctx->samples.as<uint32_t>() : nullptr;
   fm.sarec = (ctx->sarec_k == k && !no_verify) ? ctx->sarec.as<SaRec>() : nullptr;
@@ -3468,11 +3636,25 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         // K1: lane per seed when the interval table + text verification can finish a seed without
         // LF steps (the locus-table probe rides along); quad per seed otherwise, and for the seeds
         // the direct kernel defers
-        static const bool no_direct = getenv("PSIGPU_NO_DIRECT") != nullptr;      // A/B: quad kernel only
+        static const bool env_no_direct = getenv("PSIGPU_NO_DIRECT") != nullptr;   // A/B: quad kernel only
+        const bool no_direct = env_no_direct || (ctx->tune & PSIGPU_TUNE_NO_DIRECT);
         const bool direct = on_paths && fm.ftab != nullptr && fm.sarec != nullptr && !no_direct;
         LktView lk = { nullptr, 0, nullptr };
         if (probe) lk = LktView{ ctx->lkt_ht.as<TableSlot>(), ctx->lkt_ht_size, ctx->lkt_ent.as<LocusEnt>() };
         bool probed = false;
+        // the quad LF kernel: lock-step rounds (PSIGPU_TUNE_LF_LOCKSTEP, the round-1 kernel, kept for A/B), or
+        // decoupled quads with one / two seeds in flight each
+        auto launch_lf = [&](unsigned g_, const uint32_t* list_, const unsigned long long* n_list_) {
+          uint64_t* keys_ = ctx->w_seed_key.as<uint64_t>();
+          uint32_t* lo_ = ctx->w_iv_lo.as<uint32_t>(); uint32_t* cnt_ = ctx->w_iv_cnt.as<uint32_t>(); uint32_t* aux_ = ctx->w_iv_aux.as<uint32_t>();
+          uint64_t* tiles_ = ctx->w_iv_tiles.as<uint64_t>();
+          if (ctx->tune & PSIGPU_TUNE_LF_LOCKSTEP)
+            k_fm_search<<<g_, 256, 0, stream>>>(fm, keys_, d_params, n_seeds, per_wave, k, thr, lo_, cnt_, aux_, tiles_, ctr, list_, n_list_);
+          else if (ctx->tune & PSIGPU_TUNE_LF_ONE)
+            k_fm_search_lf<1><<<g_, 256, 0, stream>>>(fm, keys_, d_params, n_seeds, per_wave, k, thr, lo_, cnt_, aux_, tiles_, ctr, list_, n_list_);
+          else
+            k_fm_search_lf<2><<<g_, 256, 0, stream>>>(fm, keys_, d_params, n_seeds, per_wave, k, thr, lo_, cnt_, aux_, tiles_, ctr, list_, n_list_);
+        };
         if (kprobe) {
           KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
           k_kmer_probe<<<grid, 256, 0, stream>>>(kt, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave,
@@ -3484,17 +3666,11 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
           k_fm_search_direct<<<grid, 256, 0, stream>>>(
               fm, lk, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr, so, ctx->w_iv_tiles.as<uint64_t>(),
               probe ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, ctx->w_defer.as<uint32_t>(), ctr);
-          k_fm_search<<<256, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr,
-                                               ctx->w_iv_lo.as<uint32_t>(), ctx->w_iv_cnt.as<uint32_t>(),
-                                               ctx->w_iv_aux.as<uint32_t>(), ctx->w_iv_tiles.as<uint64_t>(), ctr,
-                                               ctx->w_defer.as<uint32_t>(), &ctr->n_defer.v);
+          launch_lf(256, ctx->w_defer.as<uint32_t>(), &ctr->n_defer.v);
           pc.search_launches = 2;
           probed = probe;
         } else if (on_paths) {
-          k_fm_search<<<grid, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr,
-                                                ctx->w_iv_lo.as<uint32_t>(), ctx->w_iv_cnt.as<uint32_t>(),
-                                                ctx->w_iv_aux.as<uint32_t>(), ctx->w_iv_tiles.as<uint64_t>(), ctr,
-                                                nullptr, nullptr);
+          launch_lf(grid, nullptr, nullptr);
           pc.search_launches = 1;
         } else {
           HIPCHK(ctx, hipMemsetAsync(ctx->w_iv_cnt.p, 0, (n_seeds + 1) * 4, stream));
@@ -3526,7 +3702,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         k_fm_locate<<<grid, 256, 0, stream>>>(fm, mv, so.iv_lo, so.iv_cnt, probe ? so.off_first : nullptr,
                                               probe ? so.off_cnt : nullptr, so.off_noff, oe,
                                               ctx->w_iv_tiles.as<uint64_t>(), d_params, n_seeds, per_wave,
-                                              ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap);
+                                              ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap, ctr);
     } else {
       EVREC(10, stream);
       EVREC(4, stream);
@@ -3626,6 +3802,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   pc.n_kpaths = h.n_kpaths.total();
   pc.n_lf_steps = h.n_lf_steps.total();
   pc.n_rows_verified = h.n_rows_verified.total();
+  pc.n_locate_steps = h.n_locate_steps.total();
   if (getenv("PSIGPU_DEBUG")) fprintf(stderr, "[psigpu] dbg0 %llu dbg1 %llu chunks %llu spilled %llu\n", h.dbg0.v, h.dbg1.v, h.n_chunks.v, (unsigned long long)pc.n_spilled);
   auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ctx->ev[a], ctx->ev[b]); return t; };
   pc.ms_pack = ms(0, 1); pc.ms_table = off_paths ? ms(2, 6) : 0.f;
@@ -3838,6 +4015,37 @@ void* psigpu_host_alloc(uint64_t bytes)
 void psigpu_host_free(void* p)
 {
   if (p) (void)hipHostFree(p);
+}
+
+int psigpu_measure_random_loads(psigpu_ctx* ctx, uint64_t table_bytes, uint64_t n_loads, uint32_t quad_sectors, double* loads_per_s)
+{
+  if (!ctx || !loads_per_s || table_bytes < (1u << 20)) return PSIGPU_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  TmpBuf t, out;
+  if (t.alloc(table_bytes) != hipSuccess) { (void)hipGetLastError(); ctx->err = "not enough device memory for the measurement table"; return PSIGPU_ERR_NOMEM; }
+  HIPCHK(ctx, out.alloc(64));
+  HIPCHK(ctx, hipMemset(t.p, 1, table_bytes));
+  const uint32_t blocks = 8192;                                   // every wave slot of the chip, as the query kernels are launched
+  const uint64_t threads = (uint64_t)blocks * 256;
+  const uint64_t per_thread = quad_sectors ? 4 * n_loads : n_loads;  // a quad's four lanes make ONE sector load
+  const uint32_t iters = (uint32_t)std::max<uint64_t>(1, (per_thread + threads - 1) / threads);
+  hipEvent_t a, b;
+  HIPCHK(ctx, hipEventCreate(&a)); HIPCHK(ctx, hipEventCreate(&b));
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; ++rep) {                             // (the first one pays the page-table walk)
+    (void)hipEventRecord(a, nullptr);
+    if (quad_sectors) k_rand_loads<true><<<blocks, 256>>>(t.as<uint4>(), table_bytes / 64, iters, out.as<uint32_t>());
+    else k_rand_loads<false><<<blocks, 256>>>(t.as<uint4>(), table_bytes / 64, iters, out.as<uint32_t>());
+    (void)hipEventRecord(b, nullptr);
+    if (hipEventSynchronize(b) != hipSuccess) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); ctx->err = "measurement kernel failed"; return PSIGPU_ERR_DEVICE; }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    if (rep && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  const double done = (double)threads * iters / (quad_sectors ? 4.0 : 1.0);
+  *loads_per_s = done / (best * 1e-3);
+  return PSIGPU_OK;
 }
 
 }  // extern "C"
@@ -4188,7 +4396,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     acc.n_reads += pc.n_reads; acc.n_seeds += pc.n_seeds; acc.n_seeds_valid += pc.n_seeds_valid;
     acc.n_seeds_on_path += pc.n_seeds_on_path; acc.n_hits_on_path += pc.n_hits_on_path;
     acc.n_hits_off_path += pc.n_hits_off_path; acc.n_kpaths += pc.n_kpaths; acc.n_spilled += pc.n_spilled;
-    acc.n_lf_steps += pc.n_lf_steps; acc.n_rows_verified += pc.n_rows_verified;
+    acc.n_lf_steps += pc.n_lf_steps; acc.n_rows_verified += pc.n_rows_verified; acc.n_locate_steps += pc.n_locate_steps;
     acc.n_loci = pc.n_loci; acc.n_locus_kmers = pc.n_locus_kmers; acc.n_path_kmers = pc.n_path_kmers;
     acc.n_loci_traversed = pc.n_loci_traversed; acc.ms_locus_table_build = pc.ms_locus_table_build;
     acc.ms_pack += pc.ms_pack; acc.ms_table += pc.ms_table; acc.ms_search += pc.ms_search; acc.ms_locate += pc.ms_locate;

@@ -4,8 +4,9 @@ kernel stats, PMC summary and per-launch traffic of the query kernels, per query
 import csv, glob, json, sys
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else 'r02'
-    for tag, mode in (('k', 'kmer_table'), ('l', 'locus_table'), ('t', 'traverse')):
+    rnd = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+    for tag, mode in (('k', 'kmer_table'), ('l', 'locus_table'), ('t', 'traverse'),
+                      ('f1', 'fm_lf_after_ftab'), ('f2', 'fm_lf_no_ftab'), ('f3', 'fm_lf_sa32')):
         d = 'gpurun_out/prof_%s' % tag
         try:
             t = json.load(open(d + '/traffic.json'))

@@ -48,5 +48,7 @@ for k,c,v,n in rows:
 mode="kmer-table"
 a="$ARGS".split()
 if "--mode" in a: mode=a[a.index("--mode")+1]
-json.dump({"args":"$ARGS","mode":mode,"per_launch":tr}, open(out+"/traffic.json","w"), indent=1)
+series=""
+if "--series" in a: series=a[a.index("--series")+1]
+json.dump({"args":"$ARGS","mode":mode,"series":series,"per_launch":tr}, open(out+"/traffic.json","w"), indent=1)
 PY
