@@ -194,7 +194,7 @@ def main():
     ap.add_argument('--sa-rate', type=int, default=1)
     ap.add_argument('--ftab', type=int, default=0, help='interval-table length (0 = auto, -1 = none)')
     ap.add_argument('--tune', type=int, default=0, help='psigpu_set_tuning flags of the main finder (1 no direct K1, 2 no text '
-                                                        'verification, 4 no row records, 8 lock-step LF kernel, 16 one seed per quad)')
+                                                        'verification, 4 no row records)')
     ap.add_argument('--series', default='', help="label of a roofline_by_mode['fm-lf'] point this run reproduces (traffic lookup)")
     ap.add_argument('--host-build', action='store_true', help='build the index on the host (SA-IS) instead of the GPU')
     ap.add_argument('--backbone', type=int, default=51_000_000)

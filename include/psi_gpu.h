@@ -281,13 +281,11 @@ int psigpu_set_query_mode(psigpu_ctx* ctx, uint32_t mode, uint32_t walk_cap);
 
 /* Measurement switches: A/B runs behind bench.py's roofline series (which kernel answers the on-path phase
  * of the FM modes).  The hit set never depends on them.  No counterpart in the reference. */
-#define PSIGPU_TUNE_NO_DIRECT 1u     /* K1 by the quad LF kernel only (k_fm_search_lf): no lane-per-seed kernel that finishes a
+#define PSIGPU_TUNE_NO_DIRECT 1u     /* K1 by the quad LF kernel only (k_fm_search): no lane-per-seed kernel that finishes a
                                         seed from its interval-table entry and the rows' records */
 #define PSIGPU_TUNE_NO_VERIFY 2u     /* every base of a seed by an LF step (fmindex.hpp:851-869 as written): small intervals
                                         are not finished by comparing the rows with the text */
 #define PSIGPU_TUNE_NO_ROWRECS 4u    /* no per-row records (SaRec, located suffix array): locate through SA + segment table */
-#define PSIGPU_TUNE_LF_LOCKSTEP 8u   /* the LF kernel of rounds 1-2 (16 quads of a wave in step) */
-#define PSIGPU_TUNE_LF_ONE 16u       /* decoupled quads, one seed in flight per quad (default: two) */
 int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags);
 
 /* Builds the tables of the current query mode for seed length k now (index load time) instead of

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('PSI_AMD_LIB') or os.path.join(_HERE, 'libpsi_gpu.so')
 
 ALL, ON_PATHS, OFF_PATHS, SORT_UNIQUE = 3, 1, 2, 4
 MAX_SEED_LEN = 31
-TUNE_NO_DIRECT, TUNE_NO_VERIFY, TUNE_NO_ROWRECS, TUNE_LF_LOCKSTEP, TUNE_LF_ONE = 1, 2, 4, 8, 16
+TUNE_NO_DIRECT, TUNE_NO_VERIFY, TUNE_NO_ROWRECS = 1, 2, 4
 
 
 class PsiGpuError(RuntimeError):

@@ -7,7 +7,7 @@
 //   K1  k_fm_search[_direct]                kmer_exact_matches descent include/psi/index_iter.hpp:835-841
 //                                           -> Iter::go_down           include/psi/fmindex.hpp:851-869
 //       k_kmer_probe                        the same result from the k-mer table (PSIGPU_MODE_KMER_TABLE)
-//   K2  k_fm_locate[_direct]                get_occurrences + mapping  include/psi/fmindex.hpp:734-777,
+//   K2  k_fm_locate_direct / k_fm_walk      get_occurrences + mapping  include/psi/fmindex.hpp:734-777,
 //                                                                      include/psi/pathindex.hpp:378-416
 //   K4  k_traverse<false>                   TraverserBFS::run          include/psi/traverser_bfs.hpp:72-161
 //       k_traverse<true>                    the same walks enumerated once per index (the tables)
@@ -725,131 +725,6 @@ k_fm_search(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __
   }
 }
 
-// The same search with the quads of a wave decoupled and NS seeds in flight per quad.  The kernel above keeps
-// its 16 quads in step: a round of 16 seeds lasts as long as its longest seed, and a quad whose seed died after
-// two steps (a read with an error, an N) idles for the rest of it.  Here every quad owns the seeds
-// start + 16 t of the wave's range, keeps NS of them in flight -- their rank blocks are requested together,
-// 2 NS independent 64-byte sectors per quad before the first popcount -- and takes the next seed the
-// moment one is finished.  What an LF step costs is the sector request (one per step once both interval
-// ends share a block), so the kernel's job is to keep the memory system's queue full and nothing else.
-template <int NS>
-__global__ void __launch_bounds__(256)
-k_fm_search_lf(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
-               uint64_t seeds_cap, uint32_t per_wave,
-               uint32_t k, uint32_t gocc_thr, uint32_t* __restrict__ iv_lo, uint32_t* __restrict__ iv_cnt,
-               uint32_t* __restrict__ iv_aux, uint64_t* __restrict__ wave_total, DevCounters* ctr,
-               const uint32_t* __restrict__ list, const unsigned long long* __restrict__ n_list)
-{
-  const bool can_verify = fm.text4 != nullptr && fm.sa != nullptr;
-  const bool listed = list != nullptr;
-  const uint32_t ql = threadIdx.x & 3, quad = (threadIdx.x & 63) >> 2;
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t n_seeds = min(params[0], seeds_cap);
-  const uint64_t s0 = listed ? wave * 16 : wave * per_wave;
-  const uint64_t s1 = listed ? min((uint64_t)*n_list, seeds_cap) : min(n_seeds, s0 + per_wave);
-  const uint64_t stride = listed ? ((uint64_t)gridDim.x * blockDim.x >> 6) * 16 : 16;
-  const bool use_ftab = fm.ftab != nullptr && k >= fm.ftab_len;
-  const uint32_t j0 = use_ftab ? fm.ftab_len : 0u;
-  const uint64_t qmask = use_ftab ? ((1ull << (2 * j0)) - 1ull) : 0ull;
-  uint32_t n_live = 0, n_steps = 0, n_rows = 0;
-  uint64_t wsum = 0;
-  uint64_t next = s0 + quad;                     // this quad's next item
-  uint64_t key[NS], seed[NS];
-  uint32_t l[NS], r[NS], jq[NS];
-  bool act[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) { act[s] = false; key[s] = 0; seed[s] = 0; l[s] = r[s] = jq[s] = 0; }
-  while (true) {
-    // ---- take new seeds into the free slots; a seed that is over at once (N, empty interval-table entry,
-    //      k <= q) is finished in `fin` below like any other ------------------------------------------
-    bool fin[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      fin[s] = false;
-      if (!act[s] && next < s1) {
-        seed[s] = listed ? list[next] : next;
-        next += stride;
-        key[s] = seed_key[seed[s]];
-        l[s] = 0; r[s] = fm.n; jq[s] = j0;
-        bool alive = key[s] != KEY_INVALID;
-        if (alive && use_ftab) {
-          const uint2 iv = fm.ftab[key[s] & qmask];
-          l[s] = iv.x; r[s] = iv.y;
-          alive = r[s] > l[s];
-        }
-        if (!alive) { l[s] = r[s] = 0; }
-        act[s] = true;
-        fin[s] = !alive || jq[s] >= k || (can_verify && (r[s] - l[s]) <= VERIFY_ROWS && (k - jq[s]) <= 16u);
-      }
-    }
-    bool any_act = false;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) any_act = any_act || act[s];
-    if (!__any(any_act)) break;
-    // ---- one LF step for every slot that is still searching: all blocks requested, then all ranks -------
-    uint4 vl[NS], vr[NS];
-    bool stp[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      stp[s] = act[s] && !fin[s];
-      vl[s] = make_uint4(0, 0, 0, 0); vr[s] = vl[s];
-      if (stp[s]) {
-        const uint32_t bl = l[s] / BLOCK_SYMS, br = r[s] / BLOCK_SYMS;
-        vl[s] = fm.blocks[(uint64_t)bl * 4 + ql];
-        vr[s] = vl[s];
-        if (br != bl) vr[s] = fm.blocks[(uint64_t)br * 4 + ql];
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (stp[s]) {
-        const uint32_t c = (uint32_t)(key[s] >> (2 * jq[s])) & 3u;
-        const uint32_t nl = fm.C[c] + quad_rank(fm, vl[s], ql, c, l[s]);
-        const uint32_t nr = fm.C[c] + quad_rank(fm, vr[s], ql, c, r[s]);
-        l[s] = nl; r[s] = nr;
-        ++jq[s];
-        n_steps += ql == 0;
-        const bool alive = r[s] > l[s];
-        fin[s] = !alive || jq[s] >= k || (can_verify && (r[s] - l[s]) <= VERIFY_ROWS && (k - jq[s]) <= 16u);
-      }
-    }
-    // ---- finished seeds: rows against the text (the quad's lanes take them four at a time), results out ---
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (!__any(fin[s])) continue;
-      const bool alive = fin[s] && r[s] > l[s];
-      uint32_t cnt = alive ? r[s] - l[s] : 0u, aux = 0, mask = 0;
-      const bool verify = alive && jq[s] < k;
-      const uint32_t rem = k - jq[s];
-      if (verify)
-        for (uint32_t t = ql; t < r[s] - l[s]; t += 4)
-          if (text_matches(fm.text4, fm.sa[l[s] + t], rem, key[s], k)) mask |= 1u << t;
-      mask = quad_sum(mask);                       // disjoint bits: sum == or
-      if (verify) { n_rows += ql == 0 ? r[s] - l[s] : 0u; cnt = (uint32_t)__popc(mask); aux = (rem << 8) | mask; }
-      const bool keep = cnt != 0 && cnt <= gocc_thr;        // index_iter.hpp:843-847
-      if (fin[s] && ql == 0) {
-        iv_lo[seed[s]] = l[s];
-        iv_cnt[seed[s]] = keep ? cnt : 0u;
-        iv_aux[seed[s]] = aux;
-        n_live += keep;
-        wsum += keep ? cnt : 0u;
-        if (listed && keep) atomicAdd((unsigned long long*)&wave_total[seed[s] / per_wave], (unsigned long long)cnt);
-      }
-      if (fin[s]) act[s] = false;
-    }
-  }
-  for (int d = 32; d > 0; d >>= 1) {
-    n_live += __shfl_down(n_live, d); wsum += __shfl_down(wsum, d);
-    n_steps += __shfl_down(n_steps, d); n_rows += __shfl_down(n_rows, d);
-  }
-  if (lane_id() == 0) {
-    if (!listed) wave_total[wave] = wsum;
-    if (n_live) ctr->n_live.add((unsigned long long)n_live);
-    if (n_steps) ctr->n_lf_steps.add((unsigned long long)n_steps);
-    if (n_rows) ctr->n_rows_verified.add((unsigned long long)n_rows);
-  }
-}
-
 // exclusive scan of the per-wave totals (at most WAVES_MAX values): one workgroup of 1024 threads,
 // WAVES_MAX / 1024 values per thread, wave shuffles + one LDS hop
 constexpr int WAVES_MAX = 8192;       // waves of K1 / the probe / K2: all resident at once (16 K and 32 K measured slower)
@@ -898,10 +773,8 @@ k_wave_offsets(uint64_t* wave_total, const uint64_t* __restrict__ wave_total_off
 }
 
 // ------------------------------------------------------------------------------------
-// K2: locate + map + emit, one quad per live seed.
-// SA value by LF-walking to the next sampled row (csa[i] behind fmindex.hpp:734-748);
-// text position -> (node, offset) through the segment table (StringSet::get_position
-// sequence.hpp:539-546 + position_to_id/offset pathindex.hpp:378-416 in one step).
+// K2: locate + map + emit.  What every K2 variant reads of the index (k_fm_locate_direct and k_kmer_emit
+// when the whole suffix array is resident, k_fm_walk + k_hits_resolve when it is sampled).
 // ------------------------------------------------------------------------------------
 struct MapView {
   const uint32_t* samples; uint32_t sa_rate;
@@ -1660,119 +1533,158 @@ k_fm_search_direct(FMView fm, LktView lk, const uint64_t* __restrict__ seed_key,
   }
 }
 
+// ------------------------------------------------------------------------------------
+// K2 for a sampled suffix array (sa_rate > 1), in two kernels.
+//
+// k_fm_walk: every on-path occurrence is LF-walked to a sampled row (csa[i] behind fmindex.hpp:734-748).
+// With SA-order sampling -- rows i % s == 0 keep their value, as sdsl's csa_wt<wt_huff<>, 32, 64> does -- a
+// walk ends with probability 1/s per step: lengths are geometric, mean s - 1, and the longest of 16 is
+// about 3.4 times the mean.  A kernel that keeps the 16 quads of a wave in step (rounds 1-2) runs at a fifth
+// of the rate the walks themselves allow (9.5 ms against 3.0 for the pair below, profiles/r03_lf_ab_locate.jsonl);
+// here the quads are decoupled.  A wave stages 64 seeds of its range in
+// registers (interval, count, first output slot: one coalesced load and one wave scan per 64 seeds), and a
+// quad whose walk has ended takes the next staged seed through shuffles -- no memory access on that path --
+// so every quad issues exactly one sector request per iteration (a rank block, or the sample that ends the
+// walk) whatever the others are doing.  Out: 12 bytes per hit (text position | occurrence number, seed).
+//
+// k_hits_resolve: one lane per hit -- text position -> segment -> (node, offset), or the locus of a table
+// hit -- and the 32-byte record (StringSet::get_position sequence.hpp:539-546 + position_to_id/offset
+// pathindex.hpp:378-416 in one step).  Independent lanes, nothing to wait for but their own loads.
+// ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_fm_locate(FMView fm, MapView mv, const uint32_t* __restrict__ iv_lo, const uint32_t* __restrict__ iv_cnt,
-            const uint32_t* __restrict__ off_first, const uint32_t* __restrict__ off_cnt,
-            const uint32_t* __restrict__ off_noff,
-            const LocusEnt* __restrict__ ent, const uint64_t* __restrict__ wave_off, const uint64_t* __restrict__ params, uint64_t seeds_cap,
-            uint32_t per_wave,
-            const uint2* __restrict__ seed_info, uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap,
-            DevCounters* ctr)
+k_fm_walk(FMView fm, const uint32_t* __restrict__ samples, uint32_t sa_rate, const uint32_t* __restrict__ exc_sa,
+          const uint32_t* __restrict__ iv_lo, const uint32_t* __restrict__ iv_cnt, const uint32_t* __restrict__ off_cnt,
+          const uint64_t* __restrict__ wave_off, const uint64_t* __restrict__ params, uint64_t seeds_cap, uint32_t per_wave,
+          uint64_t* __restrict__ hit_a, uint32_t* __restrict__ hit_seed, uint64_t cap, DevCounters* ctr)
 {
-  const uint32_t ql = threadIdx.x & 3, quad = (threadIdx.x & 63) >> 2;
+  __shared__ uint8_t sel_all[4][64];             // per wave: the staged seeds that have on-path occurrences, compacted
+  const uint32_t lane = lane_id(), ql = lane & 3, wib = threadIdx.x >> 6;
+  uint8_t* sel = sel_all[wib];
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t n_items = min(params[0], seeds_cap);
   const uint64_t s0 = wave * per_wave, s1 = min(n_items, s0 + per_wave);
-  uint64_t woff = s0 < s1 ? wave_off[wave] : 0;       // first output slot of this wave
-  uint32_t n_walk = 0;
-  for (uint64_t base = s0; base < s1; base += 16) {
-    const uint64_t item = base + quad;
-    const bool have = item < s1;
-    SeedIv e = { 0, 0 };
-    uint32_t coff = 0, ofirst = 0;             // the table's loci follow the on-path occurrences
-    bool inl = false;
-    if (have) {
-      e.lo = iv_lo[item]; e.cnt = iv_cnt[item];
-      if (off_cnt) {
-        coff = off_cnt[item]; ofirst = off_first[item];
-        inl = (coff & OFF_INLINE) != 0; coff &= ~OFF_INLINE;
-      }
-    }
-    // exclusive prefix of the 16 quads' counts (each quad's lanes all hold its count)
-    uint32_t incl = (ql == 0) ? e.cnt + coff : 0u;
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t t = (uint32_t)__shfl_up((int)incl, d);
-      if (lane_id() >= (uint32_t)d) incl += t;
-    }
-    uint32_t round_total = (uint32_t)__shfl((int)incl, 63);
-    // lane 4q+3 holds the inclusive sum through quad q; quad q's exclusive sum = that minus its count
-    uint32_t incl_q = (uint32_t)__shfl((int)incl, (int)(quad * 4 + 3));
-    uint64_t out0 = woff + (incl_q - (e.cnt + coff));
-    woff += round_total;
-    if (!__any(e.cnt + coff != 0)) continue;
-    if (coff) {
-      uint2 si = seed_info[item];
-      for (uint32_t o = ql; o < coff; o += 4) {
-        uint64_t rec = out0 + e.cnt + o;
-        if (rec < cap) {
-          struct { uint64_t node_id; uint32_t noff; } le;
-          uint2 lc = make_uint2(ofirst, 0);
-          if (inl) lc.y = off_noff[item]; else lc = mv.loci[ent[ofirst + o]];
-          le.node_id = mv.id_affine ? mv.id_base + lc.x : mv.node_id[lc.x]; le.noff = lc.y;
-          ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + rec);
-          dst[0] = make_ulonglong2(le.node_id, (uint64_t)le.noff);
-          dst[1] = make_ulonglong2(rec_offset + si.x, (uint64_t)si.y);
+  uint64_t woff = s0 < s1 ? wave_off[wave] : 0;       // next output slot of this wave
+  uint64_t cursor = s0, win_base = s0;                // seeds [win_base, win_base + 64) are staged; cursor = next to stage
+  uint32_t w_lo = 0, w_cnt = 0, win_n = 0, taken = 0;
+  uint64_t w_out0 = 0;
+  bool have = false;
+  uint32_t row = 0, steps = 0, occ = 0, q_lo = 0, q_cnt = 0, q_seed = 0, n_walk = 0;
+  uint64_t q_out0 = 0;
+  const uint64_t leaders = 0x1111111111111111ull;      // lane 0 of every quad
+  while (true) {
+    const uint64_t nm = __ballot(!have) & leaders;       // quads without a walk
+    if (nm) {
+      if (taken == win_n && cursor < s1) {
+        // stage the next 64 seeds; the table hits among them are described right here (no walk)
+        const uint64_t item = cursor + lane;
+        const bool in = item < s1;
+        w_lo = in ? iv_lo[item] : 0u;
+        w_cnt = in ? iv_cnt[item] : 0u;
+        const uint32_t coff = (in && off_cnt) ? (off_cnt[item] & ~OFF_INLINE) : 0u;
+        uint32_t incl = w_cnt + coff;
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+          if (lane >= (uint32_t)d) incl += t;
         }
+        w_out0 = woff + (incl - (w_cnt + coff));
+        woff += (uint32_t)__shfl((int)incl, 63);
+        for (uint32_t o = 0; o < coff; ++o) {
+          const uint64_t h = w_out0 + w_cnt + o;
+          if (h < cap) { hit_a[h] = (uint64_t)(w_cnt + o) << 32; hit_seed[h] = (uint32_t)item; }
+        }
+        const uint64_t m = __ballot(w_cnt != 0);
+        if (w_cnt) sel[__popcll(m & lanemask_lt())] = (uint8_t)lane;
+        win_n = (uint32_t)__popcll(m); taken = 0;
+        win_base = cursor;
+        cursor += 64;
+        __builtin_amdgcn_wave_barrier();
       }
+      // quads without a walk take staged seeds in order
+      const uint32_t idx = taken + (uint32_t)__popcll(nm & ((1ull << (lane & ~3u)) - 1ull));     // quads in front that also take one
+      const bool gets = !have && idx < win_n;
+      const int src = gets ? (int)sel[idx] : 0;
+      const uint32_t lo_ = (uint32_t)__shfl((int)w_lo, src), cnt_ = (uint32_t)__shfl((int)w_cnt, src);
+      const uint64_t out_ = __shfl(w_out0, src);
+      if (gets) { have = true; q_lo = lo_; q_cnt = cnt_; q_out0 = out_; q_seed = (uint32_t)(win_base + (uint32_t)src); occ = 0; row = lo_; steps = 0; }
+      taken = min(win_n, taken + (uint32_t)__popcll(nm));
     }
-    uint32_t maxcnt = e.cnt;
-    for (int d = 32; d > 0; d >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor((int)maxcnt, d));
-    for (uint32_t occ = 0; occ < maxcnt; ++occ) {
-      bool act = have && occ < e.cnt;
-      uint32_t row = e.lo + occ, steps = 0, pos = 0;
-      bool walking = act;
-      while (__any(walking)) {
-        if (walking) {
-          if ((row & (mv.sa_rate - 1)) == 0) {
-            pos = mv.samples[row / mv.sa_rate] + steps;
-            walking = false;
-          } else {
-            uint32_t blk = row / BLOCK_SYMS, off = row - blk * BLOCK_SYMS;
-            uint4 v = fm.blocks[(uint64_t)blk * 4 + ql];
-            // BWT[row]: owner lane extracts the symbol, quad-sum broadcasts it
-            uint32_t sym = 0;
-            if (ql == 1 + off / 64) {
-              uint32_t o = off & 63;
-              uint32_t lo = o < 32 ? v.x : v.y, hi = o < 32 ? v.z : v.w;
-              sym = ((lo >> (o & 31)) & 1u) | (((hi >> (o & 31)) & 1u) << 1);
-            }
-            sym = quad_sum(sym);
-            // is this row an exception (separator / sentinel in the BWT)?  header is on lane 0
-            uint32_t ex = 0;
-            if (ql == 0 && (v.w & 0xFF) != 0) {
-              uint32_t e0 = v.w >> 8, ne = v.w & 0xFF;
-              uint32_t end = (ne == 255) ? fm.n_exc : e0 + ne;
-              for (uint32_t q = e0; q < end; ++q) {
-                uint32_t rr = fm.exc_row[q];
-                if (rr == row) { ex = q + 1; break; }
-                if (rr > row) break;
-              }
-            }
-            ex = quad_bcast0(ex);
-            if (ex) {
-              pos = mv.exc_sa[ex - 1] + steps;
-              walking = false;
-            } else {
-              row = fm.C[sym] + quad_rank(fm, v, ql, sym, row);
-              ++steps;
-              n_walk += ql == 0;
-            }
+    if (!__any(have)) {
+      if (cursor >= s1 && taken == win_n) break;
+      continue;
+    }
+    // ---- one sector request per walking quad: the rank block of its row, or the sample that ends the walk ----
+    if (have) {
+      bool done = false;
+      uint32_t pos = 0;
+      if ((row & (sa_rate - 1)) == 0) {
+        pos = samples[row / sa_rate] + steps;
+        done = true;
+      } else {
+        const uint32_t blk = row / BLOCK_SYMS, off = row - blk * BLOCK_SYMS;
+        const uint4 v = fm.blocks[(uint64_t)blk * 4 + ql];
+        uint32_t sym = 0;                         // BWT[row]: the owning lane extracts it, the quad sum hands it round
+        if (ql == 1 + off / 64) {
+          const uint32_t o = off & 63;
+          const uint32_t lo = o < 32 ? v.x : v.y, hi = o < 32 ? v.z : v.w;
+          sym = ((lo >> (o & 31)) & 1u) | (((hi >> (o & 31)) & 1u) << 1);
+        }
+        sym = quad_sum(sym);
+        uint32_t ex = 0;                          // a separator / the sentinel in the BWT: its SA value is stored
+        if (ql == 0 && (v.w & 0xFF) != 0) {
+          const uint32_t e0 = v.w >> 8, ne = v.w & 0xFF;
+          const uint32_t end = (ne == 255) ? fm.n_exc : e0 + ne;
+          for (uint32_t q = e0; q < end; ++q) {
+            const uint32_t rr = fm.exc_row[q];
+            if (rr == row) { ex = q + 1; break; }
+            if (rr > row) break;
           }
         }
+        ex = quad_bcast0(ex);
+        if (ex) { pos = exc_sa[ex - 1] + steps; done = true; }
+        else { row = fm.C[sym] + quad_rank(fm, v, ql, sym, row); ++steps; n_walk += ql == 0; }
       }
-      if (act && ql == 0 && out0 + occ < cap) {
-        uint32_t d = mv.seg_dir[pos >> DIR_SHIFT];
-        while (mv.seg[d + 1].start <= pos) ++d;
-        SegRec sr = mv.seg[d];
-        uint2 si = seed_info[item];
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + out0 + occ);
-        dst[0] = make_ulonglong2(sr.node_id, (uint64_t)sr.noff + (pos - sr.start));
-        dst[1] = make_ulonglong2(rec_offset + si.x, (uint64_t)si.y);
+      if (done) {
+        const uint64_t h = q_out0 + occ;
+        if (ql == 0 && h < cap) { hit_a[h] = (uint64_t)pos | ((uint64_t)occ << 32); hit_seed[h] = q_seed; }
+        ++occ;
+        if (occ < q_cnt) { row = q_lo + occ; steps = 0; }
+        else have = false;
       }
     }
   }
   for (int d = 32; d > 0; d >>= 1) n_walk += __shfl_down(n_walk, d);
-  if (lane_id() == 0 && n_walk) ctr->n_locate_steps.add((unsigned long long)n_walk);
+  if (lane == 0 && n_walk) ctr->n_locate_steps.add((unsigned long long)n_walk);
+}
+
+__global__ void __launch_bounds__(256)
+k_hits_resolve(MapView mv, const uint64_t* __restrict__ hit_a, const uint32_t* __restrict__ hit_seed,
+               const uint32_t* __restrict__ iv_cnt, const uint32_t* __restrict__ off_first, const uint32_t* __restrict__ off_cnt,
+               const uint32_t* __restrict__ off_noff, const LocusEnt* __restrict__ ent, const unsigned long long* __restrict__ n_hits,
+               const uint2* __restrict__ seed_info, uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap)
+{
+  const uint64_t n = min((uint64_t)*n_hits, cap);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n; h += stride) {
+    const uint64_t a = hit_a[h];
+    const uint32_t seed = hit_seed[h], occ = (uint32_t)(a >> 32), pos = (uint32_t)a;
+    const uint32_t con = iv_cnt[seed];
+    const uint2 si = seed_info[seed];
+    uint64_t nid, noff;
+    if (occ < con) {
+      uint32_t d = mv.seg_dir[pos >> DIR_SHIFT];
+      while (mv.seg[d + 1].start <= pos) ++d;
+      const SegRec sr = mv.seg[d];
+      nid = sr.node_id; noff = (uint64_t)sr.noff + (pos - sr.start);
+    } else {
+      uint2 lc = make_uint2(off_first[seed], 0);
+      if (off_cnt[seed] & OFF_INLINE) lc.y = off_noff[seed];
+      else lc = mv.loci[ent[lc.x + (occ - con)]];
+      nid = mv.id_affine ? mv.id_base + lc.x : mv.node_id[lc.x]; noff = lc.y;
+    }
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + h);
+    dst[0] = make_ulonglong2(nid, noff);
+    dst[1] = make_ulonglong2(rec_offset + si.x, (uint64_t)si.y);
+  }
 }
 
 // One hit of a seed: occurrence `occ` of its `con` on-path rows, or entry occ - con of its run in
@@ -2517,7 +2429,7 @@ struct psigpu_ctx {
   uint64_t lkt_ht_size = 0, lkt_n_ent = 0, lkt_n_res = 0, lkt_n_walks = 0;
   float lkt_build_ms = 0.f;
   std::string lkt_note;
-  DevBuf w_seedout, w_seedres, w_iv_tiles_off, w_defer;
+  DevBuf w_seedout, w_seedres, w_iv_tiles_off, w_defer, w_hit_a, w_hit_seed;
   // per-call workspace (grow-only)
   DevBuf w_bases, w_read_off, w_cnt, w_tiles, w_seed_off, w_seed_key, w_seed_info,
       w_seed_next, w_ht, w_pfx, w_pfx12, w_iv_lo, w_iv_cnt, w_iv_aux, w_hit_off, w_iv_tiles,
@@ -2653,7 +2565,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
                     &ctx->w_iv_tiles_off, &ctx->w_defer, &ctx->sarec, &ctx->saloc, &ctx->kt_ht, &ctx->kt_ext, &ctx->seg_rank, &ctx->w_seedres };
   for (auto* b : all) b->release();
   ctx->ids_sorted.release(); ctx->w_sorted[0].release(); ctx->w_sorted[1].release(); ctx->w_count.release();
-  ctx->kt_onpos.release();
+  ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release();
   for (auto& m : ctx->more) { m->samples.release(); m->text4.release(); m->seg.release(); m->seg_dir.release(); m->seg_rank.release(); }
   ctx->w_hits_alt.release();
   for (auto& sl : ctx->slot) {
@@ -3642,18 +3554,10 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         LktView lk = { nullptr, 0, nullptr };
         if (probe) lk = LktView{ ctx->lkt_ht.as<TableSlot>(), ctx->lkt_ht_size, ctx->lkt_ent.as<LocusEnt>() };
         bool probed = false;
-        // the quad LF kernel: lock-step rounds (PSIGPU_TUNE_LF_LOCKSTEP, the round-1 kernel, kept for A/B), or
-        // decoupled quads with one / two seeds in flight each
         auto launch_lf = [&](unsigned g_, const uint32_t* list_, const unsigned long long* n_list_) {
-          uint64_t* keys_ = ctx->w_seed_key.as<uint64_t>();
-          uint32_t* lo_ = ctx->w_iv_lo.as<uint32_t>(); uint32_t* cnt_ = ctx->w_iv_cnt.as<uint32_t>(); uint32_t* aux_ = ctx->w_iv_aux.as<uint32_t>();
-          uint64_t* tiles_ = ctx->w_iv_tiles.as<uint64_t>();
-          if (ctx->tune & PSIGPU_TUNE_LF_LOCKSTEP)
-            k_fm_search<<<g_, 256, 0, stream>>>(fm, keys_, d_params, n_seeds, per_wave, k, thr, lo_, cnt_, aux_, tiles_, ctr, list_, n_list_);
-          else if (ctx->tune & PSIGPU_TUNE_LF_ONE)
-            k_fm_search_lf<1><<<g_, 256, 0, stream>>>(fm, keys_, d_params, n_seeds, per_wave, k, thr, lo_, cnt_, aux_, tiles_, ctr, list_, n_list_);
-          else
-            k_fm_search_lf<2><<<g_, 256, 0, stream>>>(fm, keys_, d_params, n_seeds, per_wave, k, thr, lo_, cnt_, aux_, tiles_, ctr, list_, n_list_);
+          k_fm_search<<<g_, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr,
+                                              ctx->w_iv_lo.as<uint32_t>(), ctx->w_iv_cnt.as<uint32_t>(), ctx->w_iv_aux.as<uint32_t>(),
+                                              ctx->w_iv_tiles.as<uint64_t>(), ctr, list_, n_list_);
         };
         if (kprobe) {
           KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
@@ -3698,11 +3602,17 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
       else if (ctx->sa_rate == 1)
         k_fm_locate_direct<<<grid, 256, 0, stream>>>(mv, so, probe, oe, ctx->w_iv_tiles.as<uint64_t>(), d_params, n_seeds,
                                                      per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap);
-      else
-        k_fm_locate<<<grid, 256, 0, stream>>>(fm, mv, so.iv_lo, so.iv_cnt, probe ? so.off_first : nullptr,
-                                              probe ? so.off_cnt : nullptr, so.off_noff, oe,
-                                              ctx->w_iv_tiles.as<uint64_t>(), d_params, n_seeds, per_wave,
-                                              ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap, ctr);
+      else {
+        // walks (decoupled quads) -> 12 bytes per hit -> records
+        HIPCHK(ctx, ctx->w_hit_a.ensure((cap + 1) * 8));
+        HIPCHK(ctx, ctx->w_hit_seed.ensure((cap + 1) * 4));
+        k_fm_walk<<<grid, 256, 0, stream>>>(fm, mv.samples, mv.sa_rate, mv.exc_sa, so.iv_lo, so.iv_cnt, probe ? so.off_cnt : nullptr,
+                                            ctx->w_iv_tiles.as<uint64_t>(), d_params, n_seeds, per_wave,
+                                            ctx->w_hit_a.as<uint64_t>(), ctx->w_hit_seed.as<uint32_t>(), cap, ctr);
+        k_hits_resolve<<<2048, 256, 0, stream>>>(mv, ctx->w_hit_a.as<uint64_t>(), ctx->w_hit_seed.as<uint32_t>(), so.iv_cnt,
+                                                 so.off_first, so.off_cnt, so.off_noff, oe, &ctr->n_hits_tab.v,
+                                                 ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap);
+      }
     } else {
       EVREC(10, stream);
       EVREC(4, stream);

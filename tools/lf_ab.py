@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of the LF (backward-search) kernels on the chr22-like workload, locus-table mode:
-lock-step quads (rounds 1-2) / decoupled quads with one or two seeds in flight, on three indexes
-(interval table 13 + LF for the rest, no interval table, SA sampled at 32).  Prints one JSON line per
+"""A/B of the FM kernels on the chr22-like workload, locus-table mode, on three indexes (interval table 13,
+no interval table, SA sampled at 32): lane-per-seed K1 / quad LF kernel with and without text verification;
+decoupled walk + resolve kernels against the lock-step locate kernel of rounds 1-2.  Prints one JSON line per
 (index, variant): K1 / K2 / step times from the library's HIP events, LF steps, hits (must agree).
 `python tools/lf_ab.py [reads] [backbone] [snvs]`."""
 import json
@@ -39,9 +39,10 @@ def main():
     for label, kw in (('ftab13', {}), ('no_ftab', dict(ftab_len=psi_amd.NO_FTAB)), ('sa32', dict(sa_rate=32))):
         ix = psi_amd.PathIndex.build(g, k, 1, rng_seed=1, device=0, **kw)
         want = {}
-        for vname, tune in (('direct (default)', 0), ('lf2 + verify', T.TUNE_NO_DIRECT), ('lf1 + verify', T.TUNE_NO_DIRECT | T.TUNE_LF_ONE),
-                            ('lockstep + verify', T.TUNE_NO_DIRECT | T.TUNE_LF_LOCKSTEP),
-                            ('lf2', NO_DV), ('lf1', NO_DV | T.TUNE_LF_ONE), ('lockstep', NO_DV | T.TUNE_LF_LOCKSTEP)):
+        variants = [('default', 0), ('quad K1 + verify', T.TUNE_NO_DIRECT), ('quad K1, LF only', NO_DV)]
+        if label == 'sa32':
+            variants = [('walk + resolve', 0)]
+        for vname, tune in variants:
             f = psi_amd.SeedFinder(g, k, mode='locus-table')
             f.set_tuning(tune)
             f.set_path_index(ix)
