@@ -87,7 +87,10 @@ typedef struct psigpu_graph_view {
  *   u32 cntA, cntC, cntG, u32 (exceptions_before << 8 | exceptions_in_block), then
  *   192 symbols as three 16-byte groups of 64 (u64 low-bit plane, u64 high-bit plane).
  *   cntT is derived.  Separators / the sentinel are stored as 'A' and
- *   listed in exc_row (sorted BWT rows) with their suffix-array values in exc_sa. */
+ *   listed in exc_row (sorted BWT rows) with their suffix-array values in exc_sa.
+ *   exceptions_before counts from the start of the block's SUPER-BLOCK of 2^exc_shift blocks; the
+ *   exceptions in front of every super-block are in exc_super -- any number of separators fits
+ *   (the patches of a whole genome are tens of millions). */
 typedef struct psigpu_index_view {
   uint32_t seed_len;            /* k the starting loci were computed for */
   uint32_t sa_rate;             /* SA-order sampling: SA[i] kept for i % sa_rate == 0 */
@@ -106,7 +109,7 @@ typedef struct psigpu_index_view {
    * steps collapsed into one lookup): entry c = SA interval [lo, hi) of the ftab_len-mer with
    * 2-bit code c (first base most significant); 4^ftab_len entries of 2 x u32; 0 = none */
   uint32_t ftab_len;
-  uint32_t reserved0;
+  uint32_t exc_shift;           /* log2 of the rank blocks per exception super-block (16) */
   const uint32_t* ftab;
   /* the indexed text itself, 4 bits per symbol (bits 0..1 base, bit 2 separator / sentinel),
    * 16 symbols per u64, first symbol in the top nibble: lets small SA intervals be finished by
@@ -124,13 +127,16 @@ typedef struct psigpu_index_view {
   const uint32_t* loci_node;
   const uint32_t* loci_off;
   /* further PARTS of the index: rows, text positions and table indexes are 32 bits wide, so paths
-   * whose concatenation would pass 2^32 symbols are indexed in groups, each with a text, FM arrays and
-   * a segment table of its own (the fields from text_len to seg_dir; seed_len, n_paths, the loci and
-   * this list are read from the first part only).  An index in several parts is answered from the
-   * k-mer table (PSIGPU_MODE_KMER_TABLE): its k-mers are tabulated over all parts at psigpu_prepare. */
+   * whose concatenation would pass 2^32 symbols are indexed in groups, each a complete FM index of its
+   * own -- text, rank blocks, exceptions, interval table, suffix array, segment table (the fields from
+   * text_len to seg_dir and exc_super; seed_len, n_paths, the loci and this list are read from the first
+   * part only).  The FM modes and MEM mode search every part (a pattern never spans two paths: the parts'
+   * occurrences are disjoint, a k-mer's occurrence count is their sum); the k-mer table tabulates the
+   * k-mers of all parts together at psigpu_prepare. */
   uint32_t n_more_parts;
   uint32_t reserved2;
   const struct psigpu_index_view* more_parts;     /* [n_more_parts] */
+  const uint32_t* exc_super;    /* [((n_blocks - 1) >> exc_shift) + 1] exceptions in front of every super-block */
 } psigpu_index_view;
 
 /* ------------------------------------------------------------------------------------
@@ -177,7 +183,8 @@ typedef struct psigpu_index_opts {
   uint32_t reserved1;
   uint64_t max_part_text;  /* text symbols per index part; 0 = the 32-bit row limit (2^32 - 256 on the device,
                               2^31 - 16 on the host).  An index whose paths do not fit one part is made in
-                              several (whole-genome graphs with several indexed walks); tests set it small */
+                              several (whole-genome graphs with several indexed walks), each a complete FM
+                              index; tests set it small */
 } psigpu_index_opts;
 
 /* SeedFinder::create_path_index(n, patched, context, step_size, ...) (seed_finder.hpp:1330-1355):

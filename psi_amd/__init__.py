@@ -53,12 +53,12 @@ class IndexView(C.Structure):
                 ('n_paths', C.c_uint32), ('text_len', C.c_uint64), ('n_blocks', C.c_uint64),
                 ('bwt_blocks', C.c_void_p), ('C', C.c_uint64 * 4), ('n_samples', C.c_uint64),
                 ('sa_samples', C.c_void_p), ('n_exc', C.c_uint64), ('exc_row', C.c_void_p),
-                ('exc_sa', C.c_void_p), ('ftab_len', C.c_uint32), ('reserved0', C.c_uint32),
+                ('exc_sa', C.c_void_p), ('ftab_len', C.c_uint32), ('exc_shift', C.c_uint32),
                 ('ftab', C.c_void_p), ('text4', C.c_void_p), ('n_segs', C.c_uint64), ('seg_start', C.c_void_p),
                 ('seg_node', C.c_void_p), ('seg_noff', C.c_void_p), ('n_dir', C.c_uint64),
                 ('seg_dir', C.c_void_p), ('n_loci', C.c_uint64), ('loci_node', C.c_void_p),
                 ('loci_off', C.c_void_p), ('n_more_parts', C.c_uint32), ('reserved2', C.c_uint32),
-                ('more_parts', C.c_void_p)]
+                ('more_parts', C.c_void_p), ('exc_super', C.c_void_p)]
 
 
 class IndexOpts(C.Structure):

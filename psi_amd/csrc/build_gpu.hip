@@ -99,15 +99,18 @@ __global__ void k_block_counts(const uint8_t* __restrict__ T, const uint32_t* __
 __global__ void k_block_build(const uint8_t* __restrict__ T, const uint32_t* __restrict__ sa, uint32_t n, uint32_t nblk,
                               const uint32_t* __restrict__ pA, const uint32_t* __restrict__ pC,
                               const uint32_t* __restrict__ pG, const uint32_t* __restrict__ pE,
-                              const uint32_t* __restrict__ cE, RankBlock* __restrict__ blocks,
-                              uint32_t* __restrict__ exc_row, uint32_t* __restrict__ exc_sa)
+                              const uint32_t* __restrict__ cE, uint32_t exc_shift, RankBlock* __restrict__ blocks,
+                              uint32_t* __restrict__ exc_row, uint32_t* __restrict__ exc_sa, uint32_t* __restrict__ exc_super)
 {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk) return;
   RankBlock B;
   B.cnt[0] = pA[b]; B.cnt[1] = pC[b]; B.cnt[2] = pG[b];
   uint32_t ne = cE[b];
-  B.exc = (pE[b] << 8) | min(ne, 255u);
+  // exceptions in front of the block, counted from its super-block's start (the header field has 24 bits)
+  const uint32_t sb = (b >> exc_shift) << exc_shift;
+  if (b == sb) exc_super[b >> exc_shift] = pE[b];
+  B.exc = ((pE[b] - pE[sb]) << 8) | min(ne, 255u);
   for (int w = 0; w < 6; ++w) B.sym[w] = 0;
   uint32_t lo = b * BLOCK_SYMS, hi = min(n, lo + BLOCK_SYMS), e = pE[b];
   for (uint32_t i = lo; i < hi; ++i) {
@@ -214,7 +217,7 @@ int scan_u32(uint32_t* in, uint32_t* out, size_t n, bool exclusive_sum, Buf& tmp
 // T: the text in builder coding (0 sentinel, 1 separator, 2..5 ACGT), sentinel last.
 // Fills x->blocks, samples, exc_row, exc_sa, C, ftab, text4 (and *sa_out when requested).
 int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, int device, Index* x,
-                 std::vector<int32_t>* sa_out, bool want_fm, std::string* err)
+                 std::vector<int32_t>* sa_out, std::string* err)
 {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -278,9 +281,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
     GB_CHK(hipMemcpy(sa_out->data(), sa_cur, (size_t)n * 4, hipMemcpyDeviceToHost));
   }
 
-  // ---- BWT rank blocks + exceptions (not for an index that is only ever tabulated: several parts, or
-  //      more separators than a block header can count) --------------------------------------------------
-  if (want_fm) {
+  {
   // ---- BWT rank blocks + exceptions ------------------------------------------------------------
   const uint32_t nblk = n / BLOCK_SYMS + 1;
   Buf cA, cC, cG, cE, cT, pA, pC, pG, pE, dblocks, dexc_row, dexc_sa;
@@ -299,12 +300,18 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
   for (int i = 0; i < 5; ++i) GB_CHK(hipMemcpy(&lastc[i], cs[i]->as<uint32_t>() + (nblk - 1), 4, hipMemcpyDeviceToHost));
   const uint64_t totA = (uint64_t)lastp[0] + lastc[0], totC = (uint64_t)lastp[1] + lastc[1];
   const uint64_t totG = (uint64_t)lastp[2] + lastc[2], totE = (uint64_t)lastp[3] + lastc[3];
-  if (totE >= (1u << 24)) { *err = "too many separators in the indexed text"; return PSIGPU_ERR_ARG; }
+  const uint32_t xs = x->exc_shift;
+  const size_t n_super = ((size_t)(nblk - 1) >> xs) + 1;
+  Buf dsuper;
   GB_CHK(dblocks.alloc((size_t)nblk * sizeof(RankBlock)));
   GB_CHK(dexc_row.alloc((size_t)(totE + 1) * 4)); GB_CHK(dexc_sa.alloc((size_t)(totE + 1) * 4));
+  GB_CHK(dsuper.alloc(n_super * 4));
   k_block_build<<<grid_for(nblk), 256>>>(dT.as<uint8_t>(), sa_cur, n, nblk, pA.as<uint32_t>(), pC.as<uint32_t>(),
-                                         pG.as<uint32_t>(), pE.as<uint32_t>(), cE.as<uint32_t>(),
-                                         dblocks.as<RankBlock>(), dexc_row.as<uint32_t>(), dexc_sa.as<uint32_t>());
+                                         pG.as<uint32_t>(), pE.as<uint32_t>(), cE.as<uint32_t>(), xs,
+                                         dblocks.as<RankBlock>(), dexc_row.as<uint32_t>(), dexc_sa.as<uint32_t>(),
+                                         dsuper.as<uint32_t>());
+  x->exc_super.resize(n_super);
+  GB_CHK(hipMemcpy(x->exc_super.data(), dsuper.p, n_super * 4, hipMemcpyDeviceToHost));
   x->blocks.resize(nblk);
   GB_CHK(hipMemcpy(x->blocks.data(), dblocks.p, (size_t)nblk * sizeof(RankBlock), hipMemcpyDeviceToHost));
   x->exc_row.resize(totE); x->exc_sa.resize(totE);
@@ -332,7 +339,6 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
   }
 
   // ---- interval table --------------------------------------------------------------------------------
-  if (!want_fm) q = 0;
   x->ftab_len = q;
   x->ftab.clear();
   if (q) {

@@ -194,7 +194,8 @@ static void fill_view(const Index& x, const Index& first, psigpu_index_view* v)
   for (int i = 0; i < 4; ++i) v->C[i] = x.C[i];
   v->n_samples = x.samples.size(); v->sa_samples = x.samples.data();
   v->n_exc = x.exc_row.size(); v->exc_row = x.exc_row.data(); v->exc_sa = x.exc_sa.data();
-  v->ftab_len = x.ftab_len; v->reserved0 = 0; v->ftab = x.ftab.empty() ? nullptr : x.ftab.data();
+  v->ftab_len = x.ftab_len; v->exc_shift = x.exc_shift; v->ftab = x.ftab.empty() ? nullptr : x.ftab.data();
+  v->exc_super = x.exc_super.empty() ? nullptr : x.exc_super.data();
   v->text4 = x.text4.empty() ? nullptr : x.text4.data();
   v->n_segs = x.seg_node.size();
   v->seg_start = x.seg_start.data(); v->seg_node = x.seg_node.data(); v->seg_noff = x.seg_noff.data();

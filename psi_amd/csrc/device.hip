@@ -191,27 +191,26 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 
 struct FMView {
   const uint4* blocks;       // n_blocks x 4 x 16 B
-  const uint32_t* exc_row;
+  const uint32_t* exc_row;   // [n_exc] exception rows, then -- same array -- the exceptions in front of every super-block of
+                             // 2^exc_shift rank blocks (a few hundred words): one pointer, and two narrow fields share a
+                             // register (the search kernel sits at the SGPR count that still allows 8 waves per SIMD)
   uint32_t n_exc;
   uint32_t n;                // text length
   uint32_t C[4];
   const uint2* ftab;         // [4^ftab_len] SA interval of the q-mer, or nullptr
-  uint32_t ftab_len;
+  uint16_t ftab_len, exc_shift;
+  __device__ __forceinline__ uint32_t exc_super(uint32_t blk) const { return exc_row[n_exc + (blk >> exc_shift)]; }
   const uint64_t* text4;     // the text, 4 bits per symbol (nullptr: never verify against the text)
   const uint32_t* sa;        // whole suffix array when sa_rate == 1, else nullptr
   const SaRec* sarec;        // per-row records for this seed length, or nullptr
 };
 
-// exceptions listed for this block that sit below row `i` (rare slow path, quad lane 0 only)
-__device__ __noinline__ uint32_t exc_below(const FMView& fm, uint32_t hdr_w, uint32_t blk_start, uint32_t i)
+// exceptions listed for this block that sit below row `i` (rare slow path, quad lane 0 only; the index's
+// arrays are passed one by one: a reference to the view would force the whole struct into scratch memory)
+__device__ __noinline__ uint32_t exc_below(const uint32_t* __restrict__ rows /* the block's first exception */, uint32_t n, uint32_t i)
 {
-  uint32_t e = hdr_w >> 8, ne = hdr_w & 0xFF, c = 0;
-  uint32_t end = (ne == 255) ? fm.n_exc : e + ne;
-  for (; e < end; ++e) {
-    uint32_t r = fm.exc_row[e];
-    if (r >= i || r >= blk_start + BLOCK_SYMS) break;
-    ++c;
-  }
+  uint32_t c = 0;                       // rows are sorted; i lies inside the block, so a row >= i ends the scan
+  while (c < n && rows[c] < i) ++c;
   return c;
 }
 
@@ -246,11 +245,18 @@ __device__ __forceinline__ uint32_t quad_rank(const FMView& fm, uint4 v, uint32_
 {
   uint32_t blk = i / BLOCK_SYMS, off = i - blk * BLOCK_SYMS;
   // header (meaningful on lane 0 only)
-  uint32_t base = blk * BLOCK_SYMS - v.x - v.y - v.z - (v.w >> 8);      // T
+  // T = rows - A - C - G - exceptions in front (header field + what lies in front of the block's super-block:
+  // a load that depends on the row alone, not on the block, from an array that stays in cache)
+  uint32_t base = 0;
+  if (c == 3) base = blk * BLOCK_SYMS - v.x - v.y - v.z - (v.w >> 8) - fm.exc_super(blk);
   base = c == 2 ? v.z : base;
   base = c == 1 ? v.y : base;
   base = c == 0 ? v.x : base;
-  if (ql == 0 && c == 0 && (v.w & 0xFF) != 0) base -= exc_below(fm, v.w, blk * BLOCK_SYMS, i);
+  if (ql == 0 && c == 0 && (v.w & 0xFF) != 0)
+  {
+    const uint32_t e = (v.w >> 8) + fm.exc_super(blk), ne = v.w & 0xFF;
+    base -= exc_below(fm.exc_row + e, ne == 255 ? fm.n_exc - e : ne, i);
+  }
   base = quad_bcast0(base);
   // symbols: this lane covers [64 (ql-1), 64 ql); m = how many of them lie below `off`
   int32_t rel = (int32_t)off - (int32_t)(ql * 64) + 64;
@@ -636,7 +642,7 @@ __global__ void k_pfx_derive(const uint32_t* __restrict__ pfx_bits, uint32_t pfx
 // k_wave_offsets turns the sums into the wave's first output slot, and k_fm_locate, walking the
 // same ranges, places every hit with a running wave-local prefix: hits come out in seed order
 // with no atomics and no scan over the seeds.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)      // 8 waves per SIMD: the launch (8192 waves) is sized to be resident at once
 k_fm_search(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
             uint64_t seeds_cap, uint32_t per_wave,
             uint32_t k, uint32_t gocc_thr, uint32_t* __restrict__ iv_lo, uint32_t* __restrict__ iv_cnt,
@@ -731,12 +737,15 @@ constexpr int WAVES_MAX = 8192;       // waves of K1 / the probe / K2: all resid
 
 __global__ void __launch_bounds__(1024)
 k_wave_offsets(uint64_t* wave_total, const uint64_t* __restrict__ wave_total_off, uint64_t n_waves, uint64_t* total_on,
-               uint64_t* total_all)
+               uint64_t* total_all, bool accumulate)
 {
+  // accumulate: this is a further part of the index -- its hits go behind those already counted in *total_all.
+  // wave_total[n_waves] / [n_waves + 1] get the part's range of output slots.
   __shared__ uint64_t wsum[16];
   __shared__ uint64_t osum[16];
   const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
   constexpr int V = WAVES_MAX / 1024;
+  const uint64_t base = accumulate ? *total_all : 0, base_on = accumulate ? *total_on : 0;
   uint64_t v[V], s = 0, on = 0;
 #pragma unroll
   for (int i = 0; i < V; ++i) {
@@ -757,7 +766,7 @@ k_wave_offsets(uint64_t* wave_total, const uint64_t* __restrict__ wave_total_off
   __syncthreads();
   uint64_t before = 0, all = 0;
   for (uint32_t i = 0; i < 16; ++i) { if (i < w) before += wsum[i]; all += wsum[i]; }
-  uint64_t run = before + incl - s;
+  uint64_t run = base + before + incl - s;
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     uint64_t idx = (uint64_t)t * V + i;
@@ -767,8 +776,49 @@ k_wave_offsets(uint64_t* wave_total, const uint64_t* __restrict__ wave_total_off
   if (t == 0) {
     uint64_t o = 0;
     for (uint32_t i = 0; i < 16; ++i) o += osum[i];
-    *total_on = o;
-    *total_all = all;
+    *total_on = base_on + o;
+    *total_all = base + all;
+    wave_total[n_waves] = base;
+    wave_total[n_waves + 1] = base + all;
+  }
+}
+
+// An index in several parts: K1 ran once per part and left every part's occurrence count per seed.  A gocc
+// threshold counts a k-mer's occurrences in the whole path text (index_iter.hpp:843-847): seeds whose counts add
+// up to more than `thr` lose them in every part; the per-wave totals of every part are made here (K1's own were
+// taken before the threshold), and the seeds with an occurrence in any part are counted once.
+__global__ void __launch_bounds__(256)
+k_parts_combine(uint32_t* __restrict__ iv_cnt, uint64_t seed_stride, uint32_t n_parts, uint32_t thr,
+                const uint64_t* __restrict__ params, uint64_t seeds_cap, uint32_t per_wave,
+                uint64_t* __restrict__ wave_total, uint64_t tiles_stride, DevCounters* ctr)
+{
+  const uint32_t lane = lane_id();
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_seeds = min(params[0], seeds_cap);
+  const uint64_t s0 = wave * per_wave, s1 = min(n_seeds, s0 + per_wave);
+  uint64_t wsum[PSIGPU_MAX_PARTS];
+  uint32_t n_live = 0;
+  for (uint32_t p = 0; p < PSIGPU_MAX_PARTS; ++p) wsum[p] = 0;
+  for (uint64_t seed = s0 + lane; seed < s1; seed += 64) {
+    uint64_t total = 0;
+    uint32_t c[PSIGPU_MAX_PARTS];
+#pragma unroll
+    for (uint32_t p = 0; p < PSIGPU_MAX_PARTS; ++p) { c[p] = p < n_parts ? iv_cnt[p * seed_stride + seed] : 0u; total += c[p]; }
+    const bool keep = total != 0 && total <= thr;
+    if (total != 0 && !keep)
+      for (uint32_t p = 0; p < n_parts; ++p) if (c[p]) iv_cnt[p * seed_stride + seed] = 0;
+    n_live += keep;
+#pragma unroll
+    for (uint32_t p = 0; p < PSIGPU_MAX_PARTS; ++p) wsum[p] += keep ? c[p] : 0u;
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    n_live += __shfl_down(n_live, d);
+#pragma unroll
+    for (uint32_t p = 0; p < PSIGPU_MAX_PARTS; ++p) wsum[p] += __shfl_down(wsum[p], d);
+  }
+  if (lane == 0) {
+    for (uint32_t p = 0; p < n_parts; ++p) wave_total[p * tiles_stride + wave] = wsum[p];
+    if (n_live) ctr->n_live.add((unsigned long long)n_live);
   }
 }
 
@@ -1631,7 +1681,7 @@ k_fm_walk(FMView fm, const uint32_t* __restrict__ samples, uint32_t sa_rate, con
         sym = quad_sum(sym);
         uint32_t ex = 0;                          // a separator / the sentinel in the BWT: its SA value is stored
         if (ql == 0 && (v.w & 0xFF) != 0) {
-          const uint32_t e0 = v.w >> 8, ne = v.w & 0xFF;
+          const uint32_t e0 = (v.w >> 8) + fm.exc_super(blk), ne = v.w & 0xFF;
           const uint32_t end = (ne == 255) ? fm.n_exc : e0 + ne;
           for (uint32_t q = e0; q < end; ++q) {
             const uint32_t rr = fm.exc_row[q];
@@ -1659,12 +1709,13 @@ k_fm_walk(FMView fm, const uint32_t* __restrict__ samples, uint32_t sa_rate, con
 __global__ void __launch_bounds__(256)
 k_hits_resolve(MapView mv, const uint64_t* __restrict__ hit_a, const uint32_t* __restrict__ hit_seed,
                const uint32_t* __restrict__ iv_cnt, const uint32_t* __restrict__ off_first, const uint32_t* __restrict__ off_cnt,
-               const uint32_t* __restrict__ off_noff, const LocusEnt* __restrict__ ent, const unsigned long long* __restrict__ n_hits,
+               const uint32_t* __restrict__ off_noff, const LocusEnt* __restrict__ ent, const uint64_t* __restrict__ range,
                const uint2* __restrict__ seed_info, uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap)
 {
-  const uint64_t n = min((uint64_t)*n_hits, cap);
+  // range[0], range[1]: the output slots of this part of the index (k_wave_offsets)
+  const uint64_t n = min(range[1], cap);
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n; h += stride) {
+  for (uint64_t h = range[0] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n; h += stride) {
     const uint64_t a = hit_a[h];
     const uint32_t seed = hit_seed[h], occ = (uint32_t)(a >> 32), pos = (uint32_t)a;
     const uint32_t con = iv_cnt[seed];
@@ -2235,7 +2286,12 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
 // two bisections over (SA[row] + depth)-th text symbols (whole SA + 4-bit text resident: sa_rate 1).
 // One lane per read: the walk is sequential inside a read and independent across reads.
 // ------------------------------------------------------------------------------------
-struct MemGroup { uint32_t read, start, plen, lo, cnt; };      // one reported pattern: SA rows [lo, lo + cnt)
+struct MemGroup { uint32_t read, start, plen, lo, cnt, part, total; };      // one reported pattern in one part: SA rows [lo, lo + cnt)
+
+// suffix array, text and segment table of every part of the index (a pattern's occurrences are the union
+// over the parts -- it never spans two paths -- and its occurrence count their sum)
+struct MemPart { const uint32_t* sa; const uint64_t* text4; const SegRec* seg; const uint32_t* seg_dir; uint32_t n; };
+struct MemParts { MemPart p[PSIGPU_MAX_PARTS]; uint32_t n_parts; };
 
 __device__ __forceinline__ int text_sym(const uint64_t* __restrict__ text4, uint64_t n, uint64_t pos)
 {
@@ -2257,7 +2313,7 @@ __device__ __forceinline__ uint32_t mem_lower(const uint32_t* __restrict__ sa, c
 
 __global__ void __launch_bounds__(64)
 k_find_mems(const char* __restrict__ bases, const uint64_t* __restrict__ read_off, uint64_t n_reads,
-            const uint32_t* __restrict__ sa, const uint64_t* __restrict__ text4, uint32_t n, uint32_t minlen,
+            MemParts mp, uint32_t minlen,
             uint32_t gocc_thr, uint32_t max_mem, MemGroup* __restrict__ groups, uint64_t cap_groups,
             unsigned long long* __restrict__ n_groups, unsigned long long* __restrict__ n_hits)
 {
@@ -2266,27 +2322,52 @@ k_find_mems(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
   const char* pat = bases + read_off[r];
   const uint64_t len = read_off[r + 1] - read_off[r];
   uint64_t start = 0, nof = 0;
-  uint32_t plen = 0, lo = 0, hi = n;
+  uint32_t plen = 0, lo[PSIGPU_MAX_PARTS], hi[PSIGPU_MAX_PARTS];
+#pragma unroll
+  for (uint32_t q = 0; q < PSIGPU_MAX_PARTS; ++q) { lo[q] = 0; hi[q] = q < mp.n_parts ? mp.p[q].n : 0u; }
   bool has_hit = false;
   while (start + plen < len) {
-    if (plen >= minlen && hi - lo <= gocc_thr) {
+    uint64_t total = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PSIGPU_MAX_PARTS; ++q) total += hi[q] - lo[q];
+    if (plen >= minlen && total <= gocc_thr) {
       has_hit = true;
-      const unsigned long long g = atomicAdd(n_groups, 1ull);
-      atomicAdd(n_hits, (unsigned long long)(hi - lo));
-      if (g < cap_groups) groups[g] = MemGroup{ (uint32_t)r, (uint32_t)start, plen, lo, hi - lo };
-      nof += hi - lo;
+#pragma unroll
+      for (uint32_t q = 0; q < PSIGPU_MAX_PARTS; ++q)
+        if (hi[q] > lo[q]) {
+          const unsigned long long g = atomicAdd(n_groups, 1ull);
+          if (g < cap_groups) groups[g] = MemGroup{ (uint32_t)r, (uint32_t)start, plen, lo[q], hi[q] - lo[q], q, (uint32_t)min(total, (uint64_t)0xFFFFFFFFu) };
+        }
+      atomicAdd(n_hits, (unsigned long long)total);
+      nof += total;
       if (nof >= max_mem) break;
     }
     bool ok = false;
     if (!has_hit) {
       const int c = base2(pat[start + plen]);
       if (c >= 0) {
-        const uint32_t a = mem_lower(sa, text4, n, lo, hi, plen, c);
-        const uint32_t b = mem_lower(sa, text4, n, a, hi, plen, c + 1);
-        if (b > a) { lo = a; hi = b; ok = true; }
+        uint32_t na[PSIGPU_MAX_PARTS], nb[PSIGPU_MAX_PARTS];
+#pragma unroll
+        for (uint32_t q = 0; q < PSIGPU_MAX_PARTS; ++q) {
+          na[q] = nb[q] = 0;
+          if (hi[q] > lo[q]) {
+            na[q] = mem_lower(mp.p[q].sa, mp.p[q].text4, mp.p[q].n, lo[q], hi[q], plen, c);
+            nb[q] = mem_lower(mp.p[q].sa, mp.p[q].text4, mp.p[q].n, na[q], hi[q], plen, c + 1);
+            ok = ok || nb[q] > na[q];
+          }
+        }
+        if (ok) {
+#pragma unroll
+          for (uint32_t q = 0; q < PSIGPU_MAX_PARTS; ++q) { lo[q] = na[q]; hi[q] = nb[q]; }
+        }
       }
     }
-    if (!ok) { lo = 0; hi = n; start += (uint64_t)plen + 1; plen = 0; has_hit = false; continue; }
+    if (!ok) {
+#pragma unroll
+      for (uint32_t q = 0; q < PSIGPU_MAX_PARTS; ++q) { lo[q] = 0; hi[q] = q < mp.n_parts ? mp.p[q].n : 0u; }
+      start += (uint64_t)plen + 1; plen = 0; has_hit = false;
+      continue;
+    }
     ++plen;
   }
 }
@@ -2296,19 +2377,19 @@ static_assert(sizeof(MemHit) == sizeof(psigpu_mem_hit), "MEM record layout");
 
 __global__ void __launch_bounds__(256)
 k_mem_locate(const MemGroup* __restrict__ groups, const uint64_t* __restrict__ group_off, uint64_t n_groups,
-             const uint32_t* __restrict__ sa, const SegRec* __restrict__ seg, const uint32_t* __restrict__ seg_dir,
-             uint64_t rec_offset, MemHit* __restrict__ out)
+             MemParts mp, uint64_t rec_offset, MemHit* __restrict__ out)
 {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
   const MemGroup mg = groups[g];
+  const MemPart& pt = mp.p[mg.part];
   MemHit* dst = out + group_off[g];
   for (uint32_t i = 0; i < mg.cnt; ++i) {
-    const uint32_t pos = sa[mg.lo + i];
-    uint32_t d = seg_dir[pos >> DIR_SHIFT];
-    while (seg[d + 1].start <= pos) ++d;
-    const SegRec sr = seg[d];
-    dst[i] = MemHit{ sr.node_id, (uint64_t)sr.noff + (pos - sr.start), rec_offset + mg.read, mg.start, mg.plen, mg.cnt };
+    const uint32_t pos = pt.sa[mg.lo + i];
+    uint32_t d = pt.seg_dir[pos >> DIR_SHIFT];
+    while (pt.seg[d + 1].start <= pos) ++d;
+    const SegRec sr = pt.seg[d];
+    dst[i] = MemHit{ sr.node_id, (uint64_t)sr.noff + (pos - sr.start), rec_offset + mg.read, mg.start, mg.plen, mg.total };
   }
 }
 
@@ -2395,19 +2476,30 @@ struct psigpu_ctx {
   bool have_index = false;
   bool fm_ok = true;               // rank blocks present: FM search possible (false: k-mer table mode only)
   uint32_t index_k = 0, sa_rate = 0, context = 0, n_paths = 0;
-  uint64_t text_len = 0, n_exc = 0, n_loci = 0, n_segs = 0;
-  uint64_t C[4] = { 0, 0, 0, 0 };
-  uint32_t ftab_len = 0;
-  DevBuf ftab, text4;
-  bool have_text4 = false;
-  DevBuf saloc;                    // (node rank, offset) per SA row (sa_rate 1, when memory is plentiful)
-  bool have_saloc = false;
-  DevBuf sarec;                    // per-row records for seed length sarec_k (sa_rate 1, interval table, text resident)
-  uint32_t sarec_k = 0;
+  uint64_t n_loci = 0;
+  // One PART of the index on the device: a complete FM index over a group of paths (an index is one part
+  // unless its text would pass the 32-bit row limit).  The FM modes and MEM mode search every part; the
+  // k-mer table tabulates them together.
+  struct FmPart {
+    DevBuf blocks, samples, exc_row, exc_sa, ftab, text4, seg, seg_dir, seg_rank;      // (exc_row: + the super-block counts)
+    DevBuf saloc;                    // (node rank, offset) per SA row (sa_rate 1, when memory is plentiful)
+    DevBuf sarec;                    // per-row records for seed length sarec_k (sa_rate 1, interval table, text resident)
+    uint64_t text_len = 0, n_exc = 0, n_segs = 0;
+    uint64_t C[4] = { 0, 0, 0, 0 };
+    uint32_t ftab_len = 0, exc_shift = EXC_SUPER_SHIFT, sarec_k = 0;
+    bool have_text4 = false, have_saloc = false;
+    void release()
+    {
+      for (DevBuf* b : { &blocks, &samples, &exc_row, &exc_sa, &ftab, &text4, &seg, &seg_dir, &seg_rank, &saloc, &sarec }) b->release();
+      text_len = n_exc = n_segs = 0; ftab_len = sarec_k = 0; have_text4 = have_saloc = false;
+    }
+  };
+  std::vector<std::unique_ptr<FmPart>> parts;      // parts[0] always exists
+  FmPart& p0() const { return *parts[0]; }
   bool rows_tried = false;         // build_row_records has run for this index (the records exist, or do not fit / apply)
   bool id_affine = false;          // external node id = rank + id_base
   uint64_t id_base = 0;
-  DevBuf blocks, samples, exc_row, exc_sa, seg, seg_dir, loci;
+  DevBuf loci;
   uint32_t gocc_thr = 0;
   uint32_t tune = 0;               // PSIGPU_TUNE_* measurement switches (psigpu_set_tuning)
   bool kt_dedup = false;           // the k-mer table was built without a gocc threshold: one entry per graph position
@@ -2415,14 +2507,7 @@ struct psigpu_ctx {
   uint32_t query_mode = PSIGPU_MODE_KMER_TABLE, walk_cap = 0;
   bool lkt_ready = false, lkt_failed = false;
   bool kt_ready = false;           // the table also holds the path k-mers (KmerSlot), K1 is one probe
-  DevBuf kt_ht, kt_ext, kt_onpos, seg_rank;
-  // further parts of an index whose text passes the 32-bit row limit: only what tabulating their k-mers
-  // needs (suffix array, text, segment table)
-  struct FmPart {
-    DevBuf samples, text4, seg, seg_dir, seg_rank;
-    uint64_t text_len = 0, n_segs = 0;
-  };
-  std::vector<std::unique_ptr<FmPart>> more;
+  DevBuf kt_ht, kt_ext, kt_onpos;
   uint64_t kt_ht_size = 0, kt_n_path_kmers = 0, kt_n_ext = 0;
   uint32_t lkt_k = 0;
   DevBuf lkt_ht, lkt_ent, lkt_res;
@@ -2542,6 +2627,7 @@ psigpu_ctx* psigpu_create(int device)
   if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
   psigpu_ctx* ctx = new psigpu_ctx;
   ctx->device = device;
+  ctx->parts.emplace_back(new psigpu_ctx::FmPart);
   for (auto& ev : ctx->ev)
     if (hipEventCreate(&ev) != hipSuccess) { g_create_err = "hipEventCreate failed"; delete ctx; return nullptr; }
   ctx->have_events = true;
@@ -2556,17 +2642,16 @@ void psigpu_destroy(psigpu_ctx* ctx)
 {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  DevBuf* all[] = { &ctx->nodes, &ctx->lite, &ctx->node_id, &ctx->lab2, &ctx->labn, &ctx->edge_to, &ctx->blocks,
-                    &ctx->samples, &ctx->ftab, &ctx->text4, &ctx->exc_row, &ctx->exc_sa, &ctx->seg, &ctx->seg_dir, &ctx->loci, &ctx->w_bases,
+  DevBuf* all[] = { &ctx->nodes, &ctx->lite, &ctx->node_id, &ctx->lab2, &ctx->labn, &ctx->edge_to, &ctx->loci, &ctx->w_bases,
                     &ctx->w_read_off, &ctx->w_cnt, &ctx->w_tiles, &ctx->w_seed_off, &ctx->w_seed_key,
                     &ctx->w_seed_info, &ctx->w_seed_next, &ctx->w_ht, &ctx->w_pfx, &ctx->w_pfx12, &ctx->w_iv_lo, &ctx->w_iv_cnt, &ctx->w_iv_aux, &ctx->w_hit_off,
                     &ctx->w_iv_tiles, &ctx->w_chunks, &ctx->w_chunk_fill, &ctx->w_chunk_off, &ctx->w_chunk_tiles, &ctx->w_hits, &ctx->w_spill_a, &ctx->w_spill_b,
                     &ctx->w_ctr, &ctx->w_total, &ctx->lkt_ht, &ctx->lkt_ent, &ctx->lkt_res, &ctx->w_seedout,
-                    &ctx->w_iv_tiles_off, &ctx->w_defer, &ctx->sarec, &ctx->saloc, &ctx->kt_ht, &ctx->kt_ext, &ctx->seg_rank, &ctx->w_seedres };
+                    &ctx->w_iv_tiles_off, &ctx->w_defer, &ctx->kt_ht, &ctx->kt_ext, &ctx->w_seedres };
   for (auto* b : all) b->release();
   ctx->ids_sorted.release(); ctx->w_sorted[0].release(); ctx->w_sorted[1].release(); ctx->w_count.release();
   ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release();
-  for (auto& m : ctx->more) { m->samples.release(); m->text4.release(); m->seg.release(); m->seg_dir.release(); m->seg_rank.release(); }
+  for (auto& m : ctx->parts) m->release();
   ctx->w_hits_alt.release();
   for (auto& sl : ctx->slot) {
     sl.bases.release(); sl.off.release();
@@ -2589,6 +2674,7 @@ const char* psigpu_last_error(const psigpu_ctx* ctx)
 }
 
 static void lkt_release(psigpu_ctx* ctx);
+static void drop_row_records(psigpu_ctx* ctx);
 
 int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr)
 {
@@ -2625,10 +2711,7 @@ int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags)
 {
   if (!ctx) return PSIGPU_ERR_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return PSIGPU_ERR_DEVICE;
-  if ((flags ^ ctx->tune) & PSIGPU_TUNE_NO_ROWRECS) {      // the per-row records are made (or dropped) by the next FM query
-    ctx->sarec.release(); ctx->saloc.release();
-    ctx->sarec_k = 0; ctx->have_saloc = false; ctx->rows_tried = false;
-  }
+  if ((flags ^ ctx->tune) & PSIGPU_TUNE_NO_ROWRECS) drop_row_records(ctx);      // made (or not) by the next FM query
   ctx->tune = flags;
   return PSIGPU_OK;
 }
@@ -2791,27 +2874,73 @@ static int upload_segments(psigpu_ctx* ctx, const psigpu_index_view* x, const st
   return upload(ctx, seg_rank, x->seg_node, x->n_segs, 1);
 }
 
+// one part's arrays -> the device; every array length follows from the part's text length
+static int load_part(psigpu_ctx* ctx, const psigpu_index_view* m, uint32_t sa_rate, bool fm_ok, const std::vector<uint64_t>& ids,
+                     psigpu_ctx::FmPart& fp)
+{
+  if (m->text_len == 0 || m->text_len >= 0xFFFFFFF0ull) { ctx->err = "text too long for the 32-bit index layout (or empty)"; return PSIGPU_ERR_ARG; }
+  const bool has_fm = m->bwt_blocks != nullptr && m->n_blocks != 0;
+  if (has_fm != fm_ok || (fm_ok && (m->n_blocks != m->text_len / BLOCK_SYMS + 1 || !m->exc_super || m->exc_shift > EXC_SUPER_SHIFT)) ||
+      (!fm_ok && (m->n_exc || m->ftab_len)) || m->n_dir != (m->text_len >> DIR_SHIFT) + 1 ||
+      m->n_samples != (m->text_len + sa_rate - 1) / sa_rate || (m->n_exc && (!m->exc_row || !m->exc_sa)) ||
+      !m->sa_samples || !m->seg_start || !m->seg_dir || (!fm_ok && (sa_rate != 1 || !m->text4)) || m->ftab_len > 16) {
+    ctx->err = "inconsistent index view";
+    return PSIGPU_ERR_ARG;
+  }
+  {
+    std::atomic<bool> bad_dir{ false };
+    const uint64_t seg_lim = m->n_segs + (m->n_segs == 0);
+    parallel_for(m->n_dir, 1u << 16, [&](uint64_t i0, uint64_t i1) {
+      bool bad = false;
+      for (uint64_t i = i0; i < i1; ++i) bad = bad || m->seg_dir[i] >= seg_lim;
+      if (bad) bad_dir = true;
+    });
+    if (bad_dir) { ctx->err = "inconsistent index view"; return PSIGPU_ERR_ARG; }
+  }
+  int st;
+  fp.release();
+  if ((st = upload(ctx, fp.blocks, (const RankBlock*)m->bwt_blocks, fm_ok ? m->n_blocks : 0, 1))) return st;
+  fp.exc_shift = fm_ok ? m->exc_shift : EXC_SUPER_SHIFT;
+  if ((st = upload(ctx, fp.samples, m->sa_samples, m->n_samples, 1))) return st;
+  {
+    // the exception rows and, behind them, the per-super-block counts (FMView::exc_super)
+    const uint64_t n_super = fm_ok ? ((m->n_blocks - 1) >> m->exc_shift) + 1 : 0;
+    HIPCHK(ctx, fp.exc_row.ensure((m->n_exc + n_super + 1) * 4 + 16));
+    if (m->n_exc) HIPCHK(ctx, hipMemcpy(fp.exc_row.p, m->exc_row, m->n_exc * 4, hipMemcpyHostToDevice));
+    if (n_super) HIPCHK(ctx, hipMemcpy(fp.exc_row.as<uint32_t>() + m->n_exc, m->exc_super, n_super * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemset(fp.exc_row.as<uint32_t>() + m->n_exc + n_super, 0, 4));
+  }
+  if ((st = upload(ctx, fp.exc_sa, m->exc_sa, m->n_exc, 1))) return st;
+  if (m->text4) {
+    if ((st = upload(ctx, fp.text4, m->text4, m->text_len / 16 + 2))) return st;
+    fp.have_text4 = true;
+  }
+  if (m->ftab_len && m->ftab) {
+    if ((st = upload(ctx, fp.ftab, m->ftab, 2ull << (2 * m->ftab_len)))) return st;
+    fp.ftab_len = m->ftab_len;
+  }
+  if ((st = upload_segments(ctx, m, ids, fp.seg, fp.seg_dir, fp.seg_rank))) return st;
+  fp.text_len = m->text_len; fp.n_exc = m->n_exc; fp.n_segs = m->n_segs;
+  for (int i = 0; i < 4; ++i) fp.C[i] = m->C[i];
+  return PSIGPU_OK;
+}
+
 int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
 {
   if (!ctx || !x) return PSIGPU_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (x->text_len >= 0xFFFFFFF0ull) { ctx->err = "text too long for the 32-bit index layout"; return PSIGPU_ERR_ARG; }
   if (x->sa_rate == 0 || (x->sa_rate & (x->sa_rate - 1))) { ctx->err = "bad sa_rate"; return PSIGPU_ERR_ARG; }
-  // nothing inconsistent reaches the kernels: every array length follows from the text length
-  // (no rank blocks: an index that can only be tabulated -- several parts, or too many separators)
+  // nothing inconsistent reaches the kernels
+  // (no rank blocks: a view that can only be tabulated -- k-mer table mode; this library's builder always makes them)
   const bool fm_ok = x->bwt_blocks != nullptr && x->n_blocks != 0;
-  if (x->seed_len == 0 || x->seed_len > PSIGPU_MAX_SEED_LEN || x->text_len == 0 ||
-      (fm_ok && x->n_blocks != x->text_len / BLOCK_SYMS + 1) || (!fm_ok && (x->n_exc || x->ftab_len)) ||
-      x->n_dir != (x->text_len >> DIR_SHIFT) + 1 ||
-      x->n_samples != (x->text_len + x->sa_rate - 1) / x->sa_rate || (x->n_exc && (!x->exc_row || !x->exc_sa)) ||
-      (x->n_loci && (!x->loci_node || !x->loci_off)) || !x->sa_samples || !x->seg_start || !x->seg_dir ||
-      (!fm_ok && (x->sa_rate != 1 || !x->text4))) {
+  if (x->seed_len == 0 || x->seed_len > PSIGPU_MAX_SEED_LEN || (x->n_loci && (!x->loci_node || !x->loci_off))) {
     ctx->err = "inconsistent index view";
     return PSIGPU_ERR_ARG;
   }
+  if (x->n_more_parts > PSIGPU_MAX_PARTS - 1 || (x->n_more_parts && !x->more_parts)) { ctx->err = "too many index parts"; return PSIGPU_ERR_ARG; }
   if (!ctx->have_graph) { ctx->err = "load the graph before the index"; return PSIGPU_ERR_STATE; }
   {
-    std::atomic<bool> bad_locus{ false }, bad_dir{ false };
+    std::atomic<bool> bad_locus{ false };
     const uint64_t n_nodes = ctx->n_nodes;
     const uint32_t* node_len = ctx->node_len.data();
     parallel_for(x->n_loci, 1u << 16, [&](uint64_t i0, uint64_t i1) {       // (1.3 G loci at whole-genome size)
@@ -2820,52 +2949,19 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
       if (bad) bad_locus = true;
     });
     if (bad_locus) { ctx->err = "starting locus outside the graph: the index does not belong to this graph"; return PSIGPU_ERR_ARG; }
-    const uint64_t seg_lim = x->n_segs + (x->n_segs == 0);
-    parallel_for(x->n_dir, 1u << 16, [&](uint64_t i0, uint64_t i1) {
-      bool bad = false;
-      for (uint64_t i = i0; i < i1; ++i) bad = bad || x->seg_dir[i] >= seg_lim;
-      if (bad) bad_dir = true;
-    });
-    if (bad_dir) { ctx->err = "inconsistent index view"; return PSIGPU_ERR_ARG; }
   }
+  ctx->have_index = false;
   int st;
-  ctx->fm_ok = fm_ok;
-  if ((st = upload(ctx, ctx->blocks, (const RankBlock*)x->bwt_blocks, fm_ok ? x->n_blocks : 0, 1))) return st;
-  if ((st = upload(ctx, ctx->samples, x->sa_samples, x->n_samples, 1))) return st;
-  if ((st = upload(ctx, ctx->exc_row, x->exc_row, x->n_exc, 1))) return st;
-  ctx->have_text4 = false;
-  if (x->text4) {
-    if ((st = upload(ctx, ctx->text4, x->text4, x->text_len / 16 + 2))) return st;
-    ctx->have_text4 = true;
-  }
-  ctx->ftab_len = 0;
-  if (x->ftab_len && x->ftab) {
-    if (x->ftab_len > 16) { ctx->err = "ftab_len above 16"; return PSIGPU_ERR_ARG; }
-    if ((st = upload(ctx, ctx->ftab, x->ftab, 2ull << (2 * x->ftab_len)))) return st;
-    ctx->ftab_len = x->ftab_len;
-  }
-  if ((st = upload(ctx, ctx->exc_sa, x->exc_sa, x->n_exc, 1))) return st;
   std::vector<uint64_t> ids(ctx->n_nodes);
   if (ctx->n_nodes) HIPCHK(ctx, hipMemcpy(ids.data(), ctx->node_id.p, ctx->n_nodes * 8, hipMemcpyDeviceToHost));
-  if ((st = upload_segments(ctx, x, ids, ctx->seg, ctx->seg_dir, ctx->seg_rank))) return st;
-  // further parts (an index whose text passes the 32-bit row limit): suffix array, text, segments
-  ctx->more.clear();
-  if (x->n_more_parts > PSIGPU_MAX_PARTS - 1 || (x->n_more_parts && !x->more_parts)) { ctx->err = "too many index parts"; return PSIGPU_ERR_ARG; }
+  while (ctx->parts.size() > 1) { ctx->parts.back()->release(); ctx->parts.pop_back(); }
+  if ((st = load_part(ctx, x, x->sa_rate, fm_ok, ids, ctx->p0()))) return st;
+  // further parts (an index whose text passes the 32-bit row limit): each a complete FM index of its own
   for (uint32_t pi = 0; pi < x->n_more_parts; ++pi) {
     const psigpu_index_view* m = &x->more_parts[pi];
-    if (x->sa_rate != 1 || m->sa_rate != 1 || !m->text4 || !x->text4 || m->text_len == 0 || m->text_len >= 0xFFFFFFF0ull ||
-        m->n_samples != m->text_len || m->n_dir != (m->text_len >> DIR_SHIFT) + 1 || !m->sa_samples || !m->seg_start || !m->seg_dir) {
-      ctx->err = "inconsistent index part (parts need the whole suffix array and the text)";
-      return PSIGPU_ERR_ARG;
-    }
-    for (uint64_t i = 0; i < m->n_dir; ++i)
-      if (m->seg_dir[i] >= m->n_segs + (m->n_segs == 0)) { ctx->err = "inconsistent index part"; return PSIGPU_ERR_ARG; }
-    ctx->more.emplace_back(new psigpu_ctx::FmPart);
-    psigpu_ctx::FmPart& fp = *ctx->more.back();
-    fp.text_len = m->text_len; fp.n_segs = m->n_segs;
-    if ((st = upload(ctx, fp.samples, m->sa_samples, m->n_samples, 1))) return st;
-    if ((st = upload(ctx, fp.text4, m->text4, m->text_len / 16 + 2))) return st;
-    if ((st = upload_segments(ctx, m, ids, fp.seg, fp.seg_dir, fp.seg_rank))) return st;
+    if (m->sa_rate != x->sa_rate) { ctx->err = "inconsistent index part"; return PSIGPU_ERR_ARG; }
+    ctx->parts.emplace_back(new psigpu_ctx::FmPart);
+    if ((st = load_part(ctx, m, x->sa_rate, fm_ok, ids, *ctx->parts.back()))) return st;
   }
   {
     // (pages first touched by the threads that fill them: 10 GB at whole-genome size)
@@ -2877,16 +2973,13 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
     });
     if ((st = upload(ctx, ctx->loci, lcp, x->n_loci, 1))) return st;
   }
-  ctx->index_k = x->seed_len; ctx->sa_rate = x->sa_rate; ctx->context = x->context;
-  ctx->n_paths = x->n_paths; ctx->text_len = x->text_len; ctx->n_exc = x->n_exc; ctx->n_segs = x->n_segs;
   // (the per-row records of the FM modes are made when an FM mode first answers a chunk: the default mode
   // never reads them, and at whole-genome size they are 70 GB)
-  ctx->sarec.release(); ctx->saloc.release();
-  ctx->sarec_k = 0; ctx->have_saloc = false; ctx->rows_tried = false;
+  ctx->rows_tried = false;
+  ctx->fm_ok = fm_ok;
   ctx->index_k = x->seed_len; ctx->sa_rate = x->sa_rate; ctx->context = x->context;
-  ctx->n_paths = x->n_paths; ctx->text_len = x->text_len; ctx->n_exc = x->n_exc;
+  ctx->n_paths = x->n_paths;
   ctx->n_loci = x->n_loci;
-  for (int i = 0; i < 4; ++i) ctx->C[i] = x->C[i];
   ctx->have_index = true;
   lkt_release(ctx);
   return PSIGPU_OK;
@@ -2897,43 +2990,56 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
 // when they do not fit or do not apply.
 static int build_row_records(psigpu_ctx* ctx, uint32_t k)
 {
-  ctx->sarec_k = 0;
-  ctx->sarec.release();
-  ctx->have_saloc = false;
-  ctx->saloc.release();
   static const bool env_no_sarec = getenv("PSIGPU_NO_SAREC") != nullptr;     // A/B (process-wide; per context: psigpu_set_tuning)
   const bool no_sarec = env_no_sarec || (ctx->tune & PSIGPU_TUNE_NO_ROWRECS);
-  const uint64_t n_rows = (ctx->text_len + ctx->sa_rate - 1) / ctx->sa_rate;
-  if (ctx->sa_rate == 1 && ctx->have_text4 && ctx->ftab_len && k >= ctx->ftab_len && k - ctx->ftab_len <= 29 &&
-      ctx->n_segs && !no_sarec) {
-    hipError_t e = ctx->sarec.ensure(n_rows * sizeof(SaRec));
-    if (e == hipSuccess) {
-      k_build_sarec<<<(unsigned)((n_rows + 255) / 256), 256>>>(
-          ctx->samples.as<uint32_t>(), n_rows, k - ctx->ftab_len, ctx->seg.as<SegRec>(), ctx->seg_rank.as<uint32_t>(),
-          ctx->seg_dir.as<uint32_t>(), ctx->text4.as<uint64_t>(), ctx->sarec.as<SaRec>());
-      HIPCHK(ctx, hipDeviceSynchronize());
-      ctx->sarec_k = k;
-    } else {
-      (void)hipGetLastError();
-      ctx->sarec.release();
+  for (auto& pp : ctx->parts) {
+    psigpu_ctx::FmPart& fp = *pp;
+    fp.sarec_k = 0; fp.sarec.release();
+    fp.have_saloc = false; fp.saloc.release();
+    const uint64_t n_rows = (fp.text_len + ctx->sa_rate - 1) / ctx->sa_rate;
+    if (ctx->sa_rate == 1 && fp.have_text4 && fp.ftab_len && k >= fp.ftab_len && k - fp.ftab_len <= 29 && fp.n_segs && !no_sarec) {
+      hipError_t e = fp.sarec.ensure(n_rows * sizeof(SaRec));
+      if (e == hipSuccess) {
+        k_build_sarec<<<(unsigned)((n_rows + 255) / 256), 256>>>(
+            fp.samples.as<uint32_t>(), n_rows, k - fp.ftab_len, fp.seg.as<SegRec>(), fp.seg_rank.as<uint32_t>(),
+            fp.seg_dir.as<uint32_t>(), fp.text4.as<uint64_t>(), fp.sarec.as<SaRec>());
+        HIPCHK(ctx, hipDeviceSynchronize());
+        fp.sarec_k = k;
+      } else {
+        (void)hipGetLastError();
+        fp.sarec.release();
+      }
     }
-  }
-  if (ctx->sa_rate == 1 && ctx->n_segs && !no_sarec && ctx->fm_ok && ctx->more.empty()) {
-    // located suffix array (FM modes): only when it is a small part of what is free (the tables come later)
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)n_rows * 8 * 6 < free_b &&
-        ctx->saloc.ensure(n_rows * sizeof(uint2)) == hipSuccess) {
-      k_build_saloc<<<(unsigned)((n_rows + 255) / 256), 256>>>(ctx->samples.as<uint32_t>(), n_rows, ctx->seg.as<SegRec>(),
-                                                               ctx->seg_rank.as<uint32_t>(), ctx->seg_dir.as<uint32_t>(),
-                                                               ctx->saloc.as<uint2>());
-      HIPCHK(ctx, hipDeviceSynchronize());
-      ctx->have_saloc = true;
-    } else {
-      (void)hipGetLastError();
-      ctx->saloc.release();
+    if (ctx->sa_rate == 1 && fp.n_segs && !no_sarec && ctx->fm_ok) {
+      // located suffix array (FM modes): only when it is a small part of what is free (the tables come later)
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)n_rows * 8 * 6 < free_b &&
+          fp.saloc.ensure(n_rows * sizeof(uint2)) == hipSuccess) {
+        k_build_saloc<<<(unsigned)((n_rows + 255) / 256), 256>>>(fp.samples.as<uint32_t>(), n_rows, fp.seg.as<SegRec>(),
+                                                                 fp.seg_rank.as<uint32_t>(), fp.seg_dir.as<uint32_t>(),
+                                                                 fp.saloc.as<uint2>());
+        HIPCHK(ctx, hipDeviceSynchronize());
+        fp.have_saloc = true;
+      } else {
+        (void)hipGetLastError();
+        fp.saloc.release();
+      }
     }
   }
   return PSIGPU_OK;
+}
+
+// the row records of every part, dropped (room for the k-mer table; psigpu_set_tuning)
+static void drop_row_records(psigpu_ctx* ctx)
+{
+  for (auto& pp : ctx->parts) { pp->sarec.release(); pp->saloc.release(); pp->sarec_k = 0; pp->have_saloc = false; }
+  ctx->rows_tried = false;
+}
+
+static bool have_row_records(const psigpu_ctx* ctx)
+{
+  for (auto& pp : ctx->parts) if (pp->sarec_k != 0 || pp->have_saloc) return true;
+  return false;
 }
 
 // The k-mer table built straight into its 16-byte slots (see k_pk_encode), over all parts of the index.
@@ -2942,7 +3048,7 @@ static int build_row_records(psigpu_ctx* ctx, uint32_t k)
 static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, uint32_t* ovals, uint64_t n_off,
                            unsigned long long* d_cnt /* room for four counters */)
 {
-  const uint32_t n_parts = 1 + (uint32_t)ctx->more.size();
+  const uint32_t n_parts = (uint32_t)ctx->parts.size();
   const bool dedup = ctx->gocc_thr == 0;
   ctx->kt_dedup = dedup;
   TmpBuf pk[PSIGPU_MAX_PARTS];
@@ -2951,15 +3057,10 @@ static int build_kt_direct(psigpu_ctx* ctx, uint32_t k, const uint64_t* okeys, u
   uint64_t rows_all = 0;
   for (uint32_t q = 0; q < n_parts; ++q) {
     PkPart& pt = parts.p[q];
-    const uint64_t* text4;
-    if (q == 0) {
-      pt.n = ctx->text_len; pt.sa = ctx->samples.as<uint32_t>(); pt.seg = ctx->seg.as<SegRec>();
-      pt.seg_rank = ctx->seg_rank.as<uint32_t>(); pt.seg_dir = ctx->seg_dir.as<uint32_t>(); text4 = ctx->text4.as<uint64_t>();
-    } else {
-      const psigpu_ctx::FmPart& fp = *ctx->more[q - 1];
-      pt.n = fp.text_len; pt.sa = fp.samples.as<uint32_t>(); pt.seg = fp.seg.as<SegRec>();
-      pt.seg_rank = fp.seg_rank.as<uint32_t>(); pt.seg_dir = fp.seg_dir.as<uint32_t>(); text4 = fp.text4.as<uint64_t>();
-    }
+    const psigpu_ctx::FmPart& fp = *ctx->parts[q];
+    pt.n = fp.text_len; pt.sa = fp.samples.as<uint32_t>(); pt.seg = fp.seg.as<SegRec>();
+    pt.seg_rank = fp.seg_rank.as<uint32_t>(); pt.seg_dir = fp.seg_dir.as<uint32_t>();
+    const uint64_t* text4 = fp.text4.as<uint64_t>();
     rows_all += pt.n;
     if (pk[q].alloc((pt.n + 1) * 8) != hipSuccess) { (void)hipGetLastError(); return PSIGPU_ERR_NOMEM; }
     pt.pk = pk[q].as<uint64_t>();
@@ -3238,16 +3339,15 @@ static int ensure_lkt(psigpu_ctx* ctx, uint32_t k, const GraphView& gv)
   }
   // k-mer table mode: path k-mers and locus k-mers in one table of 16-byte slots (needs the whole suffix
   // array and the text on the device); when it does not fit, the 16-byte locus table below
-  if (ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->sa_rate == 1 && ctx->have_text4 && ctx->n_paths) {
+  if (ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->sa_rate == 1 && ctx->p0().have_text4 && ctx->n_paths) {      // (load_part: a text in one part, a text in all)
     int st = build_kt_direct(ctx, k, sorted_keys, sorted_vals, n_ent, d_dropped);
     if (st == PSIGPU_ERR_NOMEM) {
       // not beside the per-row records of the FM modes (whole-genome indexes): give those up for the room;
       // they are made again if the table does not fit even then
       (void)hipGetLastError();
       ctx->kt_ht.release(); ctx->kt_ext.release();
-      const bool had_rows = ctx->sarec_k != 0 || ctx->have_saloc;
-      ctx->sarec.release(); ctx->saloc.release();
-      ctx->sarec_k = 0; ctx->have_saloc = false; ctx->rows_tried = false;
+      const bool had_rows = have_row_records(ctx);
+      drop_row_records(ctx);
       st = had_rows ? build_kt_direct(ctx, k, sorted_keys, sorted_vals, n_ent, d_dropped) : PSIGPU_ERR_NOMEM;
       if (st == PSIGPU_ERR_NOMEM) {
         (void)hipGetLastError();
@@ -3356,17 +3456,17 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     if (!had) EVREC(0, stream);      // a table build just ended: do not time it
   }
   // the per-row records of the FM search / locate kernels, the first time an FM mode answers on-path seeds
-  if (!use_kt && n_reads && (flags & PSIGPU_ON_PATHS) && ctx->n_paths && ctx->fm_ok && ctx->more.empty() && !ctx->rows_tried) {
+  if (!use_kt && n_reads && (flags & PSIGPU_ON_PATHS) && ctx->n_paths && ctx->fm_ok && !ctx->rows_tried) {
     int st = build_row_records(ctx, ctx->index_k);
     if (st != PSIGPU_OK) return st;
     ctx->rows_tried = true;
     EVREC(0, stream);
   }
-  if ((!ctx->more.empty() || !ctx->fm_ok) && n_reads && (flags & PSIGPU_ON_PATHS) && ctx->n_paths && !use_kt) {
+  if (!ctx->fm_ok && n_reads && (flags & PSIGPU_ON_PATHS) && ctx->n_paths && !use_kt) {
     ctx->err = ctx->query_mode != PSIGPU_MODE_KMER_TABLE || ctx->index_k != k
-                   ? "an index in several parts (or without FM arrays) is answered from the k-mer table only "
+                   ? "an index view without FM arrays is answered from the k-mer table only "
                      "(PSIGPU_MODE_KMER_TABLE, the index's seed length)"
-                   : "the k-mer table of this index (several parts / no FM arrays) does not fit the device";
+                   : "the k-mer table of this index (no FM arrays) does not fit the device";
     return PSIGPU_ERR_STATE;
   }
   const uint2* trav_loci = use_lkt ? ctx->lkt_res.as<uint2>() : ctx->loci.as<uint2>();
@@ -3424,28 +3524,35 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases, k, step,
         ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr);
   EVREC(1, stream);
-  FMView fm;
-  fm.blocks = ctx->blocks.as<uint4>();
-  fm.exc_row = ctx->exc_row.as<uint32_t>();
-  fm.n_exc = (uint32_t)ctx->n_exc;
-  fm.n = (uint32_t)ctx->text_len;
-  for (int i = 0; i < 4; ++i) fm.C[i] = (uint32_t)ctx->C[i];
-  fm.ftab = ctx->ftab_len ? ctx->ftab.as<uint2>() : nullptr;
-  fm.ftab_len = ctx->ftab_len;
   static const bool env_no_verify = getenv("PSIGPU_NO_VERIFY") != nullptr;   // A/B: LF steps only
   const bool no_verify = env_no_verify || (ctx->tune & PSIGPU_TUNE_NO_VERIFY);
-  fm.text4 = (ctx->have_text4 && !no_verify) ? ctx->text4.as<uint64_t>() : nullptr;
-  fm.sa = ctx->sa_rate == 1 ? ctx->samples.as<uint32_t>() : nullptr;
-  fm.sarec = (ctx->sarec_k == k && !no_verify) ? ctx->sarec.as<SaRec>() : nullptr;
-  MapView mv;
-  mv.samples = ctx->samples.as<uint32_t>(); mv.sa_rate = ctx->sa_rate;
-  mv.exc_sa = ctx->exc_sa.as<uint32_t>();
-  mv.seg = ctx->seg.as<SegRec>(); mv.seg_dir = ctx->seg_dir.as<uint32_t>();
-  mv.sarec = fm.sarec; mv.sarec_rem = k - ctx->ftab_len;
-  mv.node_id = ctx->node_id.as<uint64_t>(); mv.id_base = ctx->id_base; mv.id_affine = ctx->id_affine;
-  mv.loci = ctx->loci.as<uint2>();
-  mv.on_pos = ctx->kt_onpos.as<uint2>();
-  mv.saloc = ctx->have_saloc ? ctx->saloc.as<uint2>() : nullptr;
+  auto fm_view = [&](const psigpu_ctx::FmPart& fp) {
+    FMView fm;
+    fm.blocks = fp.blocks.as<uint4>();
+    fm.exc_row = fp.exc_row.as<uint32_t>();
+    fm.exc_shift = (uint16_t)fp.exc_shift;
+    fm.n_exc = (uint32_t)fp.n_exc;
+    fm.n = (uint32_t)fp.text_len;
+    for (int i = 0; i < 4; ++i) fm.C[i] = (uint32_t)fp.C[i];
+    fm.ftab = fp.ftab_len ? fp.ftab.as<uint2>() : nullptr;
+    fm.ftab_len = (uint16_t)fp.ftab_len;
+    fm.text4 = (fp.have_text4 && !no_verify) ? fp.text4.as<uint64_t>() : nullptr;
+    fm.sa = ctx->sa_rate == 1 ? fp.samples.as<uint32_t>() : nullptr;
+    fm.sarec = (fp.sarec_k == k && !no_verify) ? fp.sarec.as<SaRec>() : nullptr;
+    return fm;
+  };
+  auto map_view = [&](const psigpu_ctx::FmPart& fp, const FMView& fm) {
+    MapView mv;
+    mv.samples = fp.samples.as<uint32_t>(); mv.sa_rate = ctx->sa_rate;
+    mv.exc_sa = fp.exc_sa.as<uint32_t>();
+    mv.seg = fp.seg.as<SegRec>(); mv.seg_dir = fp.seg_dir.as<uint32_t>();
+    mv.sarec = fm.sarec; mv.sarec_rem = k - fp.ftab_len;
+    mv.node_id = ctx->node_id.as<uint64_t>(); mv.id_base = ctx->id_base; mv.id_affine = ctx->id_affine;
+    mv.loci = ctx->loci.as<uint2>();
+    mv.on_pos = ctx->kt_onpos.as<uint2>();
+    mv.saloc = fp.have_saloc ? fp.saloc.as<uint2>() : nullptr;
+    return mv;
+  };
   TableView tb;
   tb.ht = ctx->w_ht.as<TableSlot>();
   tb.ht_mask = ht_size - 1; tb.seed_next = ctx->w_seed_next.as<uint32_t>();
@@ -3467,9 +3574,12 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   hipStream_t s2 = ctx->stream2;
   uint64_t cap = std::max<uint64_t>(ctx->hits_cap_hint, 4 * n_seeds + (1u << 16));
   uint64_t cap_chunks = std::max<uint64_t>(ctx->chunks_cap_hint, n_seeds / CHUNK * 2 + 32768 + 1024);
-  HIPCHK(ctx, ctx->w_iv_lo.ensure((n_seeds + 1) * 4));
-  HIPCHK(ctx, ctx->w_iv_cnt.ensure((n_seeds + 1) * 4));
-  HIPCHK(ctx, ctx->w_iv_aux.ensure((n_seeds + 1) * 4));
+  // the FM modes search every part of the index: per-seed K1 -> K2 arrays and per-wave totals per part
+  const uint32_t n_fm = on_paths ? (uint32_t)ctx->parts.size() : 1u;
+  const uint64_t seed_stride = n_seeds + 16;
+  HIPCHK(ctx, ctx->w_iv_lo.ensure(n_fm * seed_stride * 4));
+  HIPCHK(ctx, ctx->w_iv_cnt.ensure(n_fm * seed_stride * 4));
+  HIPCHK(ctx, ctx->w_iv_aux.ensure(n_fm * seed_stride * 4));
   DevCounters& h = *reinterpret_cast<DevCounters*>(ctx->h_pinned);
   uint64_t& true_seeds = *reinterpret_cast<uint64_t*>((char*)ctx->h_pinned + sizeof(DevCounters));
   memset(&h, 0, sizeof h);
@@ -3533,16 +3643,23 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
       n_waves = (n_waves + 3) / 4 * 4;
       uint32_t per_wave = (uint32_t)(((n_seeds + n_waves - 1) / n_waves + 63) / 64 * 64);
       unsigned grid = (unsigned)(n_waves / 4);
-      HIPCHK(ctx, ctx->w_iv_tiles.ensure((n_waves + 1) * 8));
+      const uint64_t tiles_stride = n_waves + 2;             // + the part's range of output slots
+      HIPCHK(ctx, ctx->w_iv_tiles.ensure(n_fm * tiles_stride * 8));
       HIPCHK(ctx, ctx->w_iv_tiles_off.ensure((n_waves + 1) * 8));
-      // K1 -> K2 per-seed arrays: five more beside iv_lo / iv_cnt / iv_aux
-      HIPCHK(ctx, ctx->w_seedout.ensure(5 * (n_seeds + 16) * 4));
+      // K1 -> K2 per-seed arrays: five more beside iv_lo / iv_cnt / iv_aux (on_node, on_noff per part; the
+      // locus-table probe's three once)
+      HIPCHK(ctx, ctx->w_seedout.ensure((2 * n_fm + 3) * seed_stride * 4));
       if (kprobe) HIPCHK(ctx, ctx->w_seedres.ensure((n_seeds + 16) * 16));
-      SeedOut so;
-      so.iv_lo = ctx->w_iv_lo.as<uint32_t>(); so.iv_cnt = ctx->w_iv_cnt.as<uint32_t>(); so.iv_aux = ctx->w_iv_aux.as<uint32_t>();
-      so.on_node = ctx->w_seedout.as<uint32_t>(); so.on_noff = so.on_node + (n_seeds + 16);
-      so.off_first = so.on_noff + (n_seeds + 16); so.off_cnt = so.off_first + (n_seeds + 16);
-      so.off_noff = so.off_cnt + (n_seeds + 16);
+      auto seed_out = [&](uint32_t p) {
+        SeedOut so;
+        so.iv_lo = ctx->w_iv_lo.as<uint32_t>() + p * seed_stride; so.iv_cnt = ctx->w_iv_cnt.as<uint32_t>() + p * seed_stride;
+        so.iv_aux = ctx->w_iv_aux.as<uint32_t>() + p * seed_stride;
+        so.on_node = ctx->w_seedout.as<uint32_t>() + 2 * p * seed_stride; so.on_noff = so.on_node + seed_stride;
+        so.off_first = ctx->w_seedout.as<uint32_t>() + 2 * n_fm * seed_stride; so.off_cnt = so.off_first + seed_stride;
+        so.off_noff = so.off_cnt + seed_stride;
+        return so;
+      };
+      auto tiles_of = [&](uint32_t p) { return ctx->w_iv_tiles.as<uint64_t>() + p * tiles_stride; };
       if (attempt) EVREC(10, stream);
       if (attempt == 0) {
         // K1: lane per seed when the interval table + text verification can finish a seed without
@@ -3550,32 +3667,48 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         // the direct kernel defers
         static const bool env_no_direct = getenv("PSIGPU_NO_DIRECT") != nullptr;   // A/B: quad kernel only
         const bool no_direct = env_no_direct || (ctx->tune & PSIGPU_TUNE_NO_DIRECT);
-        const bool direct = on_paths && fm.ftab != nullptr && fm.sarec != nullptr && !no_direct;
         LktView lk = { nullptr, 0, nullptr };
         if (probe) lk = LktView{ ctx->lkt_ht.as<TableSlot>(), ctx->lkt_ht_size, ctx->lkt_ent.as<LocusEnt>() };
         bool probed = false;
-        auto launch_lf = [&](unsigned g_, const uint32_t* list_, const unsigned long long* n_list_) {
-          k_fm_search<<<g_, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr,
-                                              ctx->w_iv_lo.as<uint32_t>(), ctx->w_iv_cnt.as<uint32_t>(), ctx->w_iv_aux.as<uint32_t>(),
-                                              ctx->w_iv_tiles.as<uint64_t>(), ctr, list_, n_list_);
-        };
+        // a gocc threshold counts a k-mer's occurrences in ALL parts: with several, K1 reports every part's count
+        // and k_parts_combine applies the threshold to the sum
+        const bool combine = on_paths && n_fm > 1;
+        const uint32_t thr_k1 = combine ? 0xFFFFFFFFu : thr;
         if (kprobe) {
           KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
           k_kmer_probe<<<grid, 256, 0, stream>>>(kt, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave,
                                                  (flags & PSIGPU_ON_PATHS) != 0, want_off, thr, ctx->w_seedres.as<uint4>(),
                                                  ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), ctr);
           probed = true;
-        } else if (direct) {
-          HIPCHK(ctx, ctx->w_defer.ensure((n_seeds + 1) * 4));
-          k_fm_search_direct<<<grid, 256, 0, stream>>>(
-              fm, lk, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr, so, ctx->w_iv_tiles.as<uint64_t>(),
-              probe ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, ctx->w_defer.as<uint32_t>(), ctr);
-          launch_lf(256, ctx->w_defer.as<uint32_t>(), &ctr->n_defer.v);
-          pc.search_launches = 2;
-          probed = probe;
         } else if (on_paths) {
-          launch_lf(grid, nullptr, nullptr);
-          pc.search_launches = 1;
+          pc.search_launches = 0;
+          for (uint32_t p = 0; p < n_fm; ++p) {
+            const FMView fm = fm_view(*ctx->parts[p]);
+            const SeedOut so = seed_out(p);
+            const bool direct = fm.ftab != nullptr && fm.sarec != nullptr && !no_direct;
+            if (direct) {
+              HIPCHK(ctx, ctx->w_defer.ensure((n_seeds + 1) * 4));
+              if (p) HIPCHK(ctx, hipMemsetAsync(&ctr->n_defer.v, 0, 8, stream));
+              const bool ride = probe && p == 0;            // the locus-table probe rides in the first part's kernel
+              k_fm_search_direct<<<grid, 256, 0, stream>>>(
+                  fm, ride ? lk : LktView{ nullptr, 0, nullptr }, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1, so,
+                  tiles_of(p), ride ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, ctx->w_defer.as<uint32_t>(), ctr);
+              k_fm_search<<<256, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
+                                                   so.iv_lo, so.iv_cnt, so.iv_aux, tiles_of(p), ctr,
+                                                   ctx->w_defer.as<uint32_t>(), &ctr->n_defer.v);
+              pc.search_launches += 2;
+              probed = probed || ride;
+            } else {
+              k_fm_search<<<grid, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
+                                                    so.iv_lo, so.iv_cnt, so.iv_aux, tiles_of(p), ctr, nullptr, nullptr);
+              pc.search_launches += 1;
+            }
+          }
+          if (combine) {
+            HIPCHK(ctx, hipMemsetAsync(&ctr->n_live, 0, sizeof(StripedCounter), stream));      // (K1 counted per part)
+            k_parts_combine<<<grid, 256, 0, stream>>>(ctx->w_iv_cnt.as<uint32_t>(), seed_stride, n_fm, thr, d_params, n_seeds, per_wave,
+                                                      ctx->w_iv_tiles.as<uint64_t>(), tiles_stride, ctr);
+          }
         } else {
           HIPCHK(ctx, hipMemsetAsync(ctx->w_iv_cnt.p, 0, (n_seeds + 1) * 4, stream));
           HIPCHK(ctx, hipMemsetAsync(ctx->w_iv_aux.p, 0, (n_seeds + 1) * 4, stream));
@@ -3583,35 +3716,46 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         }
         if (!kprobe) EVREC(10, stream);
         if (probe && !probed) {
-          k_lkt_probe<<<grid, 256, 0, stream>>>(lk, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, so,
+          k_lkt_probe<<<grid, 256, 0, stream>>>(lk, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, seed_out(0),
                                                 ctx->w_iv_tiles_off.as<uint64_t>());
         }
-        // per-wave totals -> first output slot of every wave; total on-path hits, total K2 output
-        // (the k-mer table mode's emit kernel does this itself, from the raw totals)
+        // per-wave totals -> first output slot of every wave; total on-path hits, total K2 output: per part, each
+        // part's hits behind the parts before it (the k-mer table mode's emit kernel does this itself, from the raw totals)
         if (!kprobe)
-        k_wave_offsets<<<1, 1024, 0, stream>>>(ctx->w_iv_tiles.as<uint64_t>(),
-                                               (probe || kprobe) ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, n_waves,
-                                               (uint64_t*)&ctr->n_hits_on.v, (uint64_t*)&ctr->n_hits_tab.v);
+          for (uint32_t p = 0; p < n_fm; ++p)
+            k_wave_offsets<<<1, 1024, 0, stream>>>(tiles_of(p), (probe && p == 0) ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, n_waves,
+                                                   (uint64_t*)&ctr->n_hits_on.v, (uint64_t*)&ctr->n_hits_tab.v, p != 0);
       }
       EVREC(4, stream);
       const LocusEnt* oe = (probe || kprobe) ? ctx->lkt_ent.as<LocusEnt>() : nullptr;
-      if (kprobe)
-        k_kmer_emit<<<grid, 256, 0, stream>>>(mv, ctx->w_seedres.as<uint4>(), ctx->kt_ext.as<KmerSlot>(), oe,
+      if (kprobe) {
+        const FMView fm0 = fm_view(ctx->p0());
+        k_kmer_emit<<<grid, 256, 0, stream>>>(map_view(ctx->p0(), fm0), ctx->w_seedres.as<uint4>(), ctx->kt_ext.as<KmerSlot>(), oe,
                                               ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), d_params,
                                               n_seeds, per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap, ctr);
-      else if (ctx->sa_rate == 1)
-        k_fm_locate_direct<<<grid, 256, 0, stream>>>(mv, so, probe, oe, ctx->w_iv_tiles.as<uint64_t>(), d_params, n_seeds,
-                                                     per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap);
-      else {
-        // walks (decoupled quads) -> 12 bytes per hit -> records
-        HIPCHK(ctx, ctx->w_hit_a.ensure((cap + 1) * 8));
-        HIPCHK(ctx, ctx->w_hit_seed.ensure((cap + 1) * 4));
-        k_fm_walk<<<grid, 256, 0, stream>>>(fm, mv.samples, mv.sa_rate, mv.exc_sa, so.iv_lo, so.iv_cnt, probe ? so.off_cnt : nullptr,
-                                            ctx->w_iv_tiles.as<uint64_t>(), d_params, n_seeds, per_wave,
-                                            ctx->w_hit_a.as<uint64_t>(), ctx->w_hit_seed.as<uint32_t>(), cap, ctr);
-        k_hits_resolve<<<2048, 256, 0, stream>>>(mv, ctx->w_hit_a.as<uint64_t>(), ctx->w_hit_seed.as<uint32_t>(), so.iv_cnt,
-                                                 so.off_first, so.off_cnt, so.off_noff, oe, &ctr->n_hits_tab.v,
-                                                 ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap);
+      } else {
+        if (ctx->sa_rate != 1) {
+          HIPCHK(ctx, ctx->w_hit_a.ensure((cap + 1) * 8));
+          HIPCHK(ctx, ctx->w_hit_seed.ensure((cap + 1) * 4));
+        }
+        for (uint32_t p = 0; p < n_fm; ++p) {
+          const FMView fm = fm_view(*ctx->parts[p]);
+          const MapView mv = map_view(*ctx->parts[p], fm);
+          const SeedOut so = seed_out(p);
+          const bool with_table = probe && p == 0;             // the locus table's hits follow the first part's
+          if (ctx->sa_rate == 1)
+            k_fm_locate_direct<<<grid, 256, 0, stream>>>(mv, so, with_table, oe, tiles_of(p), d_params, n_seeds,
+                                                         per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap);
+          else {
+            // walks (decoupled quads) -> 12 bytes per hit -> records
+            k_fm_walk<<<grid, 256, 0, stream>>>(fm, mv.samples, mv.sa_rate, mv.exc_sa, so.iv_lo, so.iv_cnt, with_table ? so.off_cnt : nullptr,
+                                                tiles_of(p), d_params, n_seeds, per_wave,
+                                                ctx->w_hit_a.as<uint64_t>(), ctx->w_hit_seed.as<uint32_t>(), cap, ctr);
+            k_hits_resolve<<<2048, 256, 0, stream>>>(mv, ctx->w_hit_a.as<uint64_t>(), ctx->w_hit_seed.as<uint32_t>(), so.iv_cnt,
+                                                     so.off_first, so.off_cnt, so.off_noff, oe, tiles_of(p) + n_waves,
+                                                     ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap);
+          }
+        }
       }
     } else {
       EVREC(10, stream);
@@ -3678,7 +3822,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
                                                 &ctr->n_hits_tab.v, d_hits, cap);
       }
     }
-    const bool fix_groups = want_sorted && !off_paths && cap != 0;
+    const bool fix_groups = want_sorted && !off_paths && cap != 0 && n_fm == 1;      // (several parts: hits come out part by part)
     if (fix_groups) {
       EVREC(11, stream);
       int fs = HitSorter::fix_grouped(d_hits, cap, &ctr->n_hits_tab.v, (uint64_t*)&ctr->not_grouped.v, stream, &ctx->err);
@@ -3818,11 +3962,10 @@ int psigpu_find_mems(psigpu_ctx* ctx, const char* bases, const uint64_t* read_of
   if (minlen == 0) { ctx->err = "minimum match length must be positive"; return PSIGPU_ERR_ARG; }
   if (n_reads >= 0xFFFFFFF0ull) { ctx->err = "too many reads in one chunk"; return PSIGPU_ERR_ARG; }
   if (n_reads == 0 || ctx->n_paths == 0) return PSIGPU_OK;        // length( indexText ) == 0: nothing on paths (:1467)
-  if (ctx->sa_rate != 1 || !ctx->have_text4) {
+  if (ctx->sa_rate != 1 || !ctx->p0().have_text4) {
     ctx->err = "MEM mode needs the whole suffix array and the text on the device (sa_rate 1)";
     return PSIGPU_ERR_STATE;
   }
-  if (!ctx->more.empty()) { ctx->err = "MEM mode is not available on an index in several parts"; return PSIGPU_ERR_STATE; }
   const uint64_t n_bases = read_off[n_reads];
   for (uint64_t r = 0; r < n_reads; ++r)
     if (read_off[r + 1] - read_off[r] >= 0xFFFFFFF0ull) { ctx->err = "read too long"; return PSIGPU_ERR_ARG; }
@@ -3834,14 +3977,20 @@ int psigpu_find_mems(psigpu_ctx* ctx, const char* bases, const uint64_t* read_of
   HIPCHK(ctx, ctr.alloc(64));
   const uint32_t thr = ctx->gocc_thr ? ctx->gocc_thr : 0xFFFFFFFFu;
   const uint32_t mm = max_mem ? max_mem : 0xFFFFFFFFu;
-  uint64_t cap_groups = n_bases / std::max<uint32_t>(1, minlen) + n_reads + 1024;      // a group consumes at least minlen + 1 bases
+  MemParts mp{};
+  mp.n_parts = (uint32_t)ctx->parts.size();
+  for (uint32_t q = 0; q < mp.n_parts; ++q) {
+    const psigpu_ctx::FmPart& fp = *ctx->parts[q];
+    mp.p[q] = MemPart{ fp.samples.as<uint32_t>(), fp.text4.as<uint64_t>(), fp.seg.as<SegRec>(), fp.seg_dir.as<uint32_t>(), (uint32_t)fp.text_len };
+  }
+  // a reported pattern consumes at least minlen + 1 bases and leaves one group per part it occurs in
+  uint64_t cap_groups = (n_bases / std::max<uint32_t>(1, minlen) + n_reads) * mp.n_parts + 1024;
   unsigned long long h[2] = { 0, 0 };
   for (int attempt = 0; attempt < 2; ++attempt) {
     HIPCHK(ctx, groups.alloc(cap_groups * sizeof(MemGroup)));
     HIPCHK(ctx, hipMemset(ctr.p, 0, 64));
     k_find_mems<<<(unsigned)((n_reads + 63) / 64), 64>>>(ctx->w_bases.as<char>(), ctx->w_read_off.as<uint64_t>(), n_reads,
-                                                         ctx->samples.as<uint32_t>(), ctx->text4.as<uint64_t>(),
-                                                         (uint32_t)ctx->text_len, minlen, thr, mm, groups.as<MemGroup>(), cap_groups,
+                                                         mp, minlen, thr, mm, groups.as<MemGroup>(), cap_groups,
                                                          ctr.as<unsigned long long>(), ctr.as<unsigned long long>() + 1);
     HIPCHK(ctx, hipMemcpy(h, ctr.p, 16, hipMemcpyDeviceToHost));
     if (h[0] <= cap_groups) break;
@@ -3860,9 +4009,8 @@ int psigpu_find_mems(psigpu_ctx* ctx, const char* bases, const uint64_t* read_of
   k_scan_tiles<<<(unsigned)n_tiles, SCAN_THREADS>>>(cnt.as<uint32_t>(), n_groups, tiles.as<uint64_t>());
   k_scan_sums<<<1, SCAN_THREADS>>>(tiles.as<uint64_t>(), n_tiles, ctr.as<uint64_t>() + 2);
   k_scan_final<<<(unsigned)n_tiles, SCAN_THREADS>>>(cnt.as<uint32_t>(), n_groups, tiles.as<uint64_t>(), goff.as<uint64_t>());
-  k_mem_locate<<<(unsigned)((n_groups + 255) / 256), 256>>>(groups.as<MemGroup>(), goff.as<uint64_t>(), n_groups,
-                                                            ctx->samples.as<uint32_t>(), ctx->seg.as<SegRec>(),
-                                                            ctx->seg_dir.as<uint32_t>(), rec_offset, hits.as<MemHit>());
+  k_mem_locate<<<(unsigned)((n_groups + 255) / 256), 256>>>(groups.as<MemGroup>(), goff.as<uint64_t>(), n_groups, mp, rec_offset,
+                                                            hits.as<MemHit>());
   psigpu_mem_hit* hp = (psigpu_mem_hit*)g_pinned.get(n_hits * sizeof(psigpu_mem_hit));
   if (!hp) { ctx->err = "cannot allocate pinned host memory for the hits"; return PSIGPU_ERR_NOMEM; }
   hipError_t e = hipMemcpy(hp, hits.p, n_hits * sizeof(psigpu_mem_hit), hipMemcpyDeviceToHost);
@@ -3908,7 +4056,7 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k)
       !(ctx->n_loci == 0 && !(ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->n_paths)))
     st = ensure_lkt(ctx, k, graph_view(ctx));
   // the FM modes' per-row records (the k-mer table mode never reads them)
-  if (st == PSIGPU_OK && !(ctx->lkt_ready && ctx->kt_ready) && ctx->n_paths && ctx->fm_ok && ctx->more.empty() && !ctx->rows_tried) {
+  if (st == PSIGPU_OK && !(ctx->lkt_ready && ctx->kt_ready) && ctx->n_paths && ctx->fm_ok && !ctx->rows_tried) {
     st = build_row_records(ctx, ctx->index_k);
     ctx->rows_tried = st == PSIGPU_OK;
   }

@@ -16,9 +16,14 @@ constexpr uint32_t BLOCK_SYMS = 192;       // symbols per 64-byte rank block
 constexpr uint32_t DIR_SHIFT = 6;          // one directory entry per 64 text positions
 constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
 
+constexpr uint32_t EXC_SUPER_SHIFT = 16;   // rank blocks per exception super-block: 2^16 (12.6 M rows)
+
 struct RankBlock {            // 64 bytes, one HBM sector
   uint32_t cnt[3];            // A, C, G before this block (exceptions not counted)
-  uint32_t exc;               // (exceptions before this block) << 8 | min(255, exceptions inside)
+  uint32_t exc;               // (exceptions before this block, counted from the start of its super-block of
+                              // 2^exc_shift blocks) << 8 | min(255, exceptions inside); the exceptions in front of
+                              // every super-block are a side array (Index::exc_super), so that a text may hold any
+                              // number of separators -- the 44.6 M patches of a whole genome x 3 walks -- in 24 bits
   uint64_t sym[6];            // 192 symbols as bit planes: for group g of 64 symbols, word 2g holds
                               // their low bits and word 2g+1 their high bits (symbol j at bit j % 64)
 };
@@ -42,14 +47,15 @@ struct Index {
   std::vector<std::vector<uint32_t>> paths;    // indexed paths (node ranks)
   std::vector<uint32_t> path_head, path_tail;  // per path: offset of its first indexed base in its first node; indexed
                                                // bases of its last node (0 = all) -- Path::left / right of a patch
-  bool fm_ok = true;                           // rank blocks / exceptions / interval table present (false: an index that
-                                               // can only be tabulated -- several parts, or >= 2^24 separators)
+  bool fm_ok = true;                           // rank blocks / exceptions / interval table present
   uint32_t locus_step = 1;                     // psikt -e the starting loci were sampled with
   uint64_t graph_fp = 0;                       // fingerprint of the graph the index was made for
   uint64_t n = 0;                              // text length
   std::vector<RankBlock> blocks;
   uint64_t C[4] = { 0, 0, 0, 0 };
   std::vector<uint32_t> samples, exc_row, exc_sa;
+  std::vector<uint32_t> exc_super;             // exceptions in front of every super-block of 2^exc_shift rank blocks
+  uint32_t exc_shift = EXC_SUPER_SHIFT;
   uint32_t ftab_len = 0;
   std::vector<uint32_t> ftab;                  // 2 x 4^ftab_len
   std::vector<uint64_t> text4;                 // 4 bits / symbol, first symbol in the top nibble
@@ -58,8 +64,10 @@ struct Index {
   std::vector<uint8_t> text;                   // kept only on request
   std::vector<int32_t> sa;                     // kept only on request
   // An index whose text would pass the 32-bit row limit is made in several PARTS: consecutive groups
-  // of paths, each with its own text, FM arrays and segment table (the fields above; paths, loci and the
-  // scalars live in the first part only).  Parts beyond the first:
+  // of paths, each a complete FM index of its own -- text, rank blocks, interval table, suffix array,
+  // segment table (the fields above; paths, loci and the scalars live in the first part only).  A seed is
+  // searched in every part (a pattern never spans two paths, so the parts' occurrences are disjoint and
+  // their union is the answer).  Parts beyond the first:
   std::vector<Index> more;
 };
 
@@ -84,7 +92,7 @@ int save_index(const Index& x, const std::string& prefix);
 
 // build_gpu.hip: suffix array + FM arrays on the device (same results as the host path)
 int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, int device, Index* x,
-                 std::vector<int32_t>* sa_out, bool want_fm, std::string* err);
+                 std::vector<int32_t>* sa_out, std::string* err);
 
 // build_gpu.hip: starting loci on the device, same result as find_starting_loci()
 int gpu_find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>& paths, uint32_t k, uint32_t step,

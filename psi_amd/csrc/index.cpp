@@ -222,7 +222,7 @@ static inline int base_sym(char ch)
 
 // FM arrays + segment table over the concatenation of paths [p0, p1): one PART of the index (an index
 // is one part unless its text would pass the 32-bit row limit).  `head` / `tail`: per-path trimming.
-static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa_rate, bool keep, bool no_ftab_and_fm,
+static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa_rate, bool keep,
                       const std::vector<std::vector<uint32_t>>& paths, const std::vector<uint32_t>& head,
                       const std::vector<uint32_t>& tail, size_t p0, size_t p1, Index* x, std::string* err)
 {
@@ -267,14 +267,9 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
   T.push_back(SYM_END);
   const uint64_t n = T.size();
   x->n = n;
-  // rank blocks count the separators in front of them in 24 bits: a text with more of them (patched paths
-  // of a whole genome), like an index in several parts, has no FM arrays and is answered from the k-mer table
-  uint64_t n_sep = 0;
-  for (uint8_t c : T) n_sep += c == SYM_SEP;
-  uint64_t sep_limit = 1u << 24;
-  if (const char* e = getenv("PSIGPU_TEST_SEP_LIMIT")) sep_limit = std::min<uint64_t>(sep_limit, strtoull(e, nullptr, 10));   // tests
-  const bool want_fm = !no_ftab_and_fm && n_sep + 2 < sep_limit;
-  x->fm_ok = want_fm;
+  x->fm_ok = true;
+  x->exc_shift = EXC_SUPER_SHIFT;
+  if (const char* e = getenv("PSIGPU_TEST_EXC_SHIFT")) x->exc_shift = std::min<uint32_t>(EXC_SUPER_SHIFT, (uint32_t)strtoul(e, nullptr, 10));   // tests: tiny super-blocks
   if (ss.empty() || ss[0] != 0) {          // position 0 must belong to a segment
     ss.insert(ss.begin(), 0); sn.insert(sn.begin(), NO_NODE); so.insert(so.begin(), 0);
   }
@@ -298,7 +293,7 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
     const uint32_t q_max = opts.build_on_device ? 15 : 13;
     while (q < q_max && (1ull << (2 * q)) < n) ++q;
   }
-  if (q == 0xFFFFFFFFu || p0 == p1 || !want_fm) q = 0;
+  if (q == 0xFFFFFFFFu || p0 == p1) q = 0;
   // (the host builder marks "no q-mer here" with a 32-bit all-ones code: 16-mers need the device builder)
   if (q > 16 || (q == 16 && !opts.build_on_device)) {
     *err = "ftab_len above 16 (15 for host builds)"; return PSIGPU_ERR_ARG;
@@ -307,7 +302,7 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
   std::vector<int32_t> SA;
   if (opts.build_on_device) {
     // suffix array, rank blocks, samples, exceptions, interval table, 4-bit text on the GPU
-    int st = gpu_build_fm(T, sa_rate, q, (int)opts.build_on_device - 1, x, keep ? &SA : nullptr, want_fm, err);
+    int st = gpu_build_fm(T, sa_rate, q, (int)opts.build_on_device - 1, x, keep ? &SA : nullptr, err);
     if (st != PSIGPU_OK) return st;
   } else {
   // ---- suffix array ----------------------------------------------------------------
@@ -319,12 +314,15 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
   x->blocks.assign(nblk, RankBlock{ { 0, 0, 0 }, 0, { 0, 0, 0, 0, 0, 0 } });
   x->samples.resize((n + sa_rate - 1) / sa_rate);
   uint64_t cnt[4] = { 0, 0, 0, 0 }, nexc = 0, nsep = 0;
+  const uint32_t xs = x->exc_shift;
+  x->exc_super.assign(((nblk - 1) >> xs) + 1, 0);
   for (uint64_t i = 0; i < n; ++i) {
     uint64_t b = i / BLOCK_SYMS, j = i % BLOCK_SYMS;
     if (j == 0) {
       RankBlock& B = x->blocks[b];
       B.cnt[0] = (uint32_t)cnt[0]; B.cnt[1] = (uint32_t)cnt[1]; B.cnt[2] = (uint32_t)cnt[2];
-      B.exc = (uint32_t)(nexc << 8);
+      if ((b & ((1ull << xs) - 1)) == 0) x->exc_super[b >> xs] = (uint32_t)nexc;
+      B.exc = (uint32_t)((nexc - x->exc_super[b >> xs]) << 8);
     }
     uint8_t c = SA[i] ? T[SA[i] - 1] : T[n - 1];
     uint64_t two;
@@ -346,10 +344,9 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
   if (n % BLOCK_SYMS == 0) {
     RankBlock& B = x->blocks[nblk - 1];
     B.cnt[0] = (uint32_t)cnt[0]; B.cnt[1] = (uint32_t)cnt[1]; B.cnt[2] = (uint32_t)cnt[2];
-    B.exc = (uint32_t)(nexc << 8);
+    if (((nblk - 1) & ((1ull << xs) - 1)) == 0) x->exc_super[(nblk - 1) >> xs] = (uint32_t)nexc;
+    B.exc = (uint32_t)((nexc - x->exc_super[(nblk - 1) >> xs]) << 8);
   }
-  if (!want_fm) { x->blocks.clear(); x->exc_row.clear(); x->exc_sa.clear(); }     // (small host builds: made, then dropped)
-  else if (nexc >= (1u << 24)) { *err = "too many separators in the indexed text"; return PSIGPU_ERR_ARG; }
   x->C[0] = 1 + nsep;
   x->C[1] = x->C[0] + cnt[0];
   x->C[2] = x->C[1] + cnt[1];
@@ -533,17 +530,17 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
     fprintf(stderr, "[psigpu] index build: %s %.2f s\n", what, std::chrono::duration<double>(now - t_mark).count());
     t_mark = now;
   };
-  if (n_parts > 1 && (sa_rate != 1 || keep)) {
-    *status = PSIGPU_ERR_ARG; *err = "an index in several parts needs sa_rate 1 (and cannot keep its text)"; delete x; return nullptr;
+  if (n_parts > 1 && keep) {
+    *status = PSIGPU_ERR_ARG; *err = "an index in several parts cannot keep its text"; delete x; return nullptr;
   }
   if (n_parts > PSIGPU_MAX_PARTS) { *status = PSIGPU_ERR_ARG; *err = "indexed text too long (too many parts)"; delete x; return nullptr; }
   {
-    // several parts are only ever read to tabulate their k-mers: no interval tables
-    int st = build_part(g, opts, sa_rate, keep, n_parts > 1, paths, x->path_head, x->path_tail, cuts[0], cuts[1], x, err);
+    // every part is a complete FM index: searched one after the other in the FM modes, tabulated together for the k-mer table
+    int st = build_part(g, opts, sa_rate, keep, paths, x->path_head, x->path_tail, cuts[0], cuts[1], x, err);
     if (st != PSIGPU_OK) { *status = st; delete x; return nullptr; }
     for (size_t pt = 1; pt < n_parts; ++pt) {
       x->more.emplace_back();
-      st = build_part(g, opts, sa_rate, false, true, paths, x->path_head, x->path_tail, cuts[pt], cuts[pt + 1], &x->more.back(), err);
+      st = build_part(g, opts, sa_rate, false, paths, x->path_head, x->path_tail, cuts[pt], cuts[pt + 1], &x->more.back(), err);
       if (st != PSIGPU_OK) { *status = st; delete x; return nullptr; }
     }
   }
@@ -574,7 +571,7 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
 // Serialisation: one little-endian container `<prefix>.psigpu`.
 // ------------------------------------------------------------------------------------
 namespace {
-const char MAGIC[8] = { 'P', 'S', 'I', 'G', 'P', 'U', '0', '6' };
+const char MAGIC[8] = { 'P', 'S', 'I', 'G', 'P', 'U', '0', '7' };
 
 template <typename T> bool wr(FILE* f, const std::vector<T>& v)
 {
@@ -606,14 +603,19 @@ int save_index(const Index& x, const std::string& prefix)
   ok = ok && fwrite(extra, 8, 2, f) == 2 && wr(f, x.path_head) && wr(f, x.path_tail);
   ok = ok && wr(f, x.blocks) && wr(f, x.samples) && wr(f, x.exc_row) && wr(f, x.exc_sa) &&
        wr(f, x.seg_start) && wr(f, x.seg_node) && wr(f, x.seg_noff) && wr(f, x.seg_dir) &&
-       wr(f, x.loci_node) && wr(f, x.loci_off) && wr(f, x.ftab) && wr(f, x.text4);
+       wr(f, x.loci_node) && wr(f, x.loci_off) && wr(f, x.ftab) && wr(f, x.text4) && wr(f, x.exc_super);
+  uint64_t xs0 = x.exc_shift;
+  ok = ok && fwrite(&xs0, 8, 1, f) == 1;
   // further parts: text length, C, interval-table length, then the part's arrays
   uint64_t n_more = x.more.size();
   ok = ok && fwrite(&n_more, 8, 1, f) == 1;
   for (const Index& m : x.more) {
     uint64_t ph[6] = { m.n, m.C[0], m.C[1], m.C[2], m.C[3], m.ftab_len };
     ok = ok && fwrite(ph, 8, 6, f) == 6 && wr(f, m.blocks) && wr(f, m.samples) && wr(f, m.exc_row) && wr(f, m.exc_sa) &&
-         wr(f, m.seg_start) && wr(f, m.seg_node) && wr(f, m.seg_noff) && wr(f, m.seg_dir) && wr(f, m.ftab) && wr(f, m.text4);
+         wr(f, m.seg_start) && wr(f, m.seg_node) && wr(f, m.seg_noff) && wr(f, m.seg_dir) && wr(f, m.ftab) && wr(f, m.text4) &&
+         wr(f, m.exc_super);
+    uint64_t xs = m.exc_shift;
+    ok = ok && fwrite(&xs, 8, 1, f) == 1;
   }
   ok = (fclose(f) == 0) && ok;
   return ok ? PSIGPU_OK : PSIGPU_ERR_IO;
@@ -625,6 +627,7 @@ static bool part_consistent(const Index& x, uint32_t sa_rate)
   const uint64_t n = x.n;
   bool ok = n >= 1 && n < 0xFFFFFFF0ull && (x.blocks.empty() ? x.exc_row.empty() : x.blocks.size() == n / BLOCK_SYMS + 1) &&
             x.samples.size() == (n + sa_rate - 1) / sa_rate && x.exc_row.size() == x.exc_sa.size() &&
+            (x.blocks.empty() || x.exc_super.size() == ((x.blocks.size() - 1) >> x.exc_shift) + 1) &&
             x.seg_start.size() == x.seg_node.size() + 1 && x.seg_noff.size() == x.seg_node.size() &&
             x.seg_dir.size() == (n >> DIR_SHIFT) + 1 && x.ftab_len <= 16 &&
             (x.ftab.empty() ? x.ftab_len == 0 : x.ftab.size() == (2ull << (2 * x.ftab_len))) &&
@@ -654,7 +657,10 @@ Index* load_index(const std::string& prefix, int* status)
     x->locus_step = (uint32_t)extra[0]; x->graph_fp = extra[1];
     ok = ok && rd(f, x->blocks) && rd(f, x->samples) && rd(f, x->exc_row) && rd(f, x->exc_sa) &&
          rd(f, x->seg_start) && rd(f, x->seg_node) && rd(f, x->seg_noff) && rd(f, x->seg_dir) &&
-         rd(f, x->loci_node) && rd(f, x->loci_off) && rd(f, x->ftab) && rd(f, x->text4);
+         rd(f, x->loci_node) && rd(f, x->loci_off) && rd(f, x->ftab) && rd(f, x->text4) && rd(f, x->exc_super);
+    uint64_t xs0 = 0;
+    ok = ok && fread(&xs0, 8, 1, f) == 1 && xs0 <= EXC_SUPER_SHIFT;
+    x->exc_shift = (uint32_t)xs0;
     uint64_t n_more = 0;
     ok = ok && fread(&n_more, 8, 1, f) == 1 && n_more < PSIGPU_MAX_PARTS;
     for (uint64_t i = 0; ok && i < n_more; ++i) {
@@ -666,7 +672,10 @@ Index* load_index(const std::string& prefix, int* status)
       m.n = ph[0]; m.sa_rate = x->sa_rate; m.ftab_len = (uint32_t)ph[5];
       for (int c = 0; c < 4; ++c) m.C[c] = ph[1 + c];
       ok = rd(f, m.blocks) && rd(f, m.samples) && rd(f, m.exc_row) && rd(f, m.exc_sa) && rd(f, m.seg_start) &&
-           rd(f, m.seg_node) && rd(f, m.seg_noff) && rd(f, m.seg_dir) && rd(f, m.ftab) && rd(f, m.text4);
+           rd(f, m.seg_node) && rd(f, m.seg_noff) && rd(f, m.seg_dir) && rd(f, m.ftab) && rd(f, m.text4) && rd(f, m.exc_super);
+      uint64_t xs = 0;
+      ok = ok && fread(&xs, 8, 1, f) == 1 && xs <= EXC_SUPER_SHIFT;
+      m.exc_shift = (uint32_t)xs;
     }
   }
   fclose(f);
@@ -675,7 +684,7 @@ Index* load_index(const std::string& prefix, int* status)
     ok = x->k >= 1 && x->k <= PSIGPU_MAX_SEED_LEN && x->sa_rate && !(x->sa_rate & (x->sa_rate - 1)) &&
          part_consistent(*x, x->sa_rate) && x->loci_node.size() == x->loci_off.size() &&
          x->path_head.size() == x->paths.size() && x->path_tail.size() == x->paths.size();
-    for (const Index& m : x->more) ok = ok && x->sa_rate == 1 && part_consistent(m, 1);
+    for (const Index& m : x->more) ok = ok && part_consistent(m, x->sa_rate);
     x->fm_ok = !x->blocks.empty();
     for (Index& m : x->more) m.fm_ok = !m.blocks.empty();
   }

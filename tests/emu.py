@@ -8,8 +8,8 @@ BLOCK_SYMS = 192
 
 
 class IndexEmu:
-    def __init__(self, pindex, graph):
-        v = pindex.view
+    def __init__(self, pindex, graph, view=None):
+        v = pindex.view if view is None else view
         self.n = v.text_len
         self.sa_rate = v.sa_rate
         self.C = [int(x) for x in v.C]
@@ -26,6 +26,8 @@ class IndexEmu:
         self.seg_dir = pindex._arr(v.seg_dir, v.n_dir, np.uint32)
         self.ftab_len = v.ftab_len
         self.ftab = pindex._arr(v.ftab, 2 << (2 * v.ftab_len), np.uint32) if v.ftab_len else None
+        self.exc_shift = v.exc_shift
+        self.exc_super = pindex._arr(v.exc_super, ((nb - 1) >> v.exc_shift) + 1, np.uint32)
         self.exc_pos = {int(r): i for i, r in enumerate(self.exc_row)}
         self.node_id = graph.node_id
 
@@ -43,13 +45,13 @@ class IndexEmu:
         if c < 3:
             base = int(h[c])
         else:
-            base = b * BLOCK_SYMS - int(h[0]) - int(h[1]) - int(h[2]) - (int(h[3]) >> 8)
+            base = b * BLOCK_SYMS - int(h[0]) - int(h[1]) - int(h[2]) - (int(h[3]) >> 8) - int(self.exc_super[b >> self.exc_shift])
         cnt = 0
         for j in range(o):
             if self._sym(b, j) == c:
                 cnt += 1
         if c == 0 and (int(h[3]) & 0xFF):
-            e = int(h[3]) >> 8
+            e = (int(h[3]) >> 8) + int(self.exc_super[b >> self.exc_shift])
             while e < len(self.exc_row) and self.exc_row[e] < i and self.exc_row[e] < (b + 1) * BLOCK_SYMS:
                 cnt -= 1
                 e += 1
@@ -105,3 +107,10 @@ class IndexEmu:
             for nid, noff in cache[km]:
                 out.append((nid, noff, rid, roff))
         return out
+
+
+class PartEmu(IndexEmu):
+    """One part of an index in several parts (every part is a complete FM index)."""
+
+    def __init__(self, pindex, view, graph):
+        super().__init__(pindex, graph, view)

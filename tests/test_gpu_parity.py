@@ -978,39 +978,44 @@ def test_find_mems_vs_brute(name, minlen, npaths, patched, gocc, max_mem):
                                    'hits_multi_sim103_k31_d1.npz', 'hits_tiny_sim101_k10_d1.npz'])
 @pytest.mark.parametrize('npaths,patched', [(3, False), (6, True)])
 def test_index_in_several_parts(fname, npaths, patched, query_mode):
-    """The same hit set from an index cut into parts of a few hundred symbols: the k-mers of all parts are
-    tabulated together (occurrences of one k-mer in several parts, k-mers whose first part is not the
-    first).  Other query modes and MEM mode refuse such an index."""
+    """The same hit set from an index cut into parts of a few hundred symbols, in EVERY query mode: each part is
+    a complete FM index (the FM modes search part after part, each part's hits behind the one before), the
+    k-mer table tabulates the k-mers of all parts together (occurrences of one k-mer in several parts, k-mers
+    whose first part is not the first); MEM mode extends a pattern in all parts at once (its occurrence count
+    is the sum over the parts).  Also with the suffix array sampled, where the parts' hits are LF-walked."""
     z = np.load(os.path.join(GOLDEN, fname))
     reads = [str(r) for r in z['reads']]
     k, step = int(z['k']), int(z['step'])
     g = _graph(str(z['graph']))
     one = psi_amd.PathIndex.build(g, k, npaths, rng_seed=2, patched=patched)
     longest = max(sum(int(g.label_off[v + 1] - g.label_off[v]) for v in p) for p in one.paths())
-    px = psi_amd.PathIndex.build(g, k, npaths, rng_seed=2, patched=patched,
-                                 max_part_text=max(longest + 40, one.text_len // 5))      # at most 8 parts
+    cut = max(longest + 40, one.text_len // 5)      # at most 8 parts
+    px = psi_amd.PathIndex.build(g, k, npaths, rng_seed=2, patched=patched, max_part_text=cut, ftab_len=[0, 4, psi_amd.NO_FTAB][k % 3])
     assert px.view.n_more_parts >= 1
     assert [p.tolist() for p in px.paths()] == [p.tolist() for p in one.paths()] and px.trims() == one.trims()
     assert px.loci[0].tolist() == one.loci[0].tolist() and px.loci[1].tolist() == one.loci[1].tolist()
     f = psi_amd.SeedFinder(g, k)
     f.set_path_index(px)
-    if not query_mode.startswith('kmer-table'):
-        with pytest.raises(psi_amd.PsiGpuError, match='several parts'):
-            f.seeds_all(reads, step=step)
-        f.close()
-        return
     raw = f.seeds_all(reads, step=step)
     assert _eq(psi_amd.sort_unique(raw), z['hits'])
-    # raw emission: every on-path occurrence once, as from the one-part index
     f1 = psi_amd.SeedFinder(g, k)
     f1.set_path_index(one)
     raw1 = f1.seeds_all(reads, step=step)
-    assert len(raw) == len(raw1) and _eq(raw[np.lexsort(raw.T[::-1])], raw1[np.lexsort(raw1.T[::-1])])
+    if query_mode != 'traverse':
+        # raw emission: every on-path occurrence once, as from the one-part index
+        assert len(raw) == len(raw1) and _eq(raw[np.lexsort(raw.T[::-1])], raw1[np.lexsort(raw1.T[::-1])])
     su = f.seeds_all(reads, step=step, sort_unique=True)
     want = z['hits'][np.lexsort((z['hits'][:, 1], z['hits'][:, 0], z['hits'][:, 3], z['hits'][:, 2]))]
     assert _eq(su, want)
-    with pytest.raises(psi_amd.PsiGpuError, match='several parts'):
-        f.find_mems(reads[:3])
+    assert _eq(f.find_mems(reads[:40]), f1.find_mems(reads[:40]))
+    f.close()
+    # sampled suffix array in every part (FM modes: k_fm_walk per part; the k-mer table needs the whole array
+    # and leaves such an index to the FM kernels)
+    ps = psi_amd.PathIndex.build(g, k, npaths, rng_seed=2, patched=patched, max_part_text=cut, sa_rate=4)
+    assert ps.view.n_more_parts == px.view.n_more_parts and ps.view.sa_rate == 4
+    f = psi_amd.SeedFinder(g, k)
+    f.set_path_index(ps)
+    assert _eq(psi_amd.sort_unique(f.seeds_all(reads, step=step)), z['hits'])
     f.close(); f1.close()
 
 
@@ -1040,38 +1045,54 @@ def test_positions_deduplicated_at_table_build(query_mode):
     f.close(); f2.close(); f3.close()
 
 
-def test_index_without_fm_arrays(monkeypatch, query_mode):
-    """A text with more separators than a rank block header counts (2^24: the patches of a whole genome; here
-    the limit is lowered through the test hook) is indexed without rank blocks / interval table: answered
-    from the k-mer table, MEM mode included (it bisects the suffix array); the FM query modes refuse it."""
+def test_index_with_many_separators(monkeypatch, query_mode):
+    """A rank block header counts the separators in front of it in 24 bits -- from the start of its SUPER-BLOCK of
+    2^16 blocks; what lies in front of a super-block is a side array, so a text may hold any number (the 44.6 M
+    patches of a whole genome x 3 walks).  Here the super-blocks are shrunk to 2 / 1 blocks through the test
+    hook, so that every rank of a T and every exception lookup goes through the side array: same records as with
+    the default layout, host and device builders byte-identical, every query mode and MEM mode."""
     g, reads = _x_case()
     k = 12
-    one = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3)
-    monkeypatch.setenv('PSIGPU_TEST_SEP_LIMIT', '3')
-    px = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3, device=0)
-    py = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3)
-    monkeypatch.delenv('PSIGPU_TEST_SEP_LIMIT')
-    for ix in (px, py):
-        assert ix.view.n_more_parts == 0 and not ix.view.bwt_blocks and ix.view.n_blocks == 0 and one.view.n_blocks > 0
-        assert ix.loci[0].tolist() == one.loci[0].tolist() and ix.loci[1].tolist() == one.loci[1].tolist()
-        f = psi_amd.SeedFinder(g, k)
-        f.set_path_index(ix)
-        f1 = psi_amd.SeedFinder(g, k)
-        f1.set_path_index(one)
-        if not query_mode.startswith('kmer-table'):
-            with pytest.raises(psi_amd.PsiGpuError, match='k-mer table only'):
-                f.seeds_all(reads[:50], step=3)
-        else:
-            a, b = f.seeds_all(reads[:400], step=3), f1.seeds_all(reads[:400], step=3)
+    one = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3, sa_rate=2)
+    f1 = psi_amd.SeedFinder(g, k)
+    f1.set_path_index(one)
+    b = f1.seeds_all(reads[:400], step=3)
+    for shift in ('1', '0'):
+        monkeypatch.setenv('PSIGPU_TEST_EXC_SHIFT', shift)
+        px = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3, device=0, sa_rate=2)
+        py = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3, sa_rate=2)
+        monkeypatch.delenv('PSIGPU_TEST_EXC_SHIFT')
+        assert px.view.exc_shift == int(shift) and px.view.n_exc > 40
+        nb = px.view.n_blocks
+        assert nb == py.view.n_blocks == one.view.n_blocks
+        assert (px._arr(px.view.bwt_blocks, nb * 16, np.uint32) == py._arr(py.view.bwt_blocks, nb * 16, np.uint32)).all()
+        ns = ((nb - 1) >> int(shift)) + 1
+        sup = px._arr(px.view.exc_super, ns, np.uint32)
+        assert (sup == py._arr(py.view.exc_super, ns, np.uint32)).all() and sup[-1] > 0 and (np.diff(sup.astype(np.int64)) >= 0).all()
+        for ix in (px, py):
+            f = psi_amd.SeedFinder(g, k)
+            f.set_path_index(ix)
+            a = f.seeds_all(reads[:400], step=3)
             assert len(a) and _eq(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
-            assert _eq(f.find_mems(reads[:100]), f1.find_mems(reads[:100]))
-        f.close(); f1.close()
+            f.close()
+    f1.close()
+    # sa_rate 1: MEM mode and the k-mer table on the same layout
+    one = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3)
+    monkeypatch.setenv('PSIGPU_TEST_EXC_SHIFT', '0')
+    px = psi_amd.PathIndex.build(g, k, 4, rng_seed=1, patched=True, context=k + 3, device=0)
+    monkeypatch.delenv('PSIGPU_TEST_EXC_SHIFT')
+    f, f1 = psi_amd.SeedFinder(g, k), psi_amd.SeedFinder(g, k)
+    f.set_path_index(px); f1.set_path_index(one)
+    a, b = f.seeds_all(reads[:400], step=3), f1.seeds_all(reads[:400], step=3)
+    assert len(a) and _eq(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+    assert _eq(f.find_mems(reads[:100]), f1.find_mems(reads[:100]))
+    f.close(); f1.close()
 
 
 def test_index_parts_roundtrip_and_gocc(tmp_path, query_mode):
-    """Parts survive save / load; the gocc threshold counts a k-mer's occurrences over all parts."""
-    if not query_mode.startswith('kmer-table'):
-        pytest.skip('an index in several parts is answered from the k-mer table')
+    """Parts survive save / load; the gocc threshold counts a k-mer's occurrences over all parts (the FM modes:
+    k_parts_combine adds the parts' counts up before the threshold is applied; MEM mode: the sum of the parts'
+    intervals)."""
     g, reads = _x_case()
     k = 12
     one = psi_amd.PathIndex.build(g, k, 5, rng_seed=1)
@@ -1088,3 +1109,12 @@ def test_index_parts_roundtrip_and_gocc(tmp_path, query_mode):
         res[name] = psi_amd.sort_unique(f.seeds_all(reads[:300], step=3))
         f.close()
     assert len(res['one']) and _eq(res['one'], res['parts'])
+    # ... equal to the oracle's seeds_all( gocc_thr ) over the same paths
+    f = psi_amd.SeedFinder(g, k, gocc_threshold=3)
+    f.set_path_index(py)
+    bases, off = psi_amd.pack_reads(reads[:300])
+    assert _eq(res['parts'], _oracle_hits(_graph_arrays(g), f, bases, off, k, 3, gocc=3))
+    fm1 = psi_amd.SeedFinder(g, k, gocc_threshold=3)
+    fm1.set_path_index(one)
+    assert _eq(f.find_mems(reads[:60], max_mem=4), fm1.find_mems(reads[:60], max_mem=4))
+    f.close(); fm1.close()

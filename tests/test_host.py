@@ -467,10 +467,10 @@ def test_index_save_load_roundtrip(tmp_path, ref_data):
 
 @pytest.mark.parametrize('patched', [False, True])
 def test_index_in_several_parts_host(tmp_path, ref_data, patched):
-    """An index whose text would pass the row limit is cut into parts: consecutive groups of paths, each
-    with its own text / suffix array / segment table and no FM arrays (answered from the k-mer table).  Same
+    """An index whose text would pass the row limit is cut into parts: consecutive groups of paths, each a
+    complete FM index of its own (text, rank blocks, interval table, suffix array, segment table).  Same
     paths, trims and starting loci as the one-part index; the parts' segment tables tile the paths; the
-    container file carries the parts."""
+    container file carries the parts; every part's device layout finds its own paths' k-mers (emulated)."""
     b, g = _setup(ref_data, 'x')
     k = 16
     one = psi_amd.PathIndex.build(g, k, 4, rng_seed=3, patched=patched)
@@ -481,9 +481,9 @@ def test_index_in_several_parts_host(tmp_path, ref_data, patched):
     assert [p.tolist() for p in px.paths()] == [p.tolist() for p in one.paths()] and px.trims() == one.trims()
     assert px.loci[0].tolist() == one.loci[0].tolist() and px.loci[1].tolist() == one.loci[1].tolist()
     views = [px.view] + px.more_parts()
-    # no rank blocks / interval table in any part; whole suffix array and 4-bit text in every part
+    # rank blocks, exception super-block counts, whole suffix array and 4-bit text in every part
     for v in views:
-        assert not v.bwt_blocks and v.n_blocks == 0 and v.ftab_len == 0 and v.sa_rate == 1 and v.text4
+        assert v.bwt_blocks and v.n_blocks == v.text_len // 192 + 1 and v.exc_super and v.sa_rate == 1 and v.text4
     # the parts hold the paths in order: texts add up (the last separator of a part is its sentinel)
     assert sum(v.text_len for v in views) == one.text_len
     assert all(v.text_len <= max(max(lens) + 40, one.text_len // 4) for v in views)
@@ -497,11 +497,29 @@ def test_index_in_several_parts_host(tmp_path, ref_data, patched):
         assert (px._arr(a.text4, nt, np.uint64) == py._arr(c.text4, nt, np.uint64)).all()
         assert (px._arr(a.sa_samples, a.text_len, np.uint32) == py._arr(c.sa_samples, c.text_len, np.uint32)).all()
     assert [p.tolist() for p in py.paths()] == [p.tolist() for p in one.paths()] and py.trims() == one.trims()
-    # more than PSIGPU_MAX_PARTS parts, or a sampled suffix array, are refused
+    # more than PSIGPU_MAX_PARTS parts are refused; a sampled suffix array is fine
     with pytest.raises(psi_amd.PsiGpuError, match='too many parts'):
         psi_amd.PathIndex.build(g, k, 40, rng_seed=3, max_part_text=max(lens) + 40)
-    with pytest.raises(psi_amd.PsiGpuError, match='several parts'):
-        psi_amd.PathIndex.build(g, k, 4, rng_seed=3, sa_rate=4, max_part_text=max(max(lens) + 40, one.text_len // 4))
+    ps = psi_amd.PathIndex.build(g, k, 4, rng_seed=3, patched=patched, sa_rate=4, max_part_text=max(max(lens) + 40, one.text_len // 4))
+    assert ps.view.n_more_parts == n_more and all(v.n_samples == (v.text_len + 3) // 4 for v in [ps.view] + ps.more_parts())
+    # every part through the emulated device layout (tests/emu.py: interval table, LF steps with the exception
+    # super-block counts, locate, segment table): the union of the parts' answers = the one-part index's
+    from tests.emu import PartEmu
+    emus = [PartEmu(ps, v, g) for v in [ps.view] + ps.more_parts()]
+    e1 = IndexEmu(one, g)
+    seq = lambda p: ''.join(bytes(g.labels[g.label_off[v]:g.label_off[v + 1]]).decode() for v in p)
+    text = seq(one.paths()[0].tolist())
+    kmers = {text[i:i + k] for i in range(0, min(len(text), 3000) - k, 37)} - {''}
+    for km in sorted(kmers):
+        if 'N' in km:
+            continue
+        l, r = e1.search(km)
+        want = sorted(e1.map(e1.locate(i)) for i in range(l, r))
+        got = []
+        for e in emus:
+            l, r = e.search(km)
+            got += [e.map(e.locate(i)) for i in range(l, r)]
+        assert sorted(got) == want and want
 
 
 def test_index_argument_checks(ref_data):
