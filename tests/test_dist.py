@@ -74,3 +74,27 @@ def test_bench_two_ranks_one_gpu():
     assert j['config']['seeds_per_step_per_gpu'] == 140000 and j['value'] > 0
     g = j['gather_hits']
     assert g['records'] >= 2 * 140000 and g['sorted_by_read_id'] and g['backend'] == 'gloo'
+
+
+@pytest.mark.gpu
+def test_config3_harness_three_contexts_one_gpu():
+    """tools/wg_scale.py --devices: the harness for BASELINE.json configs[3] (whole-genome graph, 100 M reads over
+    the 8 GPUs of a node) at reduced size, the box's one GPU listed three times -- ONE process, ONE host index,
+    one context + host thread per listed device, contiguous read ranges with global read ids; psikt's default
+    indexing (3 patched walks) cut into several index parts, answered from the FM index of every part
+    (locus-table mode), compared with the k-mer table mode's records; MEM mode over the parts; the host entry
+    point through every context."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'wg_scale.py'), '--backbone', '3000000', '--snvs', '60000',
+           '--nblock', '200000', '--reads', '30000', '--devices', '0,0,0', '--paths', '3', '--patched',
+           '--max-part-text', '1500000', '--mode', 'locus-table', '--compare-modes', '--mems', '1500', '--host-entry',
+           '--steps', '2']
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    j = json.loads([l for l in p.stdout.split('\n') if l.startswith('{')][-1])
+    assert j['n_devices'] == 3 and j['index_parts'] >= 2 and j['query_mode'] == 'locus-table'
+    assert [d['reads'] for d in j['per_device']] == [10000, 10000, 10000]
+    assert j['all_seeds_found'] and j['first_base_agrees'] and j['same_records_as_kmer_table_mode']
+    assert j['counters']['n_seeds'] == 70000 and j['seeds_per_s'] > 0
+    assert j['mems_records'] >= 1500 and j['mems_first_pattern_at_sampled_locus'] and j['mems_min_len'] >= 21
+    assert j['host_entry_equals_device_entry'] and len(j['host_entry_ms_per_device']) == 3
