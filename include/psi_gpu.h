@@ -207,6 +207,16 @@ psigpu_index* psigpu_index_build_patches(const psigpu_graph* g, const psigpu_ind
                                          uint64_t n_paths, const uint64_t* path_off,
                                          const uint32_t* path_nodes, const uint32_t* head_off,
                                          const uint32_t* tail_len, int* status);
+/* PathIndex::load( prefix ) for a path index the REFERENCE wrote (pathindex.hpp:109-123): reads `paths_file` =
+ * `<prefix>_paths` -- PathIndex::save_paths_set (:315-332): u64 context, u64 direction, PathSet::serialize
+ * (pathset.hpp:260-274) = u64 #paths, then per path (path_base.hpp:551-560) an sdsl::enc_vector<elias_delta> of
+ * external node ids, u64 left, u64 right, an sdsl::bit_vector of node breaks -- and builds this library's index
+ * over those paths and trims (opts: seed_len, locus_step, sa_rate, ftab_len, build_on_device; the context comes
+ * from the file).  The companion `<prefix>` file (sdsl::csa_wt over the reversed text) is not read: the FM index
+ * is rebuilt.  sdsl's on-disk layouts are restated from its published sources (psi_amd/csrc/refio.cpp).
+ * *context_out / *forward_out (either may be NULL): the file's context and sequence direction. */
+psigpu_index* psigpu_index_from_reference_paths(const psigpu_graph* g, const psigpu_index_opts* opts, const char* paths_file,
+                                                uint64_t* context_out, uint32_t* forward_out, int* status);
 void psigpu_index_free(psigpu_index* x);
 int psigpu_index_view_get(const psigpu_index* x, psigpu_index_view* out);
 /* SeedFinder::serialize_path_index / load_path_index (seed_finder.hpp:1372-1413); own

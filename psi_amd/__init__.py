@@ -108,6 +108,7 @@ ABI = [
     ('psigpu_index_build_paths', _P, [_P, C.POINTER(IndexOpts), C.c_uint64, _P, _P, _INTP]),
     ('psigpu_index_build_patches', _P, [_P, C.POINTER(IndexOpts), C.c_uint64, _P, _P, _P, _P, _INTP]),
     ('psigpu_index_path_trim', C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ('psigpu_index_from_reference_paths', _P, [_P, C.POINTER(IndexOpts), C.c_char_p, _U64P, C.POINTER(C.c_uint32), _INTP]),
     ('psigpu_index_matches', C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
     ('psigpu_index_locus_step', C.c_uint32, [_P]),
     ('psigpu_index_set_locus_step', C.c_int, [_P, _P, C.c_uint32]),
@@ -352,6 +353,21 @@ class PathIndex:
         if not h:
             raise PsiGpuError('index build failed (%d): %s' % (st.value, _host_err()))
         return cls(h)
+
+    @classmethod
+    def from_reference_paths(cls, g: Graph, k: int, paths_file: str, step: int = 1, sa_rate: int = 0, ftab_len: int = 0,
+                             device: Optional[int] = None) -> 'PathIndex':
+        """An index over the paths of a `<prefix>_paths` file written by the reference's
+        PathIndex::save_paths_set (enc_vector node lists, trims, node-break bit vectors)."""
+        st = C.c_int(0)
+        ctx, fwd = C.c_uint64(0), C.c_uint32(0)
+        opts = IndexOpts(k, 0, step, sa_rate, ftab_len, 0, 0, 0 if device is None else device + 1, 0, 0, 0, 0)
+        h = lib().psigpu_index_from_reference_paths(g.h, C.byref(opts), paths_file.encode(), C.byref(ctx), C.byref(fwd), C.byref(st))
+        if not h:
+            raise PsiGpuError('cannot read %s (%d): %s' % (paths_file, st.value, _host_err()))
+        px = cls(h)
+        px.ref_context, px.ref_forward = ctx.value, bool(fwd.value)
+        return px
 
     @classmethod
     def load(cls, prefix: str) -> 'PathIndex':

@@ -182,6 +182,28 @@ psigpu_index* psigpu_index_build_patches(const psigpu_graph* g, const psigpu_ind
   return wrap_index(x, st, err, status);
 }
 
+// An index over the paths a reference-written `<prefix>_paths` file holds (refio.cpp): the paths and their trims are
+// read, the FM index and the starting loci are made here (the file's own node-id index and the companion
+// `<prefix>` file -- an sdsl::csa_wt of the reversed text -- are not needed for that).
+psigpu_index* psigpu_index_from_reference_paths(const psigpu_graph* g, const psigpu_index_opts* opts, const char* paths_file,
+                                                uint64_t* context_out, uint32_t* forward_out, int* status)
+{
+  if (!g || !opts || !paths_file) { if (status) *status = PSIGPU_ERR_ARG; return nullptr; }
+  std::vector<std::vector<uint32_t>> paths;
+  std::vector<uint32_t> head, tail;
+  uint64_t context = 0;
+  bool forward = false;
+  std::string err;
+  int st = read_reference_paths(paths_file, g->g, &context, &forward, paths, head, tail, &err);
+  if (st != PSIGPU_OK) { g_host_err = err; if (status) *status = st; return nullptr; }
+  if (context_out) *context_out = context;
+  if (forward_out) *forward_out = forward ? 1u : 0u;
+  psigpu_index_opts o = *opts;
+  o.context = (uint32_t)std::min<uint64_t>(context, 0xFFFFFFFFull);        // PathIndex::load_paths_set takes the file's (pathindex.hpp:286-289)
+  Index* x = build_index(g->g, o, paths, head, tail, &st, &err);
+  return wrap_index(x, st, err, status);
+}
+
 void psigpu_index_free(psigpu_index* x) { delete x; }
 
 static void fill_view(const Index& x, const Index& first, psigpu_index_view* v)

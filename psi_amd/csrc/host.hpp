@@ -90,6 +90,11 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
                         std::vector<uint32_t>& loci_off);
 int save_index(const Index& x, const std::string& prefix);
 
+// refio.cpp: the reference's `<prefix>_paths` file -> paths (node ranks) and their trims
+int read_reference_paths(const std::string& file, const Graph& g, uint64_t* context, bool* forward,
+                         std::vector<std::vector<uint32_t>>& paths, std::vector<uint32_t>& head,
+                         std::vector<uint32_t>& tail, std::string* err);
+
 // build_gpu.hip: suffix array + FM arrays on the device (same results as the host path)
 int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, int device, Index* x,
                  std::vector<int32_t>* sa_out, std::string* err);

@@ -184,6 +184,24 @@ namespace psi {
       return true;
     }
 
+    /** PathIndex::load( prefix ) for an index the REFERENCE wrote: `<prefix>_paths` (save_paths_set,
+     *  reference pathindex.hpp:315-332) holds the paths and their trims in sdsl's enc_vector / bit_vector
+     *  layouts; the FM index over them is rebuilt (the `<prefix>` file, an sdsl::csa_wt, is not read). */
+    bool load_reference( std::string const& prefix, psigpu_index_opts const& opts )
+    {
+      if ( prefix.empty() || graph_ptr == nullptr ) return false;
+      int st = 0;
+      std::uint64_t ctx_in_file = 0;
+      psigpu_index* x = psigpu_index_from_reference_paths( graph_ptr->handle(), &opts, ( prefix + "_paths" ).c_str(),
+                                                           &ctx_in_file, nullptr, &st );
+      if ( x == nullptr ) return false;
+      if ( context != 0 && context != ctx_in_file ) { psigpu_index_free( x ); return false; }      /* load_paths_set :288-289 */
+      context = ctx_in_file;
+      reset( x );
+      sync_paths();
+      return true;
+    }
+
     /** PathIndex::serialize( prefix ) (reference pathindex.hpp:135-143). */
     bool serialize( std::string const& prefix ) const
     {

@@ -132,7 +132,14 @@ namespace psi {
     bool load_path_index( std::string const& prefix, unsigned int /*context*/ = 0,
                           unsigned int step_size = 1, unsigned int = 0, unsigned int = 0 )
     {
-      if ( !pindex.load( prefix ) ) return false;
+      if ( !pindex.load( prefix ) ) {
+        /* no container of this library: a path index the reference wrote?  `<prefix>_paths` gives the paths
+         * and their trims; the FM index and the starting loci are made from them */
+        psigpu_index_opts o{};
+        o.seed_len = seed_len; o.locus_step = step_size;
+        o.build_on_device = device_ < 0 ? 0u : static_cast< unsigned int >( device_ ) + 1u;
+        if ( !pindex.load_reference( prefix, o ) ) return false;
+      }
       if ( !psigpu_index_matches( pindex.handle(), graph_ptr->handle(), seed_len, step_size ) ) {
         /* same graph and seed length, other locus step: the paths are still good, and the loci for this
          * step are recomputed from them (the reference recomputes too when open_starts finds no file for

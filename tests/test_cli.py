@@ -98,6 +98,17 @@ def test_output_bytes_match_golden(tmp_path):
     assert 'The path index has been found and loaded.' in open(str(tmp_path / 'psi2.log')).read()
     got = _records(out)
     assert got.shape == want.shape and (got == want).all()
+    # a path index the REFERENCE wrote: `<prefix>_paths` alone (enc_vector node lists, trims, node breaks -- the
+    # committed fixture holds test_pathindex.cpp's three trimmed paths, context 10) is read, the FM index rebuilt
+    import shutil
+    pre3 = str(tmp_path / 'refidx')
+    shutil.copy(os.path.join(GOLDEN, 'ref_paths_x_trimmed.bin'), pre3 + '_paths')
+    out = str(tmp_path / 'o7')
+    p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '10', '-n', '3', '-I', pre3, '-o', out, '-L', str(tmp_path / 'psi4.log'))
+    assert p.returncode == 0, p.stderr
+    assert 'The path index has been found and loaded.' in open(str(tmp_path / 'psi4.log')).read()
+    got = _records(out)
+    assert got.shape == want.shape and (got == want).all()
     # ... while a file made for another seed length is not a valid index for this run
     p = run(os.path.join(REF, 'x.gfa'), '-f', fq, '-l', '9', '-d', '10', '-n', '1', '-I', pre2, '-o', str(tmp_path / 'o6'),
             '-L', str(tmp_path / 'psi3.log'))

@@ -404,6 +404,104 @@ def test_other_locus_step_recomputes_and_ignores_stale_sidecar(tmp_path, ref_dat
     assert px.matches(g, 12, 3) and not px.matches(g_base, 12, 3) and not px.matches(g_edge, 12, 3)
 
 
+def test_reference_paths_file(tmp_path, ref_data, golden_dir):
+    """`<prefix>_paths` as the reference writes it (PathIndex::save_paths_set pathindex.hpp:315-332 ->
+    PathSet::serialize pathset.hpp:260-274 -> Path::serialize path_base.hpp:551-560; sdsl's enc_vector /
+    int_vector / bit_vector layouts): the committed fixture holds the three trimmed paths of
+    test_pathindex.cpp:248-255 (context 10, Reversed); the product's reader must recover the paths, the trims
+    and -- through the rebuilt index -- the trimmed sequences the reference asserts (:166-168).  The fixture comes
+    from an independent statement of the format (tests/golden/make_ref_paths.py); a few of its bytes are also
+    spelled out here by hand."""
+    import struct
+    sys_path = os.path.join(golden_dir)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_ref_paths', os.path.join(sys_path, 'make_ref_paths.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    b, g = _setup(ref_data, 'x')
+    fixture = os.path.join(golden_dir, 'ref_paths_x_trimmed.bin')
+    raw = open(fixture, 'rb').read()
+    # by hand: header; then path 0 = ids 205 207 209 210 -> deltas 2 2 1 -> Elias-delta codes 0100 0100 1 (LSB first)
+    # = 0x122 in 9 bits; one sample (205, pointer 0) + the closing pair (0, 9 + 1), 8 bits each
+    assert raw[:24] == struct.pack('<QQQ', 10, 0, 3)
+    assert raw[24:32] == struct.pack('<Q', 4)
+    assert raw[32:41] == struct.pack('<QB', 9, 1) and raw[41:49] == struct.pack('<Q', 0x122)
+    assert raw[49:58] == struct.pack('<QB', 32, 8) and raw[58:66] == struct.pack('<Q', 0x0A0000CD)
+    assert raw[66:82] == struct.pack('<QQ', 9, 0)                         # left 9; right 9 >= the last node's 1 base -> 0
+    assert raw[82:90] == struct.pack('<Q', 36) and raw[90:98] == struct.pack('<Q', (1 << 8) | (1 << 33) | (1 << 34) | (1 << 35))
+    assert raw == m.paths_file(10, False, [([205, 207, 209, 210], 9, 9), ([187, 189, 191, 193, 194, 195, 197], 9, 9),
+                                           ([167, 168, 171, 172, 174], 9, 9)], m.x_node_lengths())
+    px = psi_amd.PathIndex.from_reference_paths(g, 10, fixture)
+    assert px.ref_context == 10 and px.ref_forward is False and px.view.context == 10
+    ids = [[b.ids[v] for v in p.tolist()] for p in px.paths()]
+    assert ids == [[205, 207, 209, 210], [187, 189, 191, 193, 194, 195, 197], [167, 168, 171, 172, 174]]
+    assert px.trims() == [(18, 0), (0, 0), (21, 9)]                        # head offsets 27 - 9, -, 30 - 9; tails -, -, 9
+    trimmed = ['GTTTCCTGTACTAAGGACAAAGGTGCGGGGAGATAA', 'CAAGGGCTTTTAA', 'CATTTGTCTTATTGTCCAGGA']       # test_pathindex.cpp:166-168
+    same = psi_amd.PathIndex.build_paths(g, 10, [p.tolist() for p in px.paths()], head=[18, 0, 21], tail=[0, 0, 9], context=10, keep=True)
+    text = ''.join('#$ACGT'[c] for c in same.text().tolist())
+    assert text == '$'.join(trimmed) + '#'
+    assert px.loci[0].tolist() == same.loci[0].tolist() and px.text_len == same.text_len
+    # a long path (several samples of 128 ids), ids that go DOWN (deltas wrap mod 2^64), a one-node path with
+    # both trims, an empty path set; random graphs' paths through writer and reader
+    rng = np.random.default_rng(7)
+    g2, b2 = g, b
+    walks = []
+    for seed in range(6):
+        ix = psi_amd.PathIndex.build(g2, 12, 3, rng_seed=seed, patched=seed % 2 == 1, context=14 if seed % 2 else 0)
+        walks.append(ix)
+    nl = m.x_node_lengths()
+    for ix in walks:
+        recs = []
+        for p, (h, t) in zip(ix.paths(), ix.trims()):
+            pid = [b2.ids[v] for v in p.tolist()]
+            recs.append((pid, nl[pid[0]] - h if h else 0, t))
+        fn = str(tmp_path / 'w_paths')
+        open(fn, 'wb').write(m.paths_file(ix.view.context, True, recs, nl) + b'trailing bytes: the node-id index follows here')
+        py = psi_amd.PathIndex.from_reference_paths(g2, 12, fn)
+        assert [p.tolist() for p in py.paths()] == [p.tolist() for p in ix.paths()] and py.trims() == ix.trims()
+        assert py.loci[0].tolist() == ix.loci[0].tolist() and py.loci[1].tolist() == ix.loci[1].tolist()
+        assert py.ref_forward is True and py.text_len == ix.text_len
+    assert max(len(p) for p in walks[0].paths()) > 128
+    # the coder itself on values no graph path has: zero and negative deltas, 64-bit values
+    vals = [5, 5, 3, 2 ** 63, 2 ** 64 - 1, 0, 1] + list(range(1000, 1300)) + [7]
+    blob = m.enc_vector(vals)
+    fn = str(tmp_path / 'ev')
+    lens = {int(v): 1 for v in g.node_id}
+    # (through the file reader: a path set whose first path's ids are not in the graph is rejected with the id named)
+    open(fn, 'wb').write(struct.pack('<QQQ', 0, 1, 1) + blob + struct.pack('<QQ', 0, 0) + m.bit_vector([], 0))
+    with pytest.raises(psi_amd.PsiGpuError, match='is not in this graph'):
+        psi_amd.PathIndex.from_reference_paths(g, 12, fn)
+    # ... and decoded: a graph whose ids are those values, a path that walks them in that order (a self loop gives the
+    # zero delta, descending ids the wrapped ones, 2^63 / 2^64 - 1 the 64-bit codes)
+    order = [5, 5, 3, 2 ** 63, 2 ** 64 - 1, 0, 1] + list(range(1000, 1300)) + [7]
+    uniq = list(dict.fromkeys(order))
+    rk = {v: i for i, v in enumerate(uniq)}
+    edges = {}
+    for a_, b_ in zip(order, order[1:]):
+        edges.setdefault(rk[a_], [])
+        if rk[b_] not in edges[rk[a_]]:
+            edges[rk[a_]].append(rk[b_])
+    eo = np.cumsum([0] + [len(edges.get(i, [])) for i in range(len(uniq))])
+    et = [t for i in range(len(uniq)) for t in edges.get(i, [])]
+    labs = ''.join('ACGT'[(i * 7 + i // 3) % 4] * 2 for i in range(len(uniq)))
+    gw = psi_amd.Graph.from_csr(np.array(uniq, dtype=np.uint64), np.arange(0, 2 * len(uniq) + 1, 2), labs.encode(), eo, et,
+                                paths=[[rk[v] for v in order]])
+    open(fn, 'wb').write(m.paths_file(0, True, [(order, 0, 0)], {v: 2 for v in uniq}))
+    pw = psi_amd.PathIndex.from_reference_paths(gw, 5, fn)
+    assert [uniq[r] for r in pw.paths()[0].tolist()] == order
+    # corrupt / truncated files are format errors, not crashes
+    for cut in (10, 40, 70, len(raw) - 3):
+        open(fn, 'wb').write(raw[:cut])
+        with pytest.raises(psi_amd.PsiGpuError):
+            psi_amd.PathIndex.from_reference_paths(g, 10, fn)
+    bad = bytearray(raw); bad[82] = 35                                      # node breaks one bit short
+    open(fn, 'wb').write(bytes(bad))
+    with pytest.raises(psi_amd.PsiGpuError, match='node breaks'):
+        psi_amd.PathIndex.from_reference_paths(g, 10, fn)
+    with pytest.raises(psi_amd.PsiGpuError):
+        psi_amd.PathIndex.from_reference_paths(g, 10, str(tmp_path / 'missing_paths'))
+
+
 def test_reference_loci_file_format(tmp_path, ref_data):
     """`<prefix>_loci_e<E>l<K>` (reference SeedFinder::save_starts / open_starts, seed_finder.hpp:1640-1679;
     utils.hpp:521-588): u64 count + raw { node id, offset } records with external ids."""
