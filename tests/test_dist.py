@@ -96,5 +96,5 @@ def test_config3_harness_three_contexts_one_gpu():
     assert [d['reads'] for d in j['per_device']] == [10000, 10000, 10000]
     assert j['all_seeds_found'] and j['first_base_agrees'] and j['same_records_as_kmer_table_mode']
     assert j['counters']['n_seeds'] == 70000 and j['seeds_per_s'] > 0
-    assert j['mems_records'] >= 1500 and j['mems_first_pattern_at_sampled_locus'] and j['mems_min_len'] >= 21
+    assert j['mems_records'] >= 1500 and j['mems_first_pattern_subset_of_seed_hits'] and j['mems_min_len'] >= 21
     assert j['host_entry_equals_device_entry'] and len(j['host_entry_ms_per_device']) == 3

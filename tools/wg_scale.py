@@ -211,18 +211,19 @@ def main():
         del a, b
         sh0.f.set_query_mode(args.mode)
     if args.mems:
-        # MEM mode (find_mems, minimum length k) on the first reads: an error-free read is spelled by a walk, so its
-        # first pattern (read offset 0) must be reported at the position the read was sampled from -- the position
-        # of the read's first seed hit
+        # MEM mode (find_mems, minimum length k) on the first reads: a read's first pattern is reported the moment it is
+        # k bases long, with every occurrence ON THE INDEXED PATHS -- exactly the on-path hits of the read's seed at
+        # offset 0, hence a subset of that seed's hits (which also hold what the starting loci contribute)
         nm = min(args.mems, sh0.r1 - sh0.r0)
         t = time.perf_counter()
         mems = sh0.f.find_mems((bases[:int(off[nm])], off[:nm + 1]))
         out['mems_ms'] = (time.perf_counter() - t) * 1e3
         out['mems_records'] = int(len(mems))
-        first_mem = mems[mems[:, 3] == 0]
+        first_mem = mems[(mems[:, 3] == 0) & (mems[:, 4] == args.k)]
         seed0 = hits[(hits[:, 3] == 0) & (hits[:, 2] < nm)]
         key = lambda x: set(map(tuple, x[:, :3].tolist()))      # noqa: E731
-        out['mems_first_pattern_at_sampled_locus'] = bool(key(seed0) <= key(first_mem))
+        out['mems_first_patterns'] = int(len(first_mem))
+        out['mems_first_pattern_subset_of_seed_hits'] = bool(len(first_mem) > 0 and key(first_mem) <= key(seed0))
         out['mems_min_len'] = int(mems[:, 4].min()) if len(mems) else 0
         log('MEM mode: %d records for %d reads in %.0f ms' % (len(mems), nm, out['mems_ms']))
     if args.host_entry:
