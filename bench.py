@@ -499,7 +499,7 @@ def main():
         t_pg, _ = host_entry(pageable_src, psi_amd.ALL | psi_amd.SORT_UNIQUE, 6)
         c_e = finder.counters()
         bytes_in = float(len(batches[0][0]) + 8 * (args.reads + 1))
-        bytes_out = 32.0 * n_su
+        bytes_out = float(c_e['wire_bytes_per_hit'] or 32) * n_su       # (16-byte wire records, widened on the host)
         pcie_bound_ms = max(bytes_in, bytes_out) / (PCIE_PEAK_GBS * 1e9) * 1e3
         out['end_to_end'] = {
             'what': 'psigpu_find_seeds: H2D of the reads + kernels + sort-unique on the device + D2H of the hits '
@@ -510,6 +510,7 @@ def main():
             'pageable_reads_ms_per_step': t_pg * 1e3,
             'device_ms_per_step': float(c_e['ms_total']), 'device_sort_ms_per_step': float(c_e['ms_sort']),
             'sub_batches_sorted_in_place': int(c_e['sorted_in_place']),      # (of the last call: no radix sort needed)
+            'wire_bytes_per_hit': int(c_e['wire_bytes_per_hit']),
             'roofline': {'bound': 'pcie', 'achieved': max(bytes_in, bytes_out) / t_su / 1e9, 'peak': PCIE_PEAK_GBS,
                          'unit': 'GB/s', 'frac': pcie_bound_ms / (t_su * 1e3), 'bytes_in': bytes_in, 'bytes_out': bytes_out,
                          'note': 'full duplex: the bound is max(bytes in, bytes out) / one-direction rate'},

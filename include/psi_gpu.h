@@ -330,7 +330,9 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k);
  * chunk (sequence.hpp:1616).  Hits come back in library-owned pinned host memory.
  * This is SURVEY 8(d)'s timed region (H2D of the reads + kernels + D2H of the hits): the chunk
  * is cut into sub-batches that are pipelined over three streams, so the call costs about
- * max(bytes in, bytes out) / PCIe rate.  Reads held in pinned memory (psigpu_host_alloc) are
+ * max(bytes in, bytes out) / PCIe rate.  The records cross the link as 4 x u32 (node id - first id, node
+ * offset, read id - the sub-batch's first, read offset) when the graph's ids are rank + constant, and are
+ * widened to psigpu_hit by host threads while the next sub-batch is in flight.  Reads held in pinned memory (psigpu_host_alloc) are
  * DMA'd in place; pageable reads are staged by a helper thread. */
 int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off,
                       uint64_t n_reads, uint32_t k, uint32_t step, uint64_t rec_offset,
@@ -400,7 +402,8 @@ typedef struct psigpu_counters {
   uint32_t search_launches, traverse_launches;
   uint32_t sorted_in_place;                    /* PSIGPU_SORT_UNIQUE: sub-batches whose hits, emitted seed by seed, only needed
                                                 * the hits of each seed put in order (no radix sort) */
-  uint32_t reserved0;
+  uint32_t wire_bytes_per_hit;                 /* psigpu_find_seeds: bytes per record on the device-to-host link (16: packed, widened
+                                                * on the host; 32: as returned); 0 for the device-resident entry */
   uint64_t n_locate_steps;                     /* LF steps K2 walked from occurrences to sampled suffix-array rows (sa_rate > 1) */
 } psigpu_counters;
 int psigpu_get_counters(const psigpu_ctx* ctx, psigpu_counters* out);

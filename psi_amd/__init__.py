@@ -83,7 +83,7 @@ class Counters(C.Structure):
                 ('ms_locate', C.c_float), ('ms_traverse', C.c_float), ('ms_sort', C.c_float),
                 ('ms_total', C.c_float), ('ms_probe', C.c_float), ('ms_locus_table_build', C.c_float),
                 ('search_launches', C.c_uint32),
-                ('traverse_launches', C.c_uint32), ('sorted_in_place', C.c_uint32), ('reserved0', C.c_uint32),
+                ('traverse_launches', C.c_uint32), ('sorted_in_place', C.c_uint32), ('wire_bytes_per_hit', C.c_uint32),
                 ('n_locate_steps', C.c_uint64)]
 
     def as_dict(self):

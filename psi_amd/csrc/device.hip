@@ -2400,6 +2400,27 @@ __global__ void k_mem_counts(const MemGroup* __restrict__ groups, uint64_t n, ui
 }
 
 // ------------------------------------------------------------------------------------
+// The host entry's wire format.  A hit record is 4 x u64 (psi::Seed<> as psikt writes it), but of its 32 bytes
+// only about 12 carry information: the link out of the device is the bound of the host entry (224 MB of
+// records against 158 MB of reads per 1 M-read chunk), so the records cross it as 4 x u32 -- node id minus the
+// graph's first id (ids that are rank + constant), node offset, read id minus the sub-batch's first, read offset
+// -- and host threads widen them into the caller's 32-byte records while the next sub-batch is in flight.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_hits_wire16(const psigpu_hit* __restrict__ hits, const unsigned long long* __restrict__ n_a, const unsigned long long* __restrict__ n_b,
+              uint64_t n_fixed, uint64_t cap, uint64_t id_base, uint64_t rec_base, uint4* __restrict__ out)
+{
+  // the number of hits: on the device (n_a [+ n_b]) when the host does not know it yet, else n_fixed
+  const uint64_t n = min(n_a ? (uint64_t)*n_a + (n_b ? (uint64_t)*n_b : 0ull) : n_fixed, cap);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(hits + i);
+    const ulonglong2 a = src[0], b = src[1];
+    out[i] = make_uint4((uint32_t)(a.x - id_base), (uint32_t)a.y, (uint32_t)(b.x - rec_base), (uint32_t)b.y);
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // The part's random-access rate, measured in place (psigpu_measure_random_loads): what the probe of the k-mer
 // table (one divergent 16-byte load per lane) and the LF / locate kernels (one 64-byte sector per quad) are
 // bounded by.  QUAD = false: every lane loads 16 bytes from a sector of its own; QUAD = true: the four lanes
@@ -2541,6 +2562,8 @@ struct psigpu_ctx {
     void* h_stage = nullptr; size_t h_cap = 0;   // pinned staging: rebased read offsets, and the bases of pageable callers
     void* h_stage_dev = nullptr;                 // the same memory as the device addresses it
     hipEvent_t in_ready = nullptr, out_done = nullptr;
+    DevBuf d_wire;                               // 16-byte wire records of the slot's sub-batch (k_hits_wire16)
+    void* h_wire = nullptr; size_t h_wire_cap = 0;   // pinned: where they land on the host, before they are widened
   } slot[2];
   DevBuf w_hits_alt;
   hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
@@ -2654,8 +2677,9 @@ void psigpu_destroy(psigpu_ctx* ctx)
   for (auto& m : ctx->parts) m->release();
   ctx->w_hits_alt.release();
   for (auto& sl : ctx->slot) {
-    sl.bases.release(); sl.off.release();
+    sl.bases.release(); sl.off.release(); sl.d_wire.release();
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+    if (sl.h_wire) (void)hipHostFree(sl.h_wire);
     if (sl.in_ready) (void)hipEventDestroy(sl.in_ready);
     if (sl.out_done) (void)hipEventDestroy(sl.out_done);
   }
@@ -3393,8 +3417,10 @@ static GraphView graph_view(const psigpu_ctx* ctx)
 
 static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off,
                         uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t rec_offset,
-                        uint32_t flags, hipStream_t stream, uint64_t* n_hits_out)
+                        uint32_t flags, hipStream_t stream, uint64_t* n_hits_out, DevBuf* wire = nullptr)
 {
+  // `wire`: the host entry's 16-byte records of the call's hits (k_hits_wire16), made behind the last kernel of the
+  // call so that they are ready at its one host synchronisation
   // PSIGPU_SORT_UNIQUE here: the caller will sort -- when the hits come out seed by seed, order each seed's
   // hits in place before the counters go back, so that the answer to "was that enough?" comes with them
   const bool want_sorted = (flags & PSIGPU_SORT_UNIQUE) != 0;
@@ -3829,6 +3855,11 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
       if (fs != PSIGPU_OK) return fs;
     }
     EVREC(8, stream);
+    if (wire && cap) {
+      HIPCHK(ctx, wire->ensure((cap + 1) * 16));
+      k_hits_wire16<<<2048, 256, 0, stream>>>(d_hits, &ctr->n_hits_tab.v, &ctr->n_hits_off.v, 0, cap, ctx->id_base, rec_offset,
+                                              wire->as<uint4>());
+    }
     k_publish<<<1, 256, 0, stream>>>(reinterpret_cast<const uint4*>(ctr), reinterpret_cast<uint4*>(ctx->h_pinned_dev), (uint32_t)(sizeof(DevCounters) / 16));
     HIPCHK(ctx, hipStreamSynchronize(stream));
     ctx->grouped_state = fix_groups ? (h.not_grouped.v ? 2 : 1) : 0;
@@ -4141,6 +4172,48 @@ void parallel_copy(char* dst, const char* src, size_t n)
 
 }  // namespace
 
+namespace {
+
+// Widening of the wire records (k_hits_wire16) into the caller's 32-byte records on a few host threads, sub-batch
+// after sub-batch, while the pipeline goes on.  Job j: `n` records from a slot's pinned landing buffer to `dst`;
+// thread 0 waits for the slot's transfer, then every thread widens its slice.
+struct Widener {
+  struct Job { const uint4* src; psigpu_hit* dst; uint64_t n, id_base, rec_base; int slot; };
+  std::vector<Job> jobs;
+  std::atomic<size_t> posted{ 0 }, ready{ 0 }, finished{ 0 };
+  std::atomic<uint64_t> parts{ 0 };
+  std::atomic<bool> stop{ false };
+  std::vector<std::thread> th;
+  std::function<void(int)> wait_copy;           // blocks until the slot's device-to-host transfer is complete
+  unsigned T = 0;
+
+  void start(unsigned n_threads, size_t n_jobs, std::function<void(int)> wc)
+  {
+    T = n_threads; jobs.resize(n_jobs); wait_copy = std::move(wc);
+    for (unsigned t = 0; t < T; ++t) th.emplace_back([this, t] { run(t); });
+  }
+  void post(size_t j, const Job& job) { jobs[j] = job; posted.store(j + 1, std::memory_order_release); }
+  void wait_finished(size_t upto) const { while (finished.load(std::memory_order_acquire) < upto) std::this_thread::yield(); }
+  void run(unsigned t)
+  {
+    for (size_t j = 0; j < jobs.size(); ++j) {
+      while (posted.load(std::memory_order_acquire) <= j) { if (stop.load()) return; std::this_thread::yield(); }
+      const Job job = jobs[j];
+      if (t == 0) { if (job.n) wait_copy(job.slot); ready.store(j + 1, std::memory_order_release); }
+      else while (ready.load(std::memory_order_acquire) <= j) { if (stop.load()) return; std::this_thread::yield(); }
+      const uint64_t a = job.n * t / T, b = job.n * (t + 1) / T;
+      for (uint64_t i = a; i < b; ++i) {
+        const uint4 w = job.src[i];
+        job.dst[i] = psigpu_hit{ job.id_base + w.x, w.y, job.rec_base + w.z, w.w };
+      }
+      if (parts.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint64_t)T * (j + 1)) finished.store(j + 1, std::memory_order_release);
+    }
+  }
+  ~Widener() { stop = true; for (auto& x : th) if (x.joinable()) x.join(); }
+};
+
+}  // namespace
+
 extern "C" {
 
 // Streams and events of the host entry's pipeline, made on its first call.
@@ -4346,7 +4419,9 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   // output: pinned, sized from what earlier calls produced per read; regrown when a chunk has more
   uint64_t out_cap = 0, done = 0;
   psigpu_hit* hp = nullptr;
+  Widener* wd = nullptr;                            // set once the widener runs: hp must not move or go while it writes
   auto fail = [&](int st) {
+    if (wd) wd->wait_finished(wd->posted.load());
     if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }      // transfers into hp still in flight
     else if (ctx->s_out) (void)hipStreamSynchronize(ctx->s_out);
     if (hp) g_pinned.put(hp);
@@ -4355,6 +4430,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   };
   auto out_reserve = [&](uint64_t want_records) -> int {
     if (want_records <= out_cap) return PSIGPU_OK;
+    if (wd) wd->wait_finished(wd->posted.load());
     if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }
     else HIPCHK(ctx, hipStreamSynchronize(ctx->s_out));
     const uint64_t cap2 = want_records + want_records / 4 + 4096;
@@ -4370,6 +4446,18 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     if (st != PSIGPU_OK) return st;
   }
 
+  // 16-byte records over the link, widened on the host (k_hits_wire16): when the node ids are rank + constant
+  static const bool env_no_wire = getenv("PSIGPU_NO_WIRE16") != nullptr;      // A/B: 32-byte records over the link
+  const bool wire16 = ctx->id_affine && !env_no_wire;
+  Widener widener;                                  // (destroyed -- joined -- before hp can be handed back on an error path)
+  if (wire16) {
+    wd = &widener;
+    const unsigned hw = std::thread::hardware_concurrency();
+    widener.start(std::max(1u, std::min(8u, hw / 4)), n_sub, [ctx](int slot_) {
+      if (ctx->ec.ok) engine_wait(ctx->ec.sig_out[slot_]);
+      else { (void)hipSetDevice(ctx->device); (void)hipEventSynchronize(ctx->slot[slot_].out_done); }
+    });
+  }
   psigpu_counters acc{};
   const bool trace = getenv("PSIGPU_TRACE") != nullptr;        // per-sub-batch host timeline on stderr
   auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -4413,13 +4501,16 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     uint64_t n = 0;
     if (trace) { tr.push_back(now_ms() - t_call); tmark(sc); }
     k_publish<<<64, 256, 0, sc>>>(reinterpret_cast<const uint4*>(sl.h_stage_dev), sl.off.as<uint4>(), (uint32_t)(((nr + 1) * 8 + 15) / 16));
+    if (wire16 && i >= 2) widener.wait_finished(i - 1);          // the slot's landing buffer: job i - 2 has been widened
     int st = run_pipeline(ctx, sl.bases.as<char>(), sl.off.as<uint64_t>(), nr, nb, k, step, rec_offset + r0,
-                          flags | ((want_sort && !host_sort && getenv("PSIGPU_NO_GROUPED_SORT") == nullptr) ? PSIGPU_SORT_UNIQUE : 0u), sc, &n);
+                          flags | ((want_sort && !host_sort && getenv("PSIGPU_NO_GROUPED_SORT") == nullptr) ? PSIGPU_SORT_UNIQUE : 0u), sc, &n,
+                          wire16 ? &sl.d_wire : nullptr);
     if (st != PSIGPU_OK) return fail(st);
     if (trace) tr.push_back(now_ms() - t_call);
     consumed.store(i + 1, std::memory_order_release);
     const psigpu_counters pc = ctx->last;
     const psigpu_hit* src = ctx->w_hits.as<psigpu_hit>();
+    const int grouped_before = ctx->grouped_state;      // 1: run_pipeline ordered each seed's hits and that was all
     float ms_sort = 0.f;
     if (want_sort && !host_sort && n) {
       uint64_t nu = 0;
@@ -4428,6 +4519,18 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
       if (st == PSIGPU_ERR_FORMAT) host_sort = true;
       else if (st != PSIGPU_OK) return fail(st);
       else { n = nu; if (!in_place) src = ctx->w_sorted[i & 1].as<psigpu_hit>(); ms_sort = ctx->last.ms_sort; }
+    }
+    bool wire_now = wire16 && !host_sort;
+    // the wire records run_pipeline left are those of w_hits as it was at the end of the call: still good unless
+    // the records were sorted afterwards (the radix route writes elsewhere; device_sort_unique's own in-place pass
+    // reorders w_hits)
+    const bool sorted_later = want_sort && !host_sort && n && grouped_before != 1;
+    if (wire_now && n && (src != ctx->w_hits.as<psigpu_hit>() || sorted_later)) {
+      // their wire form is made now (one more synchronisation)
+      hipError_t e = sl.d_wire.ensure((n + 1) * 16);
+      if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
+      k_hits_wire16<<<2048, 256, 0, sc>>>(src, nullptr, nullptr, n, n, ctx->id_base, rec_offset + r0, sl.d_wire.as<uint4>());
+      if (hipStreamSynchronize(sc) != hipSuccess) { ctx->err = "hipStreamSynchronize"; return fail(PSIGPU_ERR_DEVICE); }
     }
     if (n) {
       // extrapolate from the reads seen so far when the reservation turns out too small
@@ -4438,17 +4541,36 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
       }
       if (trace) { tr.push_back(now_ms() - t_call); tmark(sc); tmark(ctx->s_out); }
       hipError_t e = hipSuccess;
-      if (ctx->ec.ok) {
-        if (!engine_copy(ctx, false, hp + done, src, n * sizeof(psigpu_hit), ctx->ec.sig_out[i & 1])) e = hipErrorUnknown;
+      void* h_dst = hp + done;
+      const void* d_src = src;
+      size_t bytes = n * sizeof(psigpu_hit);
+      if (wire_now) {
+        if (n * 16 > sl.h_wire_cap) {
+          if (sl.h_wire) (void)hipHostFree(sl.h_wire);
+          sl.h_wire = nullptr; sl.h_wire_cap = 0;
+          const size_t want = n * 16 + n * 4 + 4096;
+          e = hipHostMalloc(&sl.h_wire, want, hipHostMallocDefault);
+          if (e == hipSuccess) sl.h_wire_cap = want;
+        }
+        h_dst = sl.h_wire; d_src = sl.d_wire.p; bytes = n * 16;
+      }
+      if (e != hipSuccess) { /* reported below */ }
+      else if (ctx->ec.ok) {
+        if (!engine_copy(ctx, false, h_dst, d_src, bytes, ctx->ec.sig_out[i & 1])) e = hipErrorUnknown;
       } else {
-        e = hipMemcpyAsync(hp + done, src, n * sizeof(psigpu_hit), hipMemcpyDeviceToHost, ctx->s_out);
+        e = hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->s_out);
         if (e == hipSuccess) e = hipEventRecord(sl.out_done, ctx->s_out);
       }
+      if (wire_now && e == hipSuccess)
+        widener.post(i, Widener::Job{ (const uint4*)sl.h_wire, hp + done, n, ctx->id_base, rec_offset + r0, (int)(i & 1) });
       if (trace) { tr.push_back(now_ms() - t_call); tmark(ctx->s_out); }
       if (e != hipSuccess) { ctx->err = std::string("copying the hits out: ") + hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
       done += n;
-    } else if (ctx->ec.ok) hsa_signal_store_relaxed(ctx->ec.sig_out[i & 1], 0);
-    else if (hipEventRecord(sl.out_done, ctx->s_out) != hipSuccess) { ctx->err = "hipEventRecord"; return fail(PSIGPU_ERR_DEVICE); }
+    } else {
+      if (ctx->ec.ok) hsa_signal_store_relaxed(ctx->ec.sig_out[i & 1], 0);
+      else if (hipEventRecord(sl.out_done, ctx->s_out) != hipSuccess) { ctx->err = "hipEventRecord"; return fail(PSIGPU_ERR_DEVICE); }
+    }
+    if (wire16 && !(wire_now && n)) widener.post(i, Widener::Job{ nullptr, nullptr, 0, 0, 0, (int)(i & 1) });      // (jobs and sub-batches count alike)
     if (src == ctx->w_hits.as<psigpu_hit>()) std::swap(ctx->w_hits, ctx->w_hits_alt);    // the next sub-batch writes the other buffer
     // counters of the chunk = sums over its sub-batches
     acc.n_reads += pc.n_reads; acc.n_seeds += pc.n_seeds; acc.n_seeds_valid += pc.n_seeds_valid;
@@ -4464,6 +4586,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   }
   if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }
   else if (hipStreamSynchronize(ctx->s_out) != hipSuccess) { ctx->err = "hipStreamSynchronize (copy-out stream)"; return fail(PSIGPU_ERR_DEVICE); }
+  if (wire16) widener.wait_finished(n_sub);
   if (trace) {
     fprintf(stderr, "[psigpu] host entry: %zu sub-batches, %.3f ms; per sub-batch (ms since call): pipeline begin, end, D2H enqueue begin, end\n", n_sub, now_ms() - t_call);
     for (size_t j = 0; j + 3 < tr.size(); j += 4) fprintf(stderr, "[psigpu]   %.3f %.3f %.3f %.3f\n", tr[j], tr[j + 1], tr[j + 2], tr[j + 3]);
@@ -4488,6 +4611,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   if (want_sort && host_sort && done) done = sort_unique_hits(hp, done);      // records wider than the device key
   if (n_reads) ctx->hits_per_read_hint = std::max(ctx->hits_per_read_hint * 0.9, (double)done / (double)n_reads);
   acc.n_hits = done;
+  acc.wire_bytes_per_hit = (wire16 && !host_sort) ? 16u : 32u;
   ctx->last = acc;
   if (done == 0) { if (hp) g_pinned.put(hp); hp = nullptr; }
   out->data = hp;
