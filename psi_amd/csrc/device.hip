@@ -199,7 +199,7 @@ struct FMView {
   uint32_t C[4];
   const uint2* ftab;         // [4^ftab_len] SA interval of the q-mer, or nullptr
   uint16_t ftab_len, exc_shift;
-  __device__ __forceinline__ uint32_t exc_super(uint32_t blk) const { return exc_row[n_exc + (blk >> exc_shift)]; }
+  __device__ __forceinline__ uint32_t n_super() const { return ((n / BLOCK_SYMS) >> exc_shift) + 1; }
   const uint64_t* text4;     // the text, 4 bits per symbol (nullptr: never verify against the text)
   const uint32_t* sa;        // whole suffix array when sa_rate == 1, else nullptr
   const SaRec* sarec;        // per-row records for this seed length, or nullptr
@@ -240,7 +240,23 @@ __device__ __forceinline__ bool text_matches(const uint64_t* __restrict__ text4,
 // bit planes (v.x|v.y = low bits, v.z|v.w = high bits).  Every lane evaluates the header
 // arithmetic on its own chunk (garbage on lanes 1..3) and the quad takes lane 0's result with a
 // DPP broadcast; the symbol popcounts of lanes 1..3 are summed with two DPP butterflies.
-__device__ __forceinline__ uint32_t quad_rank(const FMView& fm, uint4 v, uint32_t ql, uint32_t c,
+// The exceptions in front of every super-block of rank blocks are a few hundred words that every rank of a T and
+// every exception lookup needs: the LF kernels keep them in LDS (a global load here would sit behind the block's
+// and add its latency to the step; measured: the LF search went from 0.83 to 1.05 ms per chr22-like step with it).
+constexpr uint32_t SUP_LDS = 352;       // (2^32 / 192) >> 16 = 341 super-blocks at most in the default layout
+__device__ __forceinline__ void stage_exc_super(const FMView& fm, uint32_t* s_sup)
+{
+  const uint32_t n = min(fm.n_super(), SUP_LDS);
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_sup[i] = fm.exc_row[fm.n_exc + i];
+  __syncthreads();
+}
+__device__ __forceinline__ uint32_t exc_super(const FMView& fm, const uint32_t* s_sup, uint32_t blk)
+{
+  const uint32_t i = blk >> fm.exc_shift;
+  return i < SUP_LDS ? s_sup[i] : fm.exc_row[fm.n_exc + i];        // (beyond: only the tests' tiny super-blocks)
+}
+
+__device__ __forceinline__ uint32_t quad_rank(const FMView& fm, const uint32_t* s_sup, uint4 v, uint32_t ql, uint32_t c,
                                               uint32_t i)
 {
   uint32_t blk = i / BLOCK_SYMS, off = i - blk * BLOCK_SYMS;
@@ -248,13 +264,13 @@ __device__ __forceinline__ uint32_t quad_rank(const FMView& fm, uint4 v, uint32_
   // T = rows - A - C - G - exceptions in front (header field + what lies in front of the block's super-block:
   // a load that depends on the row alone, not on the block, from an array that stays in cache)
   uint32_t base = 0;
-  if (c == 3) base = blk * BLOCK_SYMS - v.x - v.y - v.z - (v.w >> 8) - fm.exc_super(blk);
+  if (c == 3) base = blk * BLOCK_SYMS - v.x - v.y - v.z - (v.w >> 8) - exc_super(fm, s_sup, blk);
   base = c == 2 ? v.z : base;
   base = c == 1 ? v.y : base;
   base = c == 0 ? v.x : base;
   if (ql == 0 && c == 0 && (v.w & 0xFF) != 0)
   {
-    const uint32_t e = (v.w >> 8) + fm.exc_super(blk), ne = v.w & 0xFF;
+    const uint32_t e = (v.w >> 8) + exc_super(fm, s_sup, blk), ne = v.w & 0xFF;
     base -= exc_below(fm.exc_row + e, ne == 255 ? fm.n_exc - e : ne, i);
   }
   base = quad_bcast0(base);
@@ -642,7 +658,9 @@ __global__ void k_pfx_derive(const uint32_t* __restrict__ pfx_bits, uint32_t pfx
 // k_wave_offsets turns the sums into the wave's first output slot, and k_fm_locate, walking the
 // same ranges, places every hit with a running wave-local prefix: hits come out in seed order
 // with no atomics and no scan over the seeds.
-__global__ void __launch_bounds__(256, 8)      // 8 waves per SIMD: the launch (8192 waves) is sized to be resident at once
+template <bool LISTED>        // (two kernels: the list mode's pointers and strides cost the range mode scalar registers,
+                              // and at 101 of them a SIMD holds 7 waves instead of the 8 the launch is sized for)
+__global__ void __launch_bounds__(256)
 k_fm_search(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
             uint64_t seeds_cap, uint32_t per_wave,
             uint32_t k, uint32_t gocc_thr, uint32_t* __restrict__ iv_lo, uint32_t* __restrict__ iv_cnt,
@@ -652,8 +670,10 @@ k_fm_search(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __
   // Two ways to be given work: every wave owns the contiguous seed range [wave * per_wave, ...)
   // (list == nullptr), or the waves share a list of seed indices -- the seeds k_fm_search_direct
   // deferred -- and add each seed's count to the total of the wave that owns its range.
+  __shared__ uint32_t s_sup[SUP_LDS];
+  stage_exc_super(fm, s_sup);
   const bool can_verify = fm.text4 != nullptr && fm.sa != nullptr;
-  const bool listed = list != nullptr;
+  constexpr bool listed = LISTED;
   const uint32_t ql = threadIdx.x & 3, quad = (threadIdx.x & 63) >> 2;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t n_seeds = min(params[0], seeds_cap);
@@ -689,8 +709,8 @@ k_fm_search(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __
         uint4 vl = fm.blocks[(uint64_t)bl * 4 + ql];
         uint4 vr = vl;
         if (br != bl) vr = fm.blocks[(uint64_t)br * 4 + ql];
-        uint32_t nl = fm.C[c] + quad_rank(fm, vl, ql, c, l);
-        uint32_t nr = fm.C[c] + quad_rank(fm, vr, ql, c, r);
+        uint32_t nl = fm.C[c] + quad_rank(fm, s_sup, vl, ql, c, l);
+        uint32_t nr = fm.C[c] + quad_rank(fm, s_sup, vr, ql, c, r);
         l = nl; r = nr;
         alive = r > l;
         ++jq;
@@ -1608,6 +1628,8 @@ k_fm_walk(FMView fm, const uint32_t* __restrict__ samples, uint32_t sa_rate, con
           uint64_t* __restrict__ hit_a, uint32_t* __restrict__ hit_seed, uint64_t cap, DevCounters* ctr)
 {
   __shared__ uint8_t sel_all[4][64];             // per wave: the staged seeds that have on-path occurrences, compacted
+  __shared__ uint32_t s_sup[SUP_LDS];
+  stage_exc_super(fm, s_sup);
   const uint32_t lane = lane_id(), ql = lane & 3, wib = threadIdx.x >> 6;
   uint8_t* sel = sel_all[wib];
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1681,7 +1703,7 @@ k_fm_walk(FMView fm, const uint32_t* __restrict__ samples, uint32_t sa_rate, con
         sym = quad_sum(sym);
         uint32_t ex = 0;                          // a separator / the sentinel in the BWT: its SA value is stored
         if (ql == 0 && (v.w & 0xFF) != 0) {
-          const uint32_t e0 = (v.w >> 8) + fm.exc_super(blk), ne = v.w & 0xFF;
+          const uint32_t e0 = (v.w >> 8) + exc_super(fm, s_sup, blk), ne = v.w & 0xFF;
           const uint32_t end = (ne == 255) ? fm.n_exc : e0 + ne;
           for (uint32_t q = e0; q < end; ++q) {
             const uint32_t rr = fm.exc_row[q];
@@ -1691,7 +1713,7 @@ k_fm_walk(FMView fm, const uint32_t* __restrict__ samples, uint32_t sa_rate, con
         }
         ex = quad_bcast0(ex);
         if (ex) { pos = exc_sa[ex - 1] + steps; done = true; }
-        else { row = fm.C[sym] + quad_rank(fm, v, ql, sym, row); ++steps; n_walk += ql == 0; }
+        else { row = fm.C[sym] + quad_rank(fm, s_sup, v, ql, sym, row); ++steps; n_walk += ql == 0; }
       }
       if (done) {
         const uint64_t h = q_out0 + occ;
@@ -3719,13 +3741,13 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
               k_fm_search_direct<<<grid, 256, 0, stream>>>(
                   fm, ride ? lk : LktView{ nullptr, 0, nullptr }, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1, so,
                   tiles_of(p), ride ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, ctx->w_defer.as<uint32_t>(), ctr);
-              k_fm_search<<<256, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
+              k_fm_search<true><<<256, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
                                                    so.iv_lo, so.iv_cnt, so.iv_aux, tiles_of(p), ctr,
                                                    ctx->w_defer.as<uint32_t>(), &ctr->n_defer.v);
               pc.search_launches += 2;
               probed = probed || ride;
             } else {
-              k_fm_search<<<grid, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
+              k_fm_search<false><<<grid, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
                                                     so.iv_lo, so.iv_cnt, so.iv_aux, tiles_of(p), ctr, nullptr, nullptr);
               pc.search_launches += 1;
             }
@@ -4338,16 +4360,28 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   const uint64_t SUB_BYTES = sub_env ? std::max<uint64_t>(1, strtoull(sub_env, nullptr, 10)) : (16ull << 20);
   std::vector<uint64_t> cut{ 0 };
   {
-    uint64_t piece = std::max<uint64_t>(1, std::min<uint64_t>(SUB_BYTES, std::max<uint64_t>(SUB_BYTES / 8, 1)));
-    uint64_t target = 0;
-    while (cut.back() < n_reads) {
-      target += piece;
-      uint64_t r = target >= n_bases ? n_reads : (uint64_t)(std::lower_bound(read_off, read_off + n_reads, target) - read_off);
-      if (r <= cut.back()) r = cut.back() + 1;            // at least one read per sub-batch
-      if (n_bases - read_off[r] < piece / 4) r = n_reads; // no tiny tail
-      cut.push_back(r);
-      piece = std::min(SUB_BYTES, piece * 2);
+    // piece sizes in bytes of bases: SUB/8, SUB/4, SUB/2, SUB ... SUB, SUB/2, SUB/4, SUB/8 -- small at both ends: what
+    // precedes the first transfer out and what follows the last transfer in (its kernels, its records' way out,
+    // their widening) is the part of the call nothing overlaps with
+    const uint64_t small = std::max<uint64_t>(1, SUB_BYTES / 8);
+    std::vector<uint64_t> head, tail;
+    uint64_t left = n_bases;
+    for (uint64_t p = small; p < SUB_BYTES && left > 2 * p; p *= 2) { head.push_back(p); tail.push_back(p); left -= 2 * p; }
+    std::vector<uint64_t> pieces = head;
+    while (left > 0) { const uint64_t p = std::min(left, SUB_BYTES); pieces.push_back(p); left -= p; }
+    if (!pieces.empty() && pieces.back() < SUB_BYTES / 4 && pieces.size() > head.size() + 1) {     // no tiny piece in the middle
+      const uint64_t t = pieces.back(); pieces.pop_back(); pieces.back() += t;
     }
+    pieces.insert(pieces.end(), tail.rbegin(), tail.rend());
+    uint64_t target = 0;
+    for (size_t pi = 0; pi < pieces.size() && cut.back() < n_reads; ++pi) {
+      target += pieces[pi];
+      uint64_t r = (target >= n_bases || pi + 1 == pieces.size()) ? n_reads
+                                                                    : (uint64_t)(std::lower_bound(read_off, read_off + n_reads, target) - read_off);
+      if (r <= cut.back()) r = cut.back() + 1;            // at least one read per sub-batch
+      cut.push_back(std::min(r, n_reads));
+    }
+    if (cut.back() < n_reads) cut.push_back(n_reads);
   }
   const size_t n_sub = cut.size() - 1;
   ptrdiff_t pin_delta = 0;

@@ -23,7 +23,7 @@ pin = [(psi_amd.pinned_copy(b), psi_amd.pinned_copy(o)) for b, o in batches]
 L = psi_amd.lib()
 hits = psi_amd.Hits()
 for flags, name in ((psi_amd.ALL | psi_amd.SORT_UNIQUE, 'sort-unique'), (psi_amd.ALL, 'raw')):
-    for mb in (16, 32, 64):
+    for mb in (4, 8, 16, 32):
         os.environ['PSIGPU_SUB_BYTES'] = str(mb << 20)
         calls = [(f.ctx, psi_amd._ptr(p[0].array), psi_amd._ptr(p[1].array), 1_000_000, 21, 21, 0, flags, C.byref(hits)) for p in pin]
         for i in range(3):
