@@ -347,15 +347,19 @@ def main():
         if os.path.exists(tpath) and world == 1 and args.reads == 1_000_000 and k == 21 and step == 21 and args.paths == 1:
             tj = json.load(open(tpath))
             pl = tj.get('per_launch', {})
-            names = {'k_fm_locate': ['k_kmer_emit', 'k_fm_locate_direct', 'k_fm_locate'],
-                     'k_fm_search': ['k_fm_search_direct', 'k_fm_search'],
-                     'k_traverse': ['void k_traverse<false>', 'k_traverse<false>', 'k_traverse'],
-                     'k_seed_pack': ['k_seed_pack'], 'k_table_insert': ['k_table_insert']}.get(dom, [dom])
-            for nme in names:
-                t = pl.get(nme)
-                if t and tj.get('mode') == mode and tj.get('series', '') == (traffic_key or '').partition('/')[2]:
-                    traffic = t.get('fetch_size_bytes', 0.0) + t.get('write_size_bytes', 0.0)
-                    src = 'profiles/' + tname + ':' + nme
+            # (a bench "kernel" may be several launches: the walk and the per-hit resolve of a sampled suffix array; the
+            # partition and the per-bucket build of the chunk's seed table)
+            names = {'k_fm_locate': [['k_kmer_emit'], ['k_fm_locate_direct'], ['k_fm_walk', 'k_hits_resolve']],
+                     'k_fm_search': [['k_fm_search_direct'], ['void k_fm_search<false>']],
+                     'k_traverse': [['void k_traverse<false>']],
+                     'k_seed_pack': [['k_seed_pack']],
+                     'k_table_insert': [['k_sb_count', 'k_sb_scatter', 'k_sb_build']]}.get(dom, [[dom]])
+            tot = lambda t: t.get('fetch_size_bytes', 0.0) + t.get('write_size_bytes', 0.0)      # noqa: E731
+            for group in names:
+                if all(pl.get(n) for n in group) and tot(pl[group[0]]) > 1e6 and tj.get('mode') == mode and \
+                        tj.get('series', '') == (traffic_key or '').partition('/')[2]:
+                    traffic = sum(tot(pl[n]) for n in group)
+                    src = 'profiles/' + tname + ':' + '+'.join(group)
                     break
         out = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': src,

@@ -285,19 +285,6 @@ __device__ __forceinline__ uint32_t quad_rank(const FMView& fm, const uint32_t* 
   return base + quad_sum(part);
 }
 
-// One fill for the per-chunk tables (seed-table keys, duplicate heads, prefix bitmap): three
-// regions, 16 bytes per lane per store, instead of three runtime memsets.
-struct FillJob { uint4* p; uint64_t n16; uint32_t v; };
-
-__global__ void __launch_bounds__(256) k_fill3(FillJob a, FillJob b, FillJob c)
-{
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (uint64_t i = t0; i < a.n16; i += stride) a.p[i] = make_uint4(a.v, a.v, a.v, a.v);
-  for (uint64_t i = t0; i < b.n16; i += stride) b.p[i] = make_uint4(b.v, b.v, b.v, b.v);
-  for (uint64_t i = t0; i < c.n16; i += stride) c.p[i] = make_uint4(c.v, c.v, c.v, c.v);
-}
-
 // Counters / counts go back to the host through a kernel that stores into mapped pinned memory, not
 // through a copy-engine transfer: a 20-KB D2H queues behind whatever large copy the same SDMA
 // engine is busy with (the hits of the previous sub-batch in the host entry's pipeline), and the
@@ -590,16 +577,168 @@ k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
   if (lane_id() == 0 && nok) ctr->n_seeds_valid.add((unsigned long long)nok);
 }
 
-// seeds "index": open-addressing table keyed by the packed seed (the depth-k level of the
-// reference's reads index, seed_finder.hpp:1089-1097).  The thread that claims a slot stores its
-// seed index there with a plain store; later seeds with the same k-mer (rare) are chained
-// through ht_dup / seed_next.  One CAS per seed plus one OR into the 4^pfx_len prefix bitmap.
+// seeds "index" (the depth-k level of the reference's reads index, seed_finder.hpp:1089-1097, and the levels
+// above it as prefix bitmaps), built per chunk for the query-time traverser.
+//
+// Rounds 1-2 built it with one device-scope CAS per seed into a table of the whole chunk plus one device-scope OR
+// into a 4^14-bit map: 14 M random atomics, 1.0 ms per 7 M seeds (atomics retire at ~13 G/s on this part, loads at
+// ~47 G/s).  Now the seeds are first PARTITIONED by their leading SB_BASES bases (count / scan / scatter: streams),
+// and one workgroup per bucket builds the bucket's share of everything in LDS -- its slots of the table (the
+// bucket's region: two slots per seed), its 4^(14-6) bits of the 14-mer map and its 4^(12-6) bits of the 12-mer map
+// -- and writes them out whole: no global atomics, no separate reset of the table and the maps, no derive pass.
+// A bucket too large for LDS (skewed sequence: poly-A prefixes) builds its region in place with atomics; nobody
+// else touches that region.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t SB_BASES = 6;                 // partition by this many leading bases (fewer when k is shorter)
+constexpr uint32_t SB_TILE = 16384;              // seeds per workgroup in the count / scatter kernels
+constexpr uint32_t SB_LDS_SLOTS = 4096;          // table slots a bucket may have to be built in LDS (64 KB: two workgroups per CU)
+constexpr uint64_t SB_MAX_SEEDS = 9ull << 20;    // chunks up to this many seeds (upper bound) are partitioned: about 2000 seeds per bucket,
+                                                 // 2048 fit the LDS table (a fuller bucket is built in place); larger chunks take the
+                                                 // one-region build below
+
+struct SeedBuckets {
+  uint32_t pb;               // bases that select the bucket = min(SB_BASES, pfx_len)
+  uint32_t n_buckets;        // 4^pb
+  uint32_t n_wg;             // workgroups of the count / scatter kernels
+  uint32_t k;
+};
+
+__device__ __forceinline__ uint32_t sb_bucket(uint64_t key, uint32_t k, uint32_t pb) { return (uint32_t)(key >> (2 * (k - pb))); }
+// where a k-mer's search starts inside its bucket's region of m slots
+__device__ __forceinline__ uint32_t sb_home(uint64_t key, uint32_t m) { return (uint32_t)__umul64hi(mix64(key), (uint64_t)m); }
+
+__global__ void __launch_bounds__(256)
+k_sb_count(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params, uint64_t seeds_cap, SeedBuckets sb,
+           uint32_t* __restrict__ cnt /* [bucket][wg] */)
+{
+  extern __shared__ uint32_t hist[];
+  for (uint32_t i = threadIdx.x; i < sb.n_buckets; i += 256) hist[i] = 0;
+  __syncthreads();
+  const uint64_t n_seeds = min(params[0], seeds_cap);
+  const uint64_t s0 = (uint64_t)blockIdx.x * SB_TILE, s1 = min(n_seeds, s0 + SB_TILE);
+  for (uint64_t s = s0 + threadIdx.x; s < s1; s += 256 * 8) {        // eight independent loads per thread in flight
+    uint64_t key[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) key[j] = s + 256 * j < s1 ? seed_key[s + 256 * j] : KEY_INVALID;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (key[j] != KEY_INVALID) atomicAdd(&hist[sb_bucket(key[j], sb.k, sb.pb)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < sb.n_buckets; i += 256) cnt[(uint64_t)i * sb.n_wg + blockIdx.x] = hist[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_sb_scatter(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params, uint64_t seeds_cap, SeedBuckets sb,
+             const uint64_t* __restrict__ off /* exclusive scan of cnt */, uint64_t* __restrict__ out_key,
+             uint32_t* __restrict__ out_seed, uint32_t* __restrict__ seed_next)
+{
+  extern __shared__ uint32_t cur[];
+  for (uint32_t i = threadIdx.x; i < sb.n_buckets; i += 256) cur[i] = (uint32_t)off[(uint64_t)i * sb.n_wg + blockIdx.x];
+  __syncthreads();
+  const uint64_t n_seeds = min(params[0], seeds_cap);
+  const uint64_t s0 = (uint64_t)blockIdx.x * SB_TILE, s1 = min(n_seeds, s0 + SB_TILE);
+  for (uint64_t s = s0 + threadIdx.x; s < s1; s += 256 * 8) {
+    uint64_t key[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) key[j] = s + 256 * j < s1 ? seed_key[s + 256 * j] : KEY_INVALID;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (s + 256 * j < s1) seed_next[s + 256 * j] = NIL;
+      if (key[j] == KEY_INVALID) continue;
+      const uint32_t at = atomicAdd(&cur[sb_bucket(key[j], sb.k, sb.pb)], 1u);
+      out_key[at] = key[j];
+      out_seed[at] = (uint32_t)(s + 256 * j);
+    }
+  }
+}
+
+// one workgroup per bucket
+__global__ void __launch_bounds__(256)
+k_sb_build(const uint64_t* __restrict__ bkey, const uint32_t* __restrict__ bseed, const uint64_t* __restrict__ off, SeedBuckets sb,
+           TableSlot* __restrict__ ht, uint32_t* __restrict__ seed_next, uint32_t* __restrict__ pfx_bits, uint32_t pfx_len,
+           uint32_t* __restrict__ pfx12)
+{
+  __shared__ TableSlot tab[SB_LDS_SLOTS];
+  __shared__ uint32_t bm[2048];                   // 4^(14 - 6) bits at most
+  const uint32_t b = blockIdx.x;
+  const uint32_t lo = (uint32_t)off[(uint64_t)b * sb.n_wg], hi = (uint32_t)off[(uint64_t)(b + 1) * sb.n_wg];
+  const uint32_t n = hi - lo, m = 2 * n;          // the bucket's region: slots [2 lo, 2 hi)
+  const uint32_t sub = pfx_len - sb.pb;           // bases of the 14-mer prefix inside the bucket
+  const uint32_t bm_words = ((1u << (2 * sub)) + 31) / 32;
+  for (uint32_t i = threadIdx.x; i < bm_words; i += 256) bm[i] = 0;
+  const bool in_lds = m <= SB_LDS_SLOTS;
+  TableSlot* region = ht + 2ull * lo;
+  const TableSlot empty = { KEY_INVALID, NIL, NIL };
+  if (in_lds) { for (uint32_t i = threadIdx.x; i < m; i += 256) tab[i] = empty; }
+  else { for (uint32_t i = threadIdx.x; i < m; i += 256) region[i] = empty; __threadfence(); }
+  __syncthreads();
+  TableSlot* t = in_lds ? tab : region;
+  const uint32_t sh = 2 * (sb.k - pfx_len);
+  const uint32_t sub_mask = (1u << (2 * sub)) - 1u;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const uint64_t key = bkey[lo + i];
+    const uint32_t s = bseed[lo + i];
+    const uint32_t pf = (uint32_t)(key >> sh) & sub_mask;
+    atomicOr(&bm[pf >> 5], 1u << (pf & 31));
+    uint32_t h = sb_home(key, m);
+    while (true) {
+      unsigned long long prev = atomicCAS(&t[h].key, (unsigned long long)KEY_INVALID, (unsigned long long)key);
+      if (prev == KEY_INVALID) { t[h].val = s; break; }
+      if (prev == key) { seed_next[s] = atomicExch(&t[h].dup, s); break; }
+      h = h + 1 < m ? h + 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (in_lds) {
+    const uint4* src = reinterpret_cast<const uint4*>(tab);
+    uint4* dst = reinterpret_cast<uint4*>(region);
+    for (uint32_t i = threadIdx.x; i < m; i += 256) dst[i] = src[i];
+  }
+  // the bucket's bits of the seed-prefix maps: bucket b owns bits [b 4^sub, (b + 1) 4^sub) of the 4^pfx_len-bit map
+  if (bm_words * 32 == (1u << (2 * sub))) {
+    for (uint32_t i = threadIdx.x; i < bm_words; i += 256) pfx_bits[(uint64_t)b * bm_words + i] = bm[i];
+  } else {                                        // fewer than 32 bits per bucket (short prefixes): shared words
+    if (threadIdx.x == 0 && bm[0]) atomicOr(&pfx_bits[((uint64_t)b << (2 * sub)) >> 5], bm[0] << (((uint64_t)b << (2 * sub)) & 31));
+  }
+  if (pfx12 != nullptr) {
+    // a 12-mer is a seed prefix iff one of its 4^(pfx_len - 12) extensions is; this bucket owns 4^(12 - pb) of them
+    const uint32_t ext = 1u << (2 * (pfx_len - PFX_SHORT));            // 16 (pfx_len 14) or 4 (13)
+    const uint32_t n12 = 1u << (2 * (PFX_SHORT - sb.pb));               // 4096 at pb = 6
+    for (uint32_t w = threadIdx.x; w < n12 / 32; w += 256) {
+      uint32_t o = 0;
+      for (uint32_t j = 0; j < 32; ++j) {
+        const uint32_t first = (w * 32 + j) * ext;                      // first bit of the group in bm
+        const uint32_t g = (bm[first >> 5] >> (first & 31)) & (ext == 16 ? 0xFFFFu : 0xFu);
+        o |= (g ? 1u : 0u) << j;
+      }
+      pfx12[(uint64_t)b * (n12 / 32) + w] = o;
+    }
+  }
+}
+
+// The same table for chunks whose buckets would not fit LDS (more than SB_MAX_SEEDS seeds: a bucket of the partition
+// above would hold more than SB_LDS_SLOTS / 2, and a finer partition would need a count matrix larger than the
+// data): ONE region for all seeds, reset by k_fill3, one CAS per seed plus one OR into the 4^pfx_len-bit map, the
+// 12-mer map derived afterwards -- the build of rounds 1-2.  Same slots, same addressing (sb_home over the region),
+// so the traverser's lookup does not know the difference (one bucket: pb = 0).
+struct FillJob { uint4* p; uint64_t n16; uint32_t v; };
+
+__global__ void __launch_bounds__(256) k_fill3(FillJob a, FillJob b, FillJob c)
+{
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint64_t i = t0; i < a.n16; i += stride) a.p[i] = make_uint4(a.v, a.v, a.v, a.v);
+  for (uint64_t i = t0; i < b.n16; i += stride) b.p[i] = make_uint4(b.v, b.v, b.v, b.v);
+  for (uint64_t i = t0; i < c.n16; i += stride) c.p[i] = make_uint4(c.v, c.v, c.v, c.v);
+}
+
 __global__ void k_table_insert(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
-                               uint64_t seeds_cap, TableSlot* __restrict__ ht, uint64_t ht_mask,
+                               uint64_t seeds_cap, TableSlot* __restrict__ ht, uint32_t m /* slots of the one region */,
                                uint32_t* __restrict__ seed_next, uint32_t k,
-                               uint32_t* __restrict__ pfx_bits, uint32_t pfx_len)
+                               uint32_t* __restrict__ pfx_bits, uint32_t pfx_len, uint64_t* __restrict__ boff)
 {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) { boff[0] = 0; boff[1] = m / 2; }       // the one bucket's "offsets": slots [2 boff[0], 2 boff[1])
   if (s >= min(params[0], seeds_cap)) return;
   uint64_t key = seed_key[s];
   seed_next[s] = NIL;
@@ -608,12 +747,12 @@ __global__ void k_table_insert(const uint64_t* __restrict__ seed_key, const uint
     uint32_t pf = (uint32_t)(key >> (2 * (k - pfx_len)));
     atomicOr(&pfx_bits[pf >> 5], 1u << (pf & 31));
   }
-  uint64_t h = mix64(key) & ht_mask;
+  uint32_t h = sb_home(key, m);
   while (true) {
     unsigned long long prev = atomicCAS(&ht[h].key, (unsigned long long)KEY_INVALID, (unsigned long long)key);
     if (prev == KEY_INVALID) { ht[h].val = (uint32_t)s; return; }
     if (prev == key) { seed_next[s] = atomicExch(&ht[h].dup, (uint32_t)s); return; }
-    h = (h + 1) & ht_mask;
+    h = h + 1 < m ? h + 1 : 0;
   }
 }
 
@@ -2016,7 +2155,8 @@ struct GraphView {
 };
 
 struct TableView {
-  const TableSlot* ht; uint64_t ht_mask;
+  const TableSlot* ht;                            // every bucket's region one after the other (k_sb_build)
+  const uint64_t* boff; uint32_t n_wg, pb;        // bucket b: slots [2 boff[b n_wg], 2 boff[(b + 1) n_wg])
   const uint32_t* seed_next; const uint2* seed_info;
   const uint32_t* pfx12;                          // 4^12-bit prefix bitmap (nullptr when k < 12)
   const uint32_t* pfx_bits; uint32_t pfx_len;     // prefix bitmap of the seeds, 4^pfx_len bits
@@ -2064,12 +2204,17 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
   if (lane < n) {
     DoneItem d = dq[lane];
     locus = d.locus;
-    uint64_t h = mix64(d.kmer) & tb.ht_mask;
-    while (true) {
-      TableSlot sl = tb.ht[h];
-      if (sl.key == d.kmer) { s = sl.val; dup = sl.dup; break; }
-      if (sl.key == KEY_INVALID) break;
-      h = (h + 1) & tb.ht_mask;
+    const uint32_t b = sb_bucket(d.kmer, k, tb.pb);
+    const uint32_t lo = (uint32_t)tb.boff[(uint64_t)b * tb.n_wg], m = 2 * ((uint32_t)tb.boff[(uint64_t)(b + 1) * tb.n_wg] - lo);
+    if (m) {
+      const TableSlot* region = tb.ht + 2ull * lo;
+      uint32_t h = sb_home(d.kmer, m);
+      while (true) {
+        TableSlot sl = region[h];
+        if (sl.key == d.kmer) { s = sl.val; dup = sl.dup; break; }
+        if (sl.key == KEY_INVALID) break;
+        h = h + 1 < m ? h + 1 : 0;
+      }
     }
   }
   if (!__any(s != NIL)) return;
@@ -2561,7 +2706,8 @@ struct psigpu_ctx {
   // per-call workspace (grow-only)
   DevBuf w_bases, w_read_off, w_cnt, w_tiles, w_seed_off, w_seed_key, w_seed_info,
       w_seed_next, w_ht, w_pfx, w_pfx12, w_iv_lo, w_iv_cnt, w_iv_aux, w_hit_off, w_iv_tiles,
-      w_chunks, w_chunk_fill, w_chunk_off, w_chunk_tiles, w_hits, w_spill_a, w_spill_b, w_ctr, w_total;
+      w_chunks, w_chunk_fill, w_chunk_off, w_chunk_tiles, w_hits, w_spill_a, w_spill_b, w_ctr, w_total,
+      w_sb_cnt, w_sb_off, w_sb_tiles, w_sb_key, w_sb_seed;      // the partition of a chunk's seeds (k_sb_*)
   uint64_t hits_cap_hint = 0, chunks_cap_hint = 0;
   uint64_t spill_cap = 1u << 22;   // traverser spill queue entries (grows when a chunk overflows it)
   void* h_pinned = nullptr;        // pinned host mirror of the counters + counts, written by k_publish
@@ -2696,6 +2842,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
   for (auto* b : all) b->release();
   ctx->ids_sorted.release(); ctx->w_sorted[0].release(); ctx->w_sorted[1].release(); ctx->w_count.release();
   ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release();
+  for (DevBuf* b : { &ctx->w_sb_cnt, &ctx->w_sb_off, &ctx->w_sb_tiles, &ctx->w_sb_key, &ctx->w_sb_seed }) b->release();
   for (auto& m : ctx->parts) m->release();
   ctx->w_hits_alt.release();
   for (auto& sl : ctx->slot) {
@@ -3525,26 +3672,25 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   pc.ms_locus_table_build = (use_lkt || use_kt) ? ctx->lkt_build_ms : 0.f;
   const bool need_table = (flags & PSIGPU_OFF_PATHS) && n_trav_loci;
   const uint64_t seeds_ub = n_bases / step + n_reads;
-  uint64_t ht_size = 1024;
-  while (ht_size < 2 * seeds_ub) ht_size <<= 1;
   const uint32_t pfx_len = std::min<uint32_t>(k, PFX_LONG);
   const uint64_t pfx_words = ((1ull << (2 * pfx_len)) + 31) / 32;
   const bool use_pfx12 = need_table && k > PFX_SHORT;
-  auto launch_fill = [&](hipStream_t ts) -> int {
-    FillJob fa = { ctx->w_ht.as<uint4>(), ht_size, 0xFFFFFFFFu };    // key = invalid, val, dup = NIL
-    FillJob fb = { nullptr, 0, 0u };
-    FillJob fc = { ctx->w_pfx.as<uint4>(), (pfx_words * 4 + 15) / 16, 0u };
-    k_fill3<<<2048, 256, 0, ts>>>(fa, fb, fc);
-    return PSIGPU_OK;
-  };
+  SeedBuckets sb;
+  const char* sb_env = getenv("PSIGPU_SB_MAX");                         // (tests: 0 forces the one-region build on small chunks)
+  const bool sb_parts = seeds_ub <= (sb_env ? strtoull(sb_env, nullptr, 10) : SB_MAX_SEEDS);     // partitioned build, or one region for the whole chunk
+  sb.pb = sb_parts ? std::min<uint32_t>(SB_BASES, pfx_len) : 0u; sb.n_buckets = 1u << (2 * sb.pb);
+  sb.n_wg = sb_parts ? (uint32_t)((seeds_ub + SB_TILE - 1) / SB_TILE) + 1 : 1u; sb.k = k;
+  if (2 * seeds_ub >= 0xFFFFFFF0ull && need_table) { ctx->err = "too many seeds in one chunk for the traverser's seed table"; return PSIGPU_ERR_ARG; }
+  const uint64_t sb_cnt = (uint64_t)sb.n_buckets * sb.n_wg;             // counters, bucket-major
   if (need_table && n_reads) {
-    HIPCHK(ctx, ctx->w_ht.ensure(ht_size * sizeof(TableSlot)));
+    HIPCHK(ctx, ctx->w_ht.ensure((2 * seeds_ub + 16) * sizeof(TableSlot)));
     HIPCHK(ctx, ctx->w_pfx.ensure(pfx_words * 4 + 16));
     if (use_pfx12) HIPCHK(ctx, ctx->w_pfx12.ensure((1ull << (2 * PFX_SHORT)) / 8));
-    hipStream_t fs = serial ? stream : ctx->stream2;
-    if (!serial) HIPCHK(ctx, hipStreamWaitEvent(fs, ctx->ev[0], 0));
-    launch_fill(fs);
-    EVREC(9, fs);
+    HIPCHK(ctx, ctx->w_sb_cnt.ensure((sb_cnt + 1) * 4));
+    HIPCHK(ctx, ctx->w_sb_off.ensure((sb_cnt + 2) * 8));
+    HIPCHK(ctx, ctx->w_sb_tiles.ensure((sb_cnt / SCAN_TILE + 2) * 8));
+    HIPCHK(ctx, ctx->w_sb_key.ensure((seeds_ub + 1) * 8));
+    HIPCHK(ctx, ctx->w_sb_seed.ensure((seeds_ub + 1) * 4));
   }
 
   // ---- K0: seeds ---------------------------------------------------------------------
@@ -3603,7 +3749,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   };
   TableView tb;
   tb.ht = ctx->w_ht.as<TableSlot>();
-  tb.ht_mask = ht_size - 1; tb.seed_next = ctx->w_seed_next.as<uint32_t>();
+  tb.boff = ctx->w_sb_off.as<uint64_t>(); tb.n_wg = sb.n_wg; tb.pb = sb.pb;
+  tb.seed_next = ctx->w_seed_next.as<uint32_t>();
   tb.seed_info = ctx->w_seed_info.as<uint2>();
   // PSIGPU_NO_PFX (diagnostic): no pruning, so n_kpaths counts every k-walk from the starting loci
   const bool no_pfx = getenv("PSIGPU_NO_PFX") != nullptr;
@@ -3655,13 +3802,35 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     // the seeds "index" (table + prefix bitmaps) is only needed by the traverser
     auto launch_table = [&](hipStream_t ts) -> int {
       EVREC(2, ts);
-      if (attempt > 0) launch_fill(ts);       // first attempt: reset at the top of the call
-      k_table_insert<<<(unsigned)((n_seeds + 255) / 256), 256, 0, ts>>>(
-          ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, ctx->w_ht.as<TableSlot>(), ht_size - 1,
-          ctx->w_seed_next.as<uint32_t>(), k, ctx->w_pfx.as<uint32_t>(), pfx_len);
-      if (use_pfx12)
-        k_pfx_derive<<<(1u << (2 * PFX_SHORT)) / 32 / 256, 256, 0, ts>>>(ctx->w_pfx.as<uint32_t>(), pfx_len,
-                                                                        ctx->w_pfx12.as<uint32_t>());
+      if (!sb_parts) {
+        const uint32_t m = (uint32_t)(2 * seeds_ub);
+        FillJob fa = { ctx->w_ht.as<uint4>(), m, 0xFFFFFFFFu };       // key = invalid, val, dup = NIL
+        FillJob fb = { nullptr, 0, 0u };
+        FillJob fc = { ctx->w_pfx.as<uint4>(), (pfx_words * 4 + 15) / 16, 0u };
+        k_fill3<<<2048, 256, 0, ts>>>(fa, fb, fc);
+        k_table_insert<<<(unsigned)((n_seeds + 255) / 256), 256, 0, ts>>>(
+            ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, ctx->w_ht.as<TableSlot>(), m, ctx->w_seed_next.as<uint32_t>(), k,
+            ctx->w_pfx.as<uint32_t>(), pfx_len, ctx->w_sb_off.as<uint64_t>());
+        if (use_pfx12)
+          k_pfx_derive<<<(1u << (2 * PFX_SHORT)) / 32 / 256, 256, 0, ts>>>(ctx->w_pfx.as<uint32_t>(), pfx_len, ctx->w_pfx12.as<uint32_t>());
+        EVREC(6, ts);
+        return PSIGPU_OK;
+      }
+      // partition the seeds by their leading bases (count, scan, scatter), then one workgroup per bucket
+      const size_t lds = sb.n_buckets * 4;
+      k_sb_count<<<sb.n_wg, 256, lds, ts>>>(ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, sb, ctx->w_sb_cnt.as<uint32_t>());
+      const uint64_t tiles = sb_cnt / SCAN_TILE + 1;
+      k_scan_tiles<<<(unsigned)tiles, SCAN_THREADS, 0, ts>>>(ctx->w_sb_cnt.as<uint32_t>(), sb_cnt, ctx->w_sb_tiles.as<uint64_t>());
+      k_scan_sums<<<1, SCAN_THREADS, 0, ts>>>(ctx->w_sb_tiles.as<uint64_t>(), tiles, ctx->w_sb_tiles.as<uint64_t>() + tiles);
+      k_scan_final<<<(unsigned)tiles, SCAN_THREADS, 0, ts>>>(ctx->w_sb_cnt.as<uint32_t>(), sb_cnt, ctx->w_sb_tiles.as<uint64_t>(),
+                                                           ctx->w_sb_off.as<uint64_t>());
+      k_sb_scatter<<<sb.n_wg, 256, lds, ts>>>(ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, sb, ctx->w_sb_off.as<uint64_t>(),
+                                             ctx->w_sb_key.as<uint64_t>(), ctx->w_sb_seed.as<uint32_t>(), ctx->w_seed_next.as<uint32_t>());
+      if ((1u << (2 * (pfx_len - sb.pb))) < 32)              // (prefix maps of short seeds: buckets share words)
+        HIPCHK(ctx, hipMemsetAsync(ctx->w_pfx.p, 0, pfx_words * 4, ts));
+      k_sb_build<<<sb.n_buckets, 256, 0, ts>>>(ctx->w_sb_key.as<uint64_t>(), ctx->w_sb_seed.as<uint32_t>(), ctx->w_sb_off.as<uint64_t>(), sb,
+                                              ctx->w_ht.as<TableSlot>(), ctx->w_seed_next.as<uint32_t>(), ctx->w_pfx.as<uint32_t>(), pfx_len,
+                                              use_pfx12 ? ctx->w_pfx12.as<uint32_t>() : nullptr);
       EVREC(6, ts);
       return PSIGPU_OK;
     };

@@ -119,6 +119,34 @@ def test_sort_unique_in_place_and_fallback(query_mode):
     if not query_mode.startswith('traverse'):
         assert in_place == 1
     f.close()
+@pytest.mark.parametrize('query_mode', ['traverse'], indirect=True)
+def test_seed_table_builds_agree(monkeypatch, query_mode):
+    """The traverser's per-chunk seed table is built bucket by bucket in LDS (seeds partitioned by their first six
+    bases) for chunks of up to ~9 M seeds and in one region with atomics beyond; PSIGPU_SB_MAX=0 forces the second
+    build on a small chunk: same records (golden), short seeds (k = 6: one bit of the prefix map per bucket; k = 9)
+    included."""
+    z = np.load(os.path.join(GOLDEN, 'hits_x_reads_n1000l100e0i0_k21_d1.npz'))
+    reads = [str(r) for r in z['reads']]
+    g = _graph(str(z['graph']))
+    for sb_max in (None, '0'):
+        if sb_max is not None:
+            monkeypatch.setenv('PSIGPU_SB_MAX', sb_max)
+        f = psi_amd.SeedFinder(g, 21)
+        f.create_path_index(1)
+        assert _eq(psi_amd.sort_unique(f.seeds_all(reads, step=1)), z['hits'])
+        f.close()
+        from oracle import brute
+        bg = brute.parse_gfa(os.path.join(REF, 'x.gfa'))
+        for k in (4, 6, 9, 13):
+            f = psi_amd.SeedFinder(g, k)
+            f.create_path_index(0)
+            got = psi_amd.sort_unique(f.seeds_all(reads[:60], step=k))
+            want = np.array(brute.hit_set(bg, reads[:60], k, k), dtype=np.uint64).reshape(-1, 4)
+            assert _eq(got, want)
+            f.close()
+    monkeypatch.delenv('PSIGPU_SB_MAX')
+
+
 def test_traverser_truth_table():
     """test/src/test_traverser.cpp:81-82 through the GPU traverser (no path index)."""
     truth = [(1, 0), (1, 1), (9, 4), (9, 17), (16, 0), (17, 0), (20, 0), (20, 31), (20, 38), (20, 38)]
