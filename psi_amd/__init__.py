@@ -657,6 +657,17 @@ class SeedFinder:
         self.close()
 
 
+class DeviceHits:
+    """Zero-copy view of the records psigpu_find_seeds_device left in HBM -- (pointer, n) from
+    SeedFinder.seeds_all_device -- for frameworks that speak the CUDA array interface:
+    ``torch.as_tensor(DeviceHits(ptr, n), device='cuda')`` is an (n, 4) int64 tensor over the library's buffer
+    (valid until the next call on the finder).  What a gather over RCCL sends, without a trip through the host."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {'shape': (int(n), 4), 'typestr': '<i8', 'data': (int(ptr), True), 'version': 2,
+                                         'strides': None}
+
+
 def sort_unique(hits: np.ndarray) -> np.ndarray:
     if len(hits) == 0:
         return hits.reshape(0, 4)

@@ -555,6 +555,22 @@ def test_gocc_threshold_all_phases_vs_oracle_snv(npaths):
 # ---------------------------------------------------------------------------------------
 # device-resident entry point, and size-independent properties at a larger size
 # ---------------------------------------------------------------------------------------
+def test_device_hits_as_a_torch_tensor():
+    """psi_amd.DeviceHits: the records left in HBM seen by torch through the CUDA array interface, no copy."""
+    import torch
+    g, reads = _x_case()
+    f = psi_amd.SeedFinder(g, 12)
+    f.create_path_index(1)
+    bases, off = psi_amd.pack_reads(reads[:200])
+    d_bases = torch.from_numpy(bases).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    ptr, n = f.seeds_all_device(d_bases.data_ptr(), d_off.data_ptr(), 200, len(bases), step=5, flags=psi_amd.ALL | psi_amd.SORT_UNIQUE)
+    t = torch.as_tensor(psi_amd.DeviceHits(ptr, n), device='cuda')
+    assert t.shape == (n, 4) and t.dtype == torch.int64 and t.data_ptr() == ptr
+    assert _eq(t.cpu().numpy().view(np.uint64), f.copy_hits(ptr, n))
+    f.close()
+
+
 def test_device_resident_entry_matches_host_entry():
     import torch
     sg = synth.snv_graph(200_000, 6000, seed=8)

@@ -76,20 +76,30 @@ def main():
                 if pp is not None and pp.view.n_more_parts:
                     gocc = rng.choice([0, 0, 1, 3])
                     res = []
+                    pmode = rng.choice(['kmer-table', 'locus-table', 'traverse'])      # every mode answers an index in parts
                     for ix in (px, pp):
-                        f = psi_amd.SeedFinder(pg, k, mode='kmer-table', gocc_threshold=gocc)
+                        f = psi_amd.SeedFinder(pg, k, mode='kmer-table' if ix is px else pmode, gocc_threshold=gocc)
                         f.set_path_index(ix)
                         raw = f.seeds_all(reads, step=step)
                         res.append(raw[np.lexsort(raw.T[::-1])])
                         f.close()
-                    if px.view.sa_rate != 1:       # (the one-part index is then answered by the FM modes, which emit every
-                        res = [psi_amd.sort_unique(r) for r in res]      # occurrence: compare the sets)
+                    if px.view.sa_rate != 1 or pmode != 'kmer-table':       # (the FM modes emit every occurrence, the traverser
+                        res = [psi_amd.sort_unique(r) for r in res]           # what it finds again: compare the sets)
                     if not (res[0].shape == res[1].shape and (res[0] == res[1]).all()):
                         print('PARTS MISMATCH', seed, k, step, npaths, patched, cut, gocc, flush=True)
                         sys.exit(1)
                     if gocc == 0 and not (psi_amd.sort_unique(res[1]).shape == want.shape and (psi_amd.sort_unique(res[1]) == want).all()):
-                        print('PARTS vs BRUTE MISMATCH', seed, k, step, npaths, flush=True)
+                        print('PARTS vs BRUTE MISMATCH', seed, k, step, npaths, pmode, flush=True)
                         sys.exit(1)
+                    if px.view.sa_rate == 1:
+                        # MEM mode over the parts = over the one-part index
+                        fa, fb = psi_amd.SeedFinder(pg, k, gocc_threshold=gocc), psi_amd.SeedFinder(pg, k, gocc_threshold=gocc)
+                        fa.set_path_index(px); fb.set_path_index(pp)
+                        ma, mb = fa.find_mems(reads), fb.find_mems(reads)
+                        fa.close(); fb.close()
+                        if not (ma.shape == mb.shape and (ma == mb).all()):
+                            print('PARTS MEM MISMATCH', seed, k, npaths, gocc, flush=True)
+                            sys.exit(1)
                     n_cases += 1
             for mode in ('kmer-table', 'locus-table', 'traverse'):
                 for cap in ((0,) if mode == 'traverse' else (0, 1, 3)):
