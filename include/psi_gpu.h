@@ -26,7 +26,10 @@ extern "C" {
 #endif
 
 #define PSIGPU_ABI_VERSION 4
-#define PSIGPU_MAX_SEED_LEN 31u   /* seeds are 2-bit packed into one 64-bit word */
+#define PSIGPU_MAX_SEED_LEN 63u   /* psikt takes any -l (src/psikt.cpp:327); seeds are 2-bit packed into one 64-bit word up
+                                    to 31 bases and into two words from 32 to 63 */
+#define PSIGPU_MAX_TABLE_SEED_LEN 31u   /* the tabulating query modes (k-mer table, locus table) hold one-word k-mers: longer
+                                          seeds are answered by the FM index and the query-time traverser in every mode */
 #define PSIGPU_MAX_PARTS 8u       /* parts of an index whose text passes the 32-bit row limit */
 
 /* Status codes */

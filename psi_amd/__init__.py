@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PSI_AMD_LIB') or os.path.join(_HERE, 'libpsi_gpu.so')   # env: experiment builds
 
 ALL, ON_PATHS, OFF_PATHS, SORT_UNIQUE = 3, 1, 2, 4
-MAX_SEED_LEN = 31
+MAX_SEED_LEN = 63
 TUNE_NO_DIRECT, TUNE_NO_VERIFY, TUNE_NO_ROWRECS = 1, 2, 4
 
 

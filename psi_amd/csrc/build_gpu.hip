@@ -457,7 +457,7 @@ struct LociGraph {
   uint64_t n; uint32_t k, step;
 };
 
-constexpr int LOCI_DEPTH = 4 * 31 + 3;       // index.cpp's explore(): depth <= 4 k
+constexpr int LOCI_DEPTH = 4 * 63 + 3;       // index.cpp's explore(): depth <= 4 k (k <= PSIGPU_MAX_SEED_LEN)
 
 // bit `need` (1..k-1) of the result: an uncovered walk exists that leaves node v after `need`
 // more bases are still wanted -- explore() of index.cpp with an explicit stack

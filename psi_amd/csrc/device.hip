@@ -32,6 +32,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -145,11 +146,20 @@ struct DevCounters {
   PaddedCounter dbg0, dbg1;      // diagnostics (builds with -DTRAV_STATS)
 };
 
-struct TravItem {         // 16 bytes
-  uint64_t kmer;          // marker bit at 2*depth, bases below it (first base most significant)
+// Seeds of up to 31 bases are one 64-bit word (2 bits per base, first base most significant) and that is what every
+// table and every kernel of the default path is made for.  Seeds of 32..63 bases (psikt takes any -l:
+// src/psikt.cpp:327) are 128-bit words through the SAME kernels instantiated for the wider type -- the FM search, the
+// traverser and its seed table; the tabulating modes (k-mer table, locus table) stay with one word.
+typedef unsigned __int128 u128;
+template <typename KEY> __device__ __host__ __forceinline__ constexpr KEY key_invalid() { return ~(KEY)0; }   // (a valid key uses < all bits)
+
+template <typename KEY>
+struct TravItemT {        // 16 bytes (32 with 128-bit k-mers)
+  KEY kmer;               // marker bit at 2*depth, bases below it (first base most significant)
   uint32_t node;
   uint32_t locus;
 };
+typedef TravItemT<uint64_t> TravItem;
 
 // ------------------------------------------------------------------------------------
 // small device helpers
@@ -189,6 +199,22 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
   return x;
 }
 
+// position of the highest set bit
+__device__ __forceinline__ uint32_t hibit(uint64_t x) { return 63u - (uint32_t)__clzll((long long)x); }
+__device__ __forceinline__ uint32_t hibit(u128 x)
+{
+  const uint64_t h = (uint64_t)(x >> 64);
+  return h ? 127u - (uint32_t)__clzll((long long)h) : 63u - (uint32_t)__clzll((long long)(uint64_t)x);
+}
+// what the chunk's seed table is keyed by: the k-mer itself, or -- two words -- a 64-bit fingerprint of it (the
+// lookup then compares the k-mer of every seed it finds: exact whatever the fingerprints do)
+__device__ __forceinline__ uint64_t table_key(uint64_t k) { return k; }
+__device__ __forceinline__ uint64_t table_key(u128 k)
+{
+  const uint64_t f = mix64((uint64_t)k ^ mix64((uint64_t)(k >> 64) + 0x9E3779B97F4A7C15ull));
+  return f == KEY_INVALID ? 0ull : f;
+}
+
 struct FMView {
   const uint4* blocks;       // n_blocks x 4 x 16 B
   const uint32_t* exc_row;   // [n_exc] exception rows, then -- same array -- the exceptions in front of every super-block of
@@ -216,8 +242,9 @@ __device__ __noinline__ uint32_t exc_below(const uint32_t* __restrict__ rows /* 
 
 // Do the `rem` (1..16) text symbols in front of position `pos` spell the first `rem` bases of the
 // seed (2-bit key of k bases, first base most significant) with no separator among them?
+template <typename KEY>
 __device__ __forceinline__ bool text_matches(const uint64_t* __restrict__ text4, uint32_t pos, uint32_t rem,
-                                             uint64_t key, uint32_t k)
+                                             KEY key, uint32_t k)
 {
   if (pos < rem) return false;
   uint32_t a = pos - rem, w = a >> 4, sh = (a & 15) * 4;
@@ -486,16 +513,21 @@ __device__ __forceinline__ uint64_t pack8(uint64_t x, uint32_t take, uint32_t& o
 // guess gallops / bisects.  Neighbouring threads read neighbouring bytes.
 constexpr int SP = 1;        // seeds a thread works on at a time (more were measured slower: registers, occupancy)
 
+// WIDE (seeds of 32..63 bases): the 128-bit k-mer goes to seed_wide, its fingerprint (table_key) to seed_key -- what the
+// chunk's seed table is keyed by -- and its first pfx_len bases to seed_pfx (the prefix maps).
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
 k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_off,
             const uint64_t* __restrict__ seed_off, uint64_t n_reads, const uint64_t* __restrict__ params,
             uint64_t seeds_cap, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t* __restrict__ seed_key, uint2* __restrict__ seed_info,
-            DevCounters* ctr)
+            DevCounters* ctr, u128* __restrict__ seed_wide, uint32_t* __restrict__ seed_pfx, uint32_t pfx_len)
 {
+  typedef typename std::conditional<WIDE, u128, uint64_t>::type KEY;
+  constexpr uint32_t NW = WIDE ? 8 : 4;
   uint32_t nok = 0;
   const uint64_t n_seeds = min(params[0], seeds_cap), ratio = params[1];
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint32_t nw = (k + 7) >> 3;               // 64-bit loads per seed (at most 4)
+  const uint32_t nw = (k + 7) >> 3;               // 64-bit loads per seed (at most 4; 8 for two-word seeds)
   for (uint64_t s0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s0 < n_seeds; s0 += stride * SP) {
     uint64_t lo[SP], so0[SP], so1[SP], ro[SP];
     bool in[SP];
@@ -531,7 +563,7 @@ k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
         lo[j] = l; so0[j] = seed_off[l]; ro[j] = read_off[l];
       }
     }
-    uint64_t x[SP][4];
+    uint64_t x[SP][NW];
     uint64_t st[SP];
     bool fast[SP];
 #pragma unroll
@@ -541,7 +573,7 @@ k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
       const uint64_t abs0 = ro[j] + st[j];
       fast[j] = in[j] && abs0 + 8ull * nw <= n_bases;
 #pragma unroll
-      for (uint32_t w = 0; w < 4; ++w) {
+      for (uint32_t w = 0; w < NW; ++w) {
         x[j][w] = 0;
         if (fast[j] && w < nw) __builtin_memcpy(&x[j][w], bases + abs0 + 8 * w, 8);
       }
@@ -550,23 +582,28 @@ k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
     for (int j = 0; j < SP; ++j) {
       if (!in[j]) continue;
       const uint64_t s = s0 + (uint64_t)j * stride;
-      uint64_t key = 0;
+      KEY key = 0;
       uint32_t ok = 1;
       if (fast[j]) {
 #pragma unroll
-        for (uint32_t w = 0; w < 4; ++w)
+        for (uint32_t w = 0; w < NW; ++w)
           if (w < nw) {
             uint32_t take = min(8u, k - 8 * w);
-            key = (key << (2 * take)) | pack8(x[j][w], take, ok);
+            key = (key << (2 * take)) | (KEY)pack8(x[j][w], take, ok);
           }
       } else {
         const char* p = bases + ro[j] + st[j];
         for (uint32_t i = 0; i < k; ++i) {                // tail of the buffer: byte loads
           int b = base2(p[i]);
           if (b < 0) { ok = 0; b = 0; }
-          key = (key << 2) | (uint64_t)b;
+          key = (key << 2) | (KEY)b;
         }
       }
+      if constexpr (WIDE) {
+        seed_wide[s] = ok ? key : key_invalid<u128>();
+        seed_pfx[s] = (uint32_t)(key >> (2 * (k - pfx_len)));
+        seed_key[s] = ok ? table_key(key) : KEY_INVALID;
+      } else
       seed_key[s] = ok ? key : KEY_INVALID;
       seed_info[s] = make_uint2((uint32_t)lo[j], (uint32_t)st[j]);     // (read, offset in read)
       nok += ok;
@@ -603,7 +640,7 @@ struct SeedBuckets {
   uint32_t k;
 };
 
-__device__ __forceinline__ uint32_t sb_bucket(uint64_t key, uint32_t k, uint32_t pb) { return (uint32_t)(key >> (2 * (k - pb))); }
+__device__ __forceinline__ uint32_t sb_bucket(uint64_t key, uint32_t k, uint32_t pb) { return pb ? (uint32_t)(key >> (2 * (k - pb))) : 0u; }
 // where a k-mer's search starts inside its bucket's region of m slots
 __device__ __forceinline__ uint32_t sb_home(uint64_t key, uint32_t m) { return (uint32_t)__umul64hi(mix64(key), (uint64_t)m); }
 
@@ -735,7 +772,8 @@ __global__ void __launch_bounds__(256) k_fill3(FillJob a, FillJob b, FillJob c)
 __global__ void k_table_insert(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
                                uint64_t seeds_cap, TableSlot* __restrict__ ht, uint32_t m /* slots of the one region */,
                                uint32_t* __restrict__ seed_next, uint32_t k,
-                               uint32_t* __restrict__ pfx_bits, uint32_t pfx_len, uint64_t* __restrict__ boff)
+                               uint32_t* __restrict__ pfx_bits, uint32_t pfx_len, uint64_t* __restrict__ boff,
+                               const uint32_t* __restrict__ seed_pfx /* two-word seeds: the key is a fingerprint, the prefix comes from here */)
 {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s == 0) { boff[0] = 0; boff[1] = m / 2; }       // the one bucket's "offsets": slots [2 boff[0], 2 boff[1])
@@ -744,7 +782,7 @@ __global__ void k_table_insert(const uint64_t* __restrict__ seed_key, const uint
   seed_next[s] = NIL;
   if (key == KEY_INVALID) return;
   {
-    uint32_t pf = (uint32_t)(key >> (2 * (k - pfx_len)));
+    uint32_t pf = seed_pfx ? seed_pfx[s] : (uint32_t)(key >> (2 * (k - pfx_len)));
     atomicOr(&pfx_bits[pf >> 5], 1u << (pf & 31));
   }
   uint32_t h = sb_home(key, m);
@@ -797,10 +835,11 @@ __global__ void k_pfx_derive(const uint32_t* __restrict__ pfx_bits, uint32_t pfx
 // k_wave_offsets turns the sums into the wave's first output slot, and k_fm_locate, walking the
 // same ranges, places every hit with a running wave-local prefix: hits come out in seed order
 // with no atomics and no scan over the seeds.
-template <bool LISTED>        // (two kernels: the list mode's pointers and strides cost the range mode scalar registers,
-                              // and at 101 of them a SIMD holds 7 waves instead of the 8 the launch is sized for)
+template <bool LISTED, typename KEY>   // (LISTED: two kernels -- the list mode's pointers and strides cost the range mode scalar
+                              // registers, and at 101 of them a SIMD holds 7 waves instead of the 8 the launch is sized
+                              // for.  KEY: one word for seeds of up to 31 bases, two for up to 63)
 __global__ void __launch_bounds__(256)
-k_fm_search(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
+k_fm_search(FMView fm, const KEY* __restrict__ seed_key, const uint64_t* __restrict__ params,
             uint64_t seeds_cap, uint32_t per_wave,
             uint32_t k, uint32_t gocc_thr, uint32_t* __restrict__ iv_lo, uint32_t* __restrict__ iv_cnt,
             uint32_t* __restrict__ iv_aux, uint64_t* __restrict__ wave_total, DevCounters* ctr,
@@ -824,14 +863,14 @@ k_fm_search(FMView fm, const uint64_t* __restrict__ seed_key, const uint64_t* __
   for (uint64_t base = s0; base < s1; base += stride) {
     const bool in = base + quad < s1;
     const uint64_t seed = listed ? (in ? list[base + quad] : 0) : base + quad;
-    uint64_t key = in ? seed_key[seed] : KEY_INVALID;
-    bool alive = key != KEY_INVALID;
+    KEY key = in ? seed_key[seed] : key_invalid<KEY>();
+    bool alive = key != key_invalid<KEY>();
     uint32_t l = 0, r = fm.n, j0 = 0;
     if (fm.ftab != nullptr && k >= fm.ftab_len) {
       // the first ftab_len steps (the seed's last ftab_len bases) are one table lookup
       j0 = fm.ftab_len;
       if (alive) {
-        uint2 iv = fm.ftab[key & ((1ull << (2 * j0)) - 1ull)];
+        uint2 iv = fm.ftab[(uint64_t)key & ((1ull << (2 * j0)) - 1ull)];
         l = iv.x; r = iv.y;
         alive = r > l;
       }
@@ -2158,6 +2197,7 @@ struct TableView {
   const TableSlot* ht;                            // every bucket's region one after the other (k_sb_build)
   const uint64_t* boff; uint32_t n_wg, pb;        // bucket b: slots [2 boff[b n_wg], 2 boff[(b + 1) n_wg])
   const uint32_t* seed_next; const uint2* seed_info;
+  const void* seed_wide;                          // two-word seeds: the k-mer of every seed (u128), else nullptr
   const uint32_t* pfx12;                          // 4^12-bit prefix bitmap (nullptr when k < 12)
   const uint32_t* pfx_bits; uint32_t pfx_len;     // prefix bitmap of the seeds, 4^pfx_len bits
 };
@@ -2192,26 +2232,30 @@ __device__ __forceinline__ bool any_n(const uint64_t* labn, uint64_t at, uint32_
 // and the table / emit chain is paid once per 64 k-mers.
 constexpr int DONE_CAP = 128;          // completed k-mers waiting for the table lookup
 
-struct DoneItem { uint64_t kmer; uint32_t locus; uint32_t pad; };
+template <typename KEY> struct DoneItemT { KEY kmer; uint32_t locus; uint32_t pad; };
 
+template <typename KEY>
 __device__ __forceinline__ void
-process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ loci, const DoneItem* dq, uint32_t n, uint32_t k,
+process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ loci, const DoneItemT<KEY>* dq, uint32_t n, uint32_t k,
              uint64_t rec_offset, ChunkWriter& cw, DevCounters* ctr)
 {
   // lanes 0..n-1 take one completed k-mer each
   const uint32_t lane = lane_id();
   uint32_t s = NIL, dup = NIL, locus = 0;
+  KEY want = 0;
   if (lane < n) {
-    DoneItem d = dq[lane];
+    DoneItemT<KEY> d = dq[lane];
+    want = d.kmer;
+    const uint64_t tkey = table_key(d.kmer);
     locus = d.locus;
-    const uint32_t b = sb_bucket(d.kmer, k, tb.pb);
+    const uint32_t b = sb_bucket(tkey, k, tb.pb);
     const uint32_t lo = (uint32_t)tb.boff[(uint64_t)b * tb.n_wg], m = 2 * ((uint32_t)tb.boff[(uint64_t)(b + 1) * tb.n_wg] - lo);
     if (m) {
       const TableSlot* region = tb.ht + 2ull * lo;
-      uint32_t h = sb_home(d.kmer, m);
+      uint32_t h = sb_home(tkey, m);
       while (true) {
         TableSlot sl = region[h];
-        if (sl.key == d.kmer) { s = sl.val; dup = sl.dup; break; }
+        if (sl.key == tkey) { s = sl.val; dup = sl.dup; break; }
         if (sl.key == KEY_INVALID) break;
         h = h + 1 < m ? h + 1 : 0;
       }
@@ -2225,6 +2269,8 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
     uint64_t rid = 0, roff = 0;
     uint32_t nx = NIL;
     if (has) {
+      // (two-word seeds: the table is keyed by a fingerprint -- a seed counts only when its k-mer is the walk's)
+      if constexpr (sizeof(KEY) > 8) has = reinterpret_cast<const u128*>(tb.seed_wide)[s] == want;
       uint2 si = tb.seed_info[s]; rid = rec_offset + si.x; roff = si.y;
       nx = dup;                                   // then down the duplicate chain
       if (dup != NIL) dup = tb.seed_next[dup];
@@ -2234,15 +2280,18 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
   }
 }
 
-template <bool ENUM>
+template <bool ENUM, typename KEY = uint64_t>
 __global__ void __launch_bounds__(64)
 k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node rank, offset) */,
            uint64_t n_loci, uint32_t loci_per_wave,
-           const TravItem* __restrict__ spill_in, uint64_t n_spill_in,
-           TravItem* __restrict__ spill_out, uint64_t spill_cap,
+           const TravItemT<KEY>* __restrict__ spill_in, uint64_t n_spill_in,
+           TravItemT<KEY>* __restrict__ spill_out, uint64_t spill_cap,
            uint32_t k, uint64_t rec_offset, psigpu_hit* __restrict__ chunks, uint32_t* __restrict__ chunk_fill,
            uint32_t cap_chunks, uint64_t n_nodes, DevCounters* ctr, EnumOut eo)
 {
+  typedef TravItemT<KEY> TravItem;
+  typedef DoneItemT<KEY> DoneItem;
+  static_assert(!ENUM || sizeof(KEY) == 8, "the tables are made for one-word seeds");
   __shared__ TravItem stack[TRAV_CAP];
   __shared__ DoneItem doneq[DONE_CAP];
   __shared__ TravItem rootbuf[64];        // staged roots and their start offsets
@@ -2321,12 +2370,12 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
 
     // ---- extend through one node ---------------------------------------------------
     uint32_t nchild = 0, e_off = 0;
-    uint64_t fork_kmer = 0;
+    KEY fork_kmer = 0;
     bool done = false;
     if (have) {
       uint32_t widx = it.node - wb;                                     // wraps above the window
       NodeLite nl = widx < win_n ? window[widx] : g.lite[it.node];
-      uint32_t depth = (63u - (uint32_t)__clzll((long long)it.kmer)) >> 1;
+      uint32_t depth = hibit(it.kmer) >> 1;
       uint64_t b = 0;
       uint32_t take, e1 = 0, coff = 0;
       bool dead = false;
@@ -2357,8 +2406,8 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
         nl.edge0 = nr.edge0;
       }
       if (take && !dead) {
-        uint64_t body = it.kmer ^ (1ull << (2 * depth));
-        body = (body << (2 * take)) | b;
+        KEY body = it.kmer ^ ((KEY)1 << (2 * depth));
+        body = (body << (2 * take)) | (KEY)b;
         uint32_t nd = depth + take;
         // seed-prefix filter, once per level, when the walk first reaches that many bases;
         // both probes are issued together
@@ -2369,7 +2418,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
         if (c14) { p14 = (uint32_t)(body >> (2 * (nd - tb.pfx_len))); w14 = tb.pfx_bits[p14 >> 5]; }
         dead = !((w12 >> (p12 & 31)) & (w14 >> (p14 & 31)) & 1u);
         depth = nd;
-        it.kmer = body | (1ull << (2 * depth));
+        it.kmer = body | ((KEY)1 << (2 * depth));
       }
       if (dead) { have = false; nchild = 0; }
       else if (depth == k) { done = true; have = false; nchild = 0; }
@@ -2386,20 +2435,20 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
       // a locus that went over the cap stops forking (it is left to the query-time traverser)
       bool has = false;
       if (done) { ++kpaths; has = atomicAdd(&eo.walks[it.locus], 1u) < eo.walk_cap; }
-      pair_emit(eo, pw, has, it.kmer ^ (1ull << (2 * k)), it.locus, ctr);
+      pair_emit(eo, pw, has, (uint64_t)(it.kmer ^ ((KEY)1 << (2 * k))), it.locus, ctr);
       if (nchild > 1 && eo.walks[it.locus] > eo.walk_cap) { nchild = 0; have = false; }
     } else {
       uint64_t dm = __ballot(done);
       if (dm) {
         if (done) {
           ++kpaths;
-          DoneItem d = { it.kmer ^ (1ull << (2 * k)), it.locus, 0 };
+          DoneItem d = { it.kmer ^ ((KEY)1 << (2 * k)), it.locus, 0 };
           doneq[ndone + (uint32_t)__popcll(dm & lanemask_lt())] = d;
         }
         ndone += (uint32_t)__popcll(dm);
         __builtin_amdgcn_wave_barrier();
         if (ndone >= 64) {
-          process_done(g, tb, loci, doneq + (ndone - 64), 64, k, rec_offset, cw, ctr);
+          process_done<KEY>(g, tb, loci, doneq + (ndone - 64), 64, k, rec_offset, cw, ctr);
           ndone -= 64;
         }
       }
@@ -2427,7 +2476,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   if constexpr (ENUM) {
     if (pw.id != NIL && pw.id < eo.cap_chunks && lane == 0) eo.fill[pw.id] = pw.n;
   } else {
-    if (ndone) process_done(g, tb, loci, doneq, ndone, k, rec_offset, cw, ctr);
+    if (ndone) process_done<KEY>(g, tb, loci, doneq, ndone, k, rec_offset, cw, ctr);
     chunk_close(cw);
   }
 #ifdef TRAV_STATS
@@ -2707,7 +2756,8 @@ struct psigpu_ctx {
   DevBuf w_bases, w_read_off, w_cnt, w_tiles, w_seed_off, w_seed_key, w_seed_info,
       w_seed_next, w_ht, w_pfx, w_pfx12, w_iv_lo, w_iv_cnt, w_iv_aux, w_hit_off, w_iv_tiles,
       w_chunks, w_chunk_fill, w_chunk_off, w_chunk_tiles, w_hits, w_spill_a, w_spill_b, w_ctr, w_total,
-      w_sb_cnt, w_sb_off, w_sb_tiles, w_sb_key, w_sb_seed;      // the partition of a chunk's seeds (k_sb_*)
+      w_sb_cnt, w_sb_off, w_sb_tiles, w_sb_key, w_sb_seed,      // the partition of a chunk's seeds (k_sb_*)
+      w_seed_wide, w_seed_pfx;                                  // two-word seeds: the k-mers themselves, their first 14 bases
   uint64_t hits_cap_hint = 0, chunks_cap_hint = 0;
   uint64_t spill_cap = 1u << 22;   // traverser spill queue entries (grows when a chunk overflows it)
   void* h_pinned = nullptr;        // pinned host mirror of the counters + counts, written by k_publish
@@ -2842,7 +2892,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
   for (auto* b : all) b->release();
   ctx->ids_sorted.release(); ctx->w_sorted[0].release(); ctx->w_sorted[1].release(); ctx->w_count.release();
   ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release();
-  for (DevBuf* b : { &ctx->w_sb_cnt, &ctx->w_sb_off, &ctx->w_sb_tiles, &ctx->w_sb_key, &ctx->w_sb_seed }) b->release();
+  for (DevBuf* b : { &ctx->w_sb_cnt, &ctx->w_sb_off, &ctx->w_sb_tiles, &ctx->w_sb_key, &ctx->w_sb_seed, &ctx->w_seed_wide, &ctx->w_seed_pfx }) b->release();
   for (auto& m : ctx->parts) m->release();
   ctx->w_hits_alt.release();
   for (auto& sl : ctx->slot) {
@@ -3383,7 +3433,7 @@ static int ensure_lkt(psigpu_ctx* ctx, uint32_t k, const GraphView& gv)
       PASS_TRY(hipMemset(ctr, 0, sizeof(DevCounters)));
       EnumOut eo = { ps.chunks.as<ulonglong2>(), ps.fill.as<uint32_t>(), (uint32_t)ps.cap_chunks, ps.walks.as<uint32_t>(), cap };
       if (n_roots)
-        k_traverse<true><<<(unsigned)n_waves, 64>>>(gv, tb, roots, n_roots, per_wave, nullptr, 0, spill_a.as<TravItem>(),
+        k_traverse<true, uint64_t><<<(unsigned)n_waves, 64>>>(gv, tb, roots, n_roots, per_wave, nullptr, 0, spill_a.as<TravItem>(),
                                                     spill_cap, k, 0, nullptr, nullptr, 0, ctx->n_nodes, ctr, eo);
       PASS_TRY(hipMemcpy(&h, ctr, sizeof h, hipMemcpyDeviceToHost));
       TmpBuf* qin = &spill_a;
@@ -3403,7 +3453,7 @@ static int ensure_lkt(psigpu_ctx* ctx, uint32_t k, const GraphView& gv)
           break;
         }
         PASS_TRY(hipMemset(&ctr->n_spill.v, 0, 8));
-        k_traverse<true><<<(unsigned)((ns + 63) / 64), 64>>>(gv, tb, roots, n_roots, 64, qin->as<TravItem>(), ns,
+        k_traverse<true, uint64_t><<<(unsigned)((ns + 63) / 64), 64>>>(gv, tb, roots, n_roots, 64, qin->as<TravItem>(), ns,
                                                             qout->as<TravItem>(), spill_cap, k, 0, nullptr, nullptr, 0,
                                                             ctx->n_nodes, ctr, eo);
         std::swap(qin, qout);
@@ -3596,7 +3646,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   flags &= ~PSIGPU_SORT_UNIQUE;
   ctx->grouped_state = 0;
   if (step == 0) step = k;                       // src/psikt.cpp:469
-  if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..31)"; return PSIGPU_ERR_ARG; }
+  if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..63)"; return PSIGPU_ERR_ARG; }
   if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
   if ((flags & PSIGPU_OFF_PATHS) && ctx->n_loci && ctx->index_k != k) {
     ctx->err = "starting loci were computed for a different seed length";
@@ -3639,10 +3689,13 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   // Off-path hits: from the locus k-mer table (built on first use), the query-time traverser for
   // the loci the table leaves out -- or for all of them in PSIGPU_OFFPATH_TRAVERSE mode.
   const bool want_off = (flags & PSIGPU_OFF_PATHS) && ctx->n_loci && n_reads;
-  const bool want_kt = ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->index_k == k && n_reads &&
+  // seeds of 32..63 bases are two words: answered by the FM index and the query-time traverser (the reference's
+  // scheme); the tables of the other modes hold one-word k-mers
+  const bool wide = k > PSIGPU_MAX_TABLE_SEED_LEN;
+  const bool want_kt = ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->index_k == k && n_reads && !wide &&
                        (want_off || ((flags & PSIGPU_ON_PATHS) && ctx->n_paths));
   bool use_lkt = false, use_kt = false;
-  if ((want_off && ctx->query_mode != PSIGPU_MODE_TRAVERSE) || want_kt) {
+  if (((want_off && ctx->query_mode != PSIGPU_MODE_TRAVERSE) || want_kt) && !wide) {
     const bool had = (ctx->lkt_ready || ctx->lkt_failed) && ctx->lkt_k == k;
     int st = ensure_lkt(ctx, k, gv);
     if (st != PSIGPU_OK) return st;
@@ -3677,7 +3730,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   const bool use_pfx12 = need_table && k > PFX_SHORT;
   SeedBuckets sb;
   const char* sb_env = getenv("PSIGPU_SB_MAX");                         // (tests: 0 forces the one-region build on small chunks)
-  const bool sb_parts = seeds_ub <= (sb_env ? strtoull(sb_env, nullptr, 10) : SB_MAX_SEEDS);     // partitioned build, or one region for the whole chunk
+  const bool sb_parts = !wide && seeds_ub <= (sb_env ? strtoull(sb_env, nullptr, 10) : SB_MAX_SEEDS);     // partitioned build, or one region for the whole chunk
   sb.pb = sb_parts ? std::min<uint32_t>(SB_BASES, pfx_len) : 0u; sb.n_buckets = 1u << (2 * sb.pb);
   sb.n_wg = sb_parts ? (uint32_t)((seeds_ub + SB_TILE - 1) / SB_TILE) + 1 : 1u; sb.k = k;
   if (2 * seeds_ub >= 0xFFFFFFF0ull && need_table) { ctx->err = "too many seeds in one chunk for the traverser's seed table"; return PSIGPU_ERR_ARG; }
@@ -3713,10 +3766,21 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   HIPCHK(ctx, ctx->w_seed_key.ensure((n_seeds + 1) * 8));
   HIPCHK(ctx, ctx->w_seed_info.ensure((n_seeds + 1) * 8));
   HIPCHK(ctx, ctx->w_seed_next.ensure((n_seeds + 1) * 4));
-  if (n_seeds)
-        k_seed_pack<<<(unsigned)std::min<uint64_t>((n_seeds + 256 * SP - 1) / (256 * SP), 256 * 32), 256, 0, stream>>>(
-        d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases, k, step,
-        ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr);
+  if (wide) {
+    HIPCHK(ctx, ctx->w_seed_wide.ensure((n_seeds + 1) * 16));
+    HIPCHK(ctx, ctx->w_seed_pfx.ensure((n_seeds + 1) * 4));
+  }
+  if (n_seeds) {
+    const unsigned pgrid = (unsigned)std::min<uint64_t>((n_seeds + 256 * SP - 1) / (256 * SP), 256 * 32);
+    if (wide)
+      k_seed_pack<true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases,
+                                                   k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
+                                                   ctx->w_seed_wide.as<u128>(), ctx->w_seed_pfx.as<uint32_t>(), pfx_len);
+    else
+      k_seed_pack<false><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases,
+                                                    k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
+                                                    nullptr, nullptr, 0);
+  }
   EVREC(1, stream);
   static const bool env_no_verify = getenv("PSIGPU_NO_VERIFY") != nullptr;   // A/B: LF steps only
   const bool no_verify = env_no_verify || (ctx->tune & PSIGPU_TUNE_NO_VERIFY);
@@ -3752,6 +3816,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   tb.boff = ctx->w_sb_off.as<uint64_t>(); tb.n_wg = sb.n_wg; tb.pb = sb.pb;
   tb.seed_next = ctx->w_seed_next.as<uint32_t>();
   tb.seed_info = ctx->w_seed_info.as<uint2>();
+  tb.seed_wide = wide ? ctx->w_seed_wide.p : nullptr;
   // PSIGPU_NO_PFX (diagnostic): no pruning, so n_kpaths counts every k-walk from the starting loci
   const bool no_pfx = getenv("PSIGPU_NO_PFX") != nullptr;
   tb.pfx12 = (use_pfx12 && !no_pfx) ? ctx->w_pfx12.as<uint32_t>() : nullptr;
@@ -3783,8 +3848,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   constexpr int MAX_ATTEMPTS = 6;
   for (int attempt = 0; attempt < MAX_ATTEMPTS; ++attempt) {
     if (off_paths) {
-      HIPCHK(ctx, ctx->w_spill_a.ensure(spill_cap * sizeof(TravItem)));
-      HIPCHK(ctx, ctx->w_spill_b.ensure(spill_cap * sizeof(TravItem)));
+      HIPCHK(ctx, ctx->w_spill_a.ensure(spill_cap * sizeof(TravItemT<u128>)));       // (room for either item type)
+      HIPCHK(ctx, ctx->w_spill_b.ensure(spill_cap * sizeof(TravItemT<u128>)));
     }
     HIPCHK(ctx, ctx->w_hits.ensure((cap + 1) * sizeof(psigpu_hit)));
     psigpu_hit* d_hits = ctx->w_hits.as<psigpu_hit>();
@@ -3810,7 +3875,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         k_fill3<<<2048, 256, 0, ts>>>(fa, fb, fc);
         k_table_insert<<<(unsigned)((n_seeds + 255) / 256), 256, 0, ts>>>(
             ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, ctx->w_ht.as<TableSlot>(), m, ctx->w_seed_next.as<uint32_t>(), k,
-            ctx->w_pfx.as<uint32_t>(), pfx_len, ctx->w_sb_off.as<uint64_t>());
+            ctx->w_pfx.as<uint32_t>(), pfx_len, ctx->w_sb_off.as<uint64_t>(), wide ? ctx->w_seed_pfx.as<uint32_t>() : nullptr);
         if (use_pfx12)
           k_pfx_derive<<<(1u << (2 * PFX_SHORT)) / 32 / 256, 256, 0, ts>>>(ctx->w_pfx.as<uint32_t>(), pfx_len, ctx->w_pfx12.as<uint32_t>());
         EVREC(6, ts);
@@ -3838,7 +3903,14 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
       // ~96 waves per CU over the launch keeps the tail short and the atomics few
       const uint32_t per_wave = (uint32_t)std::max<uint64_t>(256, (n_trav_loci + 24575) / 24576);
       uint64_t n_waves = (n_trav_loci + per_wave - 1) / per_wave;
-      k_traverse<false><<<(unsigned)n_waves, 64, 0, ts>>>(
+      if (wide)
+        k_traverse<false, u128><<<(unsigned)n_waves, 64, 0, ts>>>(
+            gv, tb, trav_loci, n_trav_loci, per_wave,
+            nullptr, 0, ctx->w_spill_a.as<TravItemT<u128>>(), spill_cap, k, rec_offset,
+            ctx->w_chunks.as<psigpu_hit>(), ctx->w_chunk_fill.as<uint32_t>(), (uint32_t)cap_chunks, ctx->n_nodes, ctr,
+            EnumOut{});
+      else
+      k_traverse<false, uint64_t><<<(unsigned)n_waves, 64, 0, ts>>>(
           gv, tb, trav_loci, n_trav_loci, per_wave,
           nullptr, 0, ctx->w_spill_a.as<TravItem>(), spill_cap, k, rec_offset,
           ctx->w_chunks.as<psigpu_hit>(), ctx->w_chunk_fill.as<uint32_t>(), (uint32_t)cap_chunks, ctx->n_nodes, ctr,
@@ -3902,7 +3974,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
           for (uint32_t p = 0; p < n_fm; ++p) {
             const FMView fm = fm_view(*ctx->parts[p]);
             const SeedOut so = seed_out(p);
-            const bool direct = fm.ftab != nullptr && fm.sarec != nullptr && !no_direct;
+            const bool direct = fm.ftab != nullptr && fm.sarec != nullptr && !no_direct && !wide;      // (row records verify <= 29 bases)
             if (direct) {
               HIPCHK(ctx, ctx->w_defer.ensure((n_seeds + 1) * 4));
               if (p) HIPCHK(ctx, hipMemsetAsync(&ctr->n_defer.v, 0, 8, stream));
@@ -3910,13 +3982,17 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
               k_fm_search_direct<<<grid, 256, 0, stream>>>(
                   fm, ride ? lk : LktView{ nullptr, 0, nullptr }, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1, so,
                   tiles_of(p), ride ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, ctx->w_defer.as<uint32_t>(), ctr);
-              k_fm_search<true><<<256, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
+              k_fm_search<true, uint64_t><<<256, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
                                                    so.iv_lo, so.iv_cnt, so.iv_aux, tiles_of(p), ctr,
                                                    ctx->w_defer.as<uint32_t>(), &ctr->n_defer.v);
               pc.search_launches += 2;
               probed = probed || ride;
             } else {
-              k_fm_search<false><<<grid, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
+              if (wide)
+                k_fm_search<false, u128><<<grid, 256, 0, stream>>>(fm, ctx->w_seed_wide.as<u128>(), d_params, n_seeds, per_wave, k, thr_k1,
+                                                                  so.iv_lo, so.iv_cnt, so.iv_aux, tiles_of(p), ctr, nullptr, nullptr);
+              else
+              k_fm_search<false, uint64_t><<<grid, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
                                                     so.iv_lo, so.iv_cnt, so.iv_aux, tiles_of(p), ctr, nullptr, nullptr);
               pc.search_launches += 1;
             }
@@ -4009,7 +4085,14 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         pc.n_spilled += ns;
         HIPCHK(ctx, hipMemsetAsync(&ctr->n_spill.v, 0, 8, stream));
         const uint32_t pw = 64;
-        k_traverse<false><<<(unsigned)((ns + pw - 1) / pw), 64, 0, stream>>>(
+        if (wide)
+          k_traverse<false, u128><<<(unsigned)((ns + pw - 1) / pw), 64, 0, stream>>>(
+              gv, tb, trav_loci, n_trav_loci, pw,
+              qin->as<TravItemT<u128>>(), ns, qout->as<TravItemT<u128>>(), spill_cap, k, rec_offset,
+              ctx->w_chunks.as<psigpu_hit>(), ctx->w_chunk_fill.as<uint32_t>(), (uint32_t)cap_chunks, ctx->n_nodes, ctr,
+              EnumOut{});
+        else
+        k_traverse<false, uint64_t><<<(unsigned)((ns + pw - 1) / pw), 64, 0, stream>>>(
             gv, tb, trav_loci, n_trav_loci, pw,
             qin->as<TravItem>(), ns, qout->as<TravItem>(), spill_cap, k, rec_offset,
             ctx->w_chunks.as<psigpu_hit>(), ctx->w_chunk_fill.as<uint32_t>(), (uint32_t)cap_chunks, ctx->n_nodes, ctr,
@@ -4270,9 +4353,9 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k)
 {
   if (!ctx) return PSIGPU_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..31)"; return PSIGPU_ERR_ARG; }
+  if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..63)"; return PSIGPU_ERR_ARG; }
   if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
-  if (ctx->index_k != k) return PSIGPU_OK;                                // tables exist for the index's seed length only
+  if (ctx->index_k != k || k > PSIGPU_MAX_TABLE_SEED_LEN) return PSIGPU_OK;   // tables exist for the index's seed length only, and for one-word seeds
   int st = PSIGPU_OK;
   if (ctx->query_mode != PSIGPU_MODE_TRAVERSE &&                           // (nothing is tabulated in traverse mode)
       !(ctx->n_loci == 0 && !(ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->n_paths)))

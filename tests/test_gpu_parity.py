@@ -222,7 +222,7 @@ def test_argument_errors():
         f2.seeds_all(reads[:3])
     assert len(f2.seeds_on_paths(reads[:3]))   # the FM-index itself is k-independent
     with pytest.raises(psi_amd.PsiGpuError):
-        psi_amd.SeedFinder(g, 32)
+        psi_amd.SeedFinder(g, 64)
     f.close()
     f2.close()
 
@@ -944,6 +944,72 @@ def test_random_graphs_vs_brute(seed):
         got = psi_amd.sort_unique(f.seeds_all(reads, step=step))
         assert _eq(got, want), (seed, k, step, npaths)
         f.close()
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_long_seeds_random_graphs_vs_brute(seed):
+    """Seeds of 32..63 bases (psikt takes any -l, src/psikt.cpp:327): two-word k-mers through the FM search, the
+    traverser and its seed table (keyed by a fingerprint, every candidate's k-mer compared); the tabulating modes
+    answer them the same way.  Random graphs (cycles, N runs, out-degree up to 5) against the brute-force definition."""
+    from oracle import brute
+    import random
+    g, reads = _random_graph(5000 + seed)
+    rng = random.Random(seed)
+    rank = {v: i for i, v in enumerate(g.ids)}
+    label_off = np.cumsum([0] + [len(g.seq[v]) for v in g.ids])
+    labels = ''.join(g.seq[v] for v in g.ids).encode()
+    edge_off = np.cumsum([0] + [len(g.out[v]) for v in g.ids])
+    edge_to = [rank[t] for v in g.ids for t in g.out[v]]
+    pg = psi_amd.Graph.from_csr(g.ids, label_off, labels, edge_off, edge_to,
+                                paths=[[rank[v] for v in g.paths[0][1]]])
+    for _ in range(2):
+        k = rng.choice([32, 33, 40, 47, 56, 63])
+        step = rng.choice([1, 2, 5])
+        npaths = rng.choice([0, 1, 2])
+        want = np.array(brute.hit_set(g, [r.upper() for r in reads], k, step), dtype=np.uint64).reshape(-1, 4)
+        f = psi_amd.SeedFinder(pg, k)
+        f.create_path_index(npaths, rng_seed=seed, sa_rate=rng.choice([1, 1, 4]), ftab_len=rng.choice([0, 4, psi_amd.NO_FTAB]),
+                            build_on_device=rng.random() < 0.5)
+        got = psi_amd.sort_unique(f.seeds_all(reads, step=step))
+        assert _eq(got, want), (seed, k, step, npaths)
+        f.close()
+
+
+@pytest.mark.parametrize('k,npaths', [(32, 1), (45, 0), (45, -3), (63, 2)])
+def test_long_seeds_reference_graph(k, npaths):
+    """The same on the reference's graph x with its 100-bp reads (npaths < 0: patched paths, context k + 2): brute-force
+    hit set; the library's sort-unique; phases partition the set; a gocc threshold; an index in two parts."""
+    from oracle import brute
+    g, reads = _x_case()
+    reads = reads[:150]
+    bg = brute.parse_gfa(os.path.join(REF, 'x.gfa'))
+    want = np.array(brute.hit_set(bg, reads, k, 7), dtype=np.uint64).reshape(-1, 4)
+    assert len(want) > 150
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(abs(npaths), rng_seed=5, patched=npaths < 0, context=k + 2 if npaths < 0 else 0)
+    assert _eq(psi_amd.sort_unique(f.seeds_all(reads, step=7)), want)
+    su = f.seeds_all(reads, step=7, sort_unique=True)
+    assert _eq(su, want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))])
+    on, off_ = f.seeds_on_paths(reads, step=7), f.seeds_off_paths(reads, step=7)
+    assert _eq(psi_amd.sort_unique(np.concatenate([on, off_])), want) and (len(on) > 0) == (npaths != 0)
+    if npaths:
+        bases, off = psi_amd.pack_reads(reads)
+        f.set_gocc_threshold(1)
+        got1 = psi_amd.sort_unique(f.seeds_all(reads, step=7))
+        assert len(got1) <= len(want)
+        f.set_gocc_threshold(0)
+        lens = [sum(int(g.label_off[v + 1] - g.label_off[v]) for v in p) for p in f.pindex.paths()]
+        if abs(npaths) >= 2:
+            pp = psi_amd.PathIndex.build(g, k, abs(npaths), rng_seed=5, patched=npaths < 0, context=k + 2 if npaths < 0 else 0,
+                                         max_part_text=max(max(lens) + 40, f.pindex.text_len // 2))
+            assert pp.view.n_more_parts >= 1
+            f2 = psi_amd.SeedFinder(g, k, gocc_threshold=1)
+            f2.set_path_index(pp)
+            assert _eq(psi_amd.sort_unique(f2.seeds_all(reads, step=7)), got1)
+            f2.close()
+    f.close()
+    with pytest.raises(psi_amd.PsiGpuError):
+        psi_amd.SeedFinder(g, 64)
 
 
 def test_regression_all_t_31mer_with_an_ext_record(query_mode):

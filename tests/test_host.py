@@ -623,7 +623,12 @@ def test_index_in_several_parts_host(tmp_path, ref_data, patched):
 def test_index_argument_checks(ref_data):
     b, g = _setup(ref_data, 'tiny')
     with pytest.raises(psi_amd.PsiGpuError):
-        psi_amd.PathIndex.build(g, 32, 1)              # seed length above 31
+        psi_amd.PathIndex.build(g, 64, 1)              # seed length above 63
+    # starting loci for a two-word seed length = the brute-force definition (tiny: 15 nodes)
+    px = psi_amd.PathIndex.build(g, 40, 1, rng_seed=2)
+    ln, lo = px.loci
+    paths = [[b.ids[v] for v in p.tolist()] for p in px.paths()]
+    assert [(b.ids[v], int(o)) for v, o in zip(ln.tolist(), lo.tolist())] == brute.uncovered_loci(b, paths, 40)
     with pytest.raises(psi_amd.PsiGpuError):
         psi_amd.PathIndex.build(g, 10, 1, sa_rate=3)   # not a power of two
     with pytest.raises(psi_amd.PsiGpuError):
