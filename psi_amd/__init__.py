@@ -664,7 +664,7 @@ class DeviceHits:
     (valid until the next call on the finder).  What a gather over RCCL sends, without a trip through the host."""
 
     def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {'shape': (int(n), 4), 'typestr': '<i8', 'data': (int(ptr), True), 'version': 2,
+        self.__cuda_array_interface__ = {'shape': (int(n), 4), 'typestr': '<i8', 'data': (int(ptr), False), 'version': 2,
                                          'strides': None}
 
 

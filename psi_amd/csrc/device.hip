@@ -2376,7 +2376,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
       uint32_t widx = it.node - wb;                                     // wraps above the window
       NodeLite nl = widx < win_n ? window[widx] : g.lite[it.node];
       uint32_t depth = hibit(it.kmer) >> 1;
-      uint64_t b = 0;
+      KEY b = 0;
       uint32_t take, e1 = 0, coff = 0;
       bool dead = false;
       if (!(nl.meta & LITE_SLOW)) {
@@ -2397,6 +2397,10 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
           } else {                            // long node: label words
             uint64_t lab = nr.w0 & 0xFFFFFFFFFFull;
             dead = (nr.w0 >> 63) && any_n(g.labn, lab + off, take);
+            if (sizeof(KEY) > 8 && take > 32)           // (two-word seeds: up to 63 bases of one long node at a time)
+              b = dead ? (KEY)0 : (((KEY)fetch_bases(g.lab2, lab + off, 32) << (2 * (take - 32))) |
+                                   (KEY)fetch_bases(g.lab2, lab + off + 32, take - 32));
+            else
             b = dead ? 0 : fetch_bases(g.lab2, lab + off, take);
           }
         }
@@ -2407,7 +2411,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
       }
       if (take && !dead) {
         KEY body = it.kmer ^ ((KEY)1 << (2 * depth));
-        body = (body << (2 * take)) | (KEY)b;
+        body = (body << (2 * take)) | b;
         uint32_t nd = depth + take;
         // seed-prefix filter, once per level, when the walk first reaches that many bases;
         // both probes are issued together
