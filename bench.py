@@ -350,16 +350,18 @@ def main():
             # (a bench "kernel" may be several launches: the walk and the per-hit resolve of a sampled suffix array; the
             # partition and the per-bucket build of the chunk's seed table)
             names = {'k_fm_locate': [['k_kmer_emit'], ['k_fm_locate_direct'], ['k_fm_walk', 'k_hits_resolve']],
-                     'k_fm_search': [['k_fm_search_direct'], ['void k_fm_search<false>']],
-                     'k_traverse': [['void k_traverse<false>']],
+                     'k_fm_search': [['k_fm_search_direct'], ['void k_fm_search<false']],
+                     'k_traverse': [['void k_traverse<false']],
                      'k_seed_pack': [['k_seed_pack']],
                      'k_table_insert': [['k_sb_count', 'k_sb_scatter', 'k_sb_build']]}.get(dom, [[dom]])
             tot = lambda t: t.get('fetch_size_bytes', 0.0) + t.get('write_size_bytes', 0.0)      # noqa: E731
+            find = lambda pre: next((kn for kn in pl if kn == pre or kn.startswith(pre + ',') or kn.startswith(pre + '>')), None)   # noqa: E731
             for group in names:
-                if all(pl.get(n) for n in group) and tot(pl[group[0]]) > 1e6 and tj.get('mode') == mode and \
+                real = [find(n) for n in group]
+                if all(real) and tot(pl[real[0]]) > 1e6 and tj.get('mode') == mode and \
                         tj.get('series', '') == (traffic_key or '').partition('/')[2]:
-                    traffic = sum(tot(pl[n]) for n in group)
-                    src = 'profiles/' + tname + ':' + '+'.join(group)
+                    traffic = sum(tot(pl[n]) for n in real)
+                    src = 'profiles/' + tname + ':' + '+'.join(real)
                     break
         out = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': src,
