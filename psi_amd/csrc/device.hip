@@ -4616,19 +4616,20 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   const uint64_t SUB_BYTES = sub_env ? std::max<uint64_t>(1, strtoull(sub_env, nullptr, 10)) : (16ull << 20);
   std::vector<uint64_t> cut{ 0 };
   {
-    // piece sizes in bytes of bases: SUB/8, SUB/4, SUB/2, SUB ... SUB, SUB/2, SUB/4, SUB/8 -- small at both ends: what
-    // precedes the first transfer out and what follows the last transfer in (its kernels, its records' way out,
-    // their widening) is the part of the call nothing overlaps with
+    // piece sizes in bytes of bases: SUB/8, SUB/4, SUB/2, SUB ... SUB -- small at the start: what precedes the first
+    // transfer out is the one part of the call nothing overlaps with.  (Small pieces at the END as well -- so that the
+    // last kernels, the last records' way out and their widening are short -- were measured and do not pay: a
+    // sub-batch costs ~0.1 ms of launches and synchronisation whatever its size; tools/e2e_ab.py, three alternations
+    // on one box: 4.58 ms grow-only, 4.78-4.86 with tapered ends.)
     const uint64_t small = std::max<uint64_t>(1, SUB_BYTES / 8);
-    std::vector<uint64_t> head, tail;
+    std::vector<uint64_t> pieces;
     uint64_t left = n_bases;
-    for (uint64_t p = small; p < SUB_BYTES && left > 2 * p; p *= 2) { head.push_back(p); tail.push_back(p); left -= 2 * p; }
-    std::vector<uint64_t> pieces = head;
+    for (uint64_t p = small; p < SUB_BYTES && left > p; p *= 2) { pieces.push_back(p); left -= p; }
+    const size_t n_head = pieces.size();
     while (left > 0) { const uint64_t p = std::min(left, SUB_BYTES); pieces.push_back(p); left -= p; }
-    if (!pieces.empty() && pieces.back() < SUB_BYTES / 4 && pieces.size() > head.size() + 1) {     // no tiny piece in the middle
+    if (pieces.size() > n_head + 1 && pieces.back() < SUB_BYTES / 4) {      // no tiny tail
       const uint64_t t = pieces.back(); pieces.pop_back(); pieces.back() += t;
     }
-    pieces.insert(pieces.end(), tail.rbegin(), tail.rend());
     uint64_t target = 0;
     for (size_t pi = 0; pi < pieces.size() && cut.back() < n_reads; ++pi) {
       target += pieces[pi];
