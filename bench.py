@@ -373,13 +373,16 @@ def main():
             # N-free seed, the locus-table slot probed beside it (locus-table mode), one 16-byte row record
             # per row verified, two rank blocks per LF step still executed
             has_ftab = int(ix.view.ftab_len) not in (0, 0xFFFFFFFF)
+            # (an LF step needs one rank block when both interval ends share it -- the rule once the interval is small --
+            # and two otherwise: one per step is the lower bound counted here)
             loads = c['n_seeds_valid'] * ((1 if has_ftab else 0) + (1 if mode == 'locus-table' and res.get('probe_in_k1', True) else 0)) + \
-                c['n_rows_verified'] + 2 * c['n_lf_steps']
+                c['n_rows_verified'] + c['n_lf_steps']
             out['random_loads_per_launch'] = float(loads)
             out['random_loads_per_s'] = loads / (avg_ms * 1e-3)
             out['random_load_peak_per_s'] = random_load_peak(True)
             out['random_load_peak_source'] = 'psigpu_measure_random_loads (64-byte sector per quad, 4 GiB table), this run'
             out['lf_steps_per_launch'] = int(c['n_lf_steps'])
+            out['lf_steps_per_s'] = c['n_lf_steps'] / (avg_ms * 1e-3)
         if dom == 'k_kmer_probe':
             # secondary bound: divergent 16-byte loads per second against the rate
             # tools/rand_sector2.hip measures on this part for a table of this size

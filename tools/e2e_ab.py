@@ -1,3 +1,5 @@
+"""Host entry (psigpu_find_seeds, sort-unique) on the bench workload, alternating A/B settings on ONE box (the boxes of
+the pool differ by 10-15 % in link rate): 16-byte wire records against 32-byte records, pinned and pageable reads."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import numpy as np, psi_amd
@@ -19,9 +21,7 @@ def run(src, reps=10):
         assert L.psigpu_find_seeds(*calls[i % 2]) == 0; L.psigpu_free_hits(C.byref(hits))
     return (time.perf_counter() - t) / reps * 1e3
 for rnd in range(3):
-    for taper in ('0', '1', '2'):
-        os.environ['PSIGPU_TAPER'] = taper
-        for wire in ('1', '0'):
+    for wire in ('1', '0'):          # 16-byte wire records widened on the host / 32-byte records over the link
             if wire == '0': os.environ['PSIGPU_NO_WIRE16'] = '1'
             else: os.environ.pop('PSIGPU_NO_WIRE16', None)
-            print('round', rnd, 'taper', taper, 'wire16', wire, 'pinned %.2f ms' % run([(p[0].array, p[1].array) for p in pin]), 'pageable %.2f ms' % run(page, 6), flush=True)
+            print('round', rnd, 'wire16', wire, 'pinned %.2f ms' % run([(p[0].array, p[1].array) for p in pin]), 'pageable %.2f ms' % run(page, 6), flush=True)
