@@ -417,10 +417,14 @@ def main():
     if world > 1:
         ptr, n = finder.seeds_all_device(dev[0][0].data_ptr(), dev[0][1].data_ptr(), args.reads, dev[0][2], step=step,
                                          rec_offset=rec_offset, flags=psi_amd.ALL | psi_amd.SORT_UNIQUE, stream=stream)
+        mine = None
         if backend == 'nccl' and n:
             # the library's device buffer itself (no trip through the host), copied once because the gather outlives the call
-            mine = torch.as_tensor(psi_amd.DeviceHits(ptr, n), device='cuda').clone()
-        else:
+            try:
+                mine = torch.as_tensor(psi_amd.DeviceHits(ptr, n), device='cuda').clone()
+            except Exception as ex:            # (a torch build without the array interface: through the host, as before)
+                log('DeviceHits view failed (%s): gathering through a host copy' % ex)
+        if mine is None:
             mine = torch.from_numpy(finder.copy_hits(ptr, n).view(np.int64))
             if backend == 'nccl':
                 mine = mine.cuda()

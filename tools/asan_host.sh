@@ -8,7 +8,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="${1:-/tmp/psi_asan}"
 mkdir -p "$OUT"
 cd "$ROOT/psi_amd/csrc"
-for f in graph index pathsel capi_host hits; do
+for f in graph index pathsel capi_host hits refio; do
   g++ -O1 -g -std=c++17 -fPIC -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -c $f.cpp -o "$OUT/$f.o" &
 done
 wait
