@@ -441,6 +441,51 @@ def main():
                       'gb_per_s': allh.shape[0] * 32 / t_g / 1e9, 'backend': backend,
                       'sorted_by_read_id': bool((ids[1:] >= ids[:-1]).all().item()) if allh.shape[0] > 1 else True}
 
+    # the same gather through the library's own C++ entry (psigpu_gather_hits: RCCL loaded by the library, counts
+    # all-gathered, one send/recv per rank in one group).  It runs last and under a watchdog: no torch collective
+    # follows it, so if RCCL's second communicator could not come up on some rank the line is still printed.
+    cxx_stuck = False
+    if world > 1 and backend == 'nccl' and not os.environ.get('PSIGPU_BENCH_NO_CXX_GATHER'):
+        res_cxx = {}
+        ok = torch.tensor([1 if psi_amd.HitGather.available() else 0], device='cuda')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()):
+            idt = torch.zeros(128, dtype=torch.uint8, device='cuda')
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(psi_amd.HitGather.unique_id()), dtype=torch.uint8).cuda()
+            dist.broadcast(idt, src=0)
+            id_bytes = bytes(idt.cpu().numpy().tobytes())
+            dist.barrier()
+
+            def cxx_leg():
+                try:
+                    hg = psi_amd.HitGather(local_rank, id_bytes, rank, world)
+                    hg.gather(ptr, n, 0)                       # warm: the first transfer sets the links up
+                    t2 = time.perf_counter()
+                    d_all, n_all, counts = hg.gather(ptr, n, 0)
+                    res_cxx.update(ms=(time.perf_counter() - t2) * 1e3, records=int(n_all), counts=[int(x) for x in counts])
+                    if rank == 0 and n_all:
+                        ids = torch.as_tensor(psi_amd.DeviceHits(d_all, n_all), device='cuda')[:, 2]
+                        res_cxx['sorted_by_read_id'] = bool((ids[1:] >= ids[:-1]).all().item())
+                    hg.close()
+                except Exception as ex:
+                    res_cxx['error'] = str(ex)
+
+            import threading
+            th = threading.Thread(target=cxx_leg, daemon=True)
+            th.start()
+            th.join(timeout=90)
+            cxx_stuck = th.is_alive()
+            if cxx_stuck:
+                res_cxx = {'error': 'timed out'}
+        else:
+            res_cxx['error'] = 'RCCL could not be loaded by the library on some rank'
+        if gather is not None:
+            if 'ms' in res_cxx:
+                res_cxx['gb_per_s'] = res_cxx['records'] * 32 / (res_cxx['ms'] * 1e-3) / 1e9
+                res_cxx['same_records_as_torch_gather'] = res_cxx['records'] == gather['records']
+            gather['cxx'] = res_cxx
+
     if rank == 0:
         c = main_res['c']
         steps = args.steps
@@ -629,6 +674,9 @@ def main():
         if 'cpu_baseline' not in out:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
+    if cxx_stuck:                 # a thread is still inside RCCL: leave without tearing anything down under it
+        sys.stdout.flush()
+        os._exit(0)
     finder.close()
     if world > 1:
         dist.destroy_process_group()

@@ -419,6 +419,27 @@ int psigpu_get_counters(const psigpu_ctx* ctx, psigpu_counters* out);
 int psigpu_measure_random_loads(psigpu_ctx* ctx, uint64_t table_bytes, uint64_t n_loads, uint32_t quad_sectors,
                                 double* loads_per_s);
 
+/* ------------------------------------------------------------------------------------
+ * The gather of hit lists over RCCL / xGMI (BASELINE north_star: "RCCL over xGMI only to gather hit lists"): one
+ * process per GPU, reads sharded in contiguous ranges, every rank's device-resident records (psigpu_find_seeds_device
+ * with PSIGPU_SORT_UNIQUE) into the root's HBM in rank order -- which is the sorted chunk.  An all-gather of the counts,
+ * then one point-to-point transfer per rank inside one group.  RCCL is loaded on first use (psigpu_comm_available).
+ * No counterpart in the reference.  The unique id is made by one rank (psigpu_comm_unique_id) and handed to the others
+ * by the launcher (MPI, torch.distributed, a file); psigpu_comm_create is collective over the `world` ranks.
+ * ---------------------------------------------------------------------------------- */
+#define PSIGPU_COMM_ID_BYTES 128u
+typedef struct psigpu_comm psigpu_comm;
+int psigpu_comm_available(void);                                  /* 1: RCCL could be loaded */
+int psigpu_comm_unique_id(uint8_t id[PSIGPU_COMM_ID_BYTES]);
+psigpu_comm* psigpu_comm_create(int device, const uint8_t id[PSIGPU_COMM_ID_BYTES], int rank, int world);
+void psigpu_comm_destroy(psigpu_comm* comm);
+const char* psigpu_comm_last_error(const psigpu_comm* comm);      /* comm may be NULL: last create / id error on this thread */
+/* d_hits: `n` records in this rank's HBM.  On the root *d_all points at library-owned device memory (valid until the
+ * next gather on this communicator) holding *n_all records, rank 0's first; elsewhere NULL / 0.  counts (may be NULL):
+ * every rank's record count. */
+int psigpu_gather_hits(psigpu_comm* comm, const psigpu_hit* d_hits, uint64_t n, int root, const psigpu_hit** d_all,
+                       uint64_t* n_all, uint64_t* counts);
+
 uint32_t psigpu_abi_version(void);
 /* Text of the last host-side (graph / index) failure on this thread. */
 const char* psigpu_host_last_error(void);

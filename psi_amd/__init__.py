@@ -142,6 +142,12 @@ ABI = [
     ('psigpu_free_mems', None, [C.POINTER(Mems)]),
     ('psigpu_prepare', C.c_int, [_P, C.c_uint32]),
     ('psigpu_copy_hits', C.c_int, [_P, _P, _P, C.c_uint64]),
+    ('psigpu_comm_available', C.c_int, []),
+    ('psigpu_comm_unique_id', C.c_int, [_P]),
+    ('psigpu_comm_create', _P, [C.c_int, _P, C.c_int, C.c_int]),
+    ('psigpu_comm_destroy', None, [_P]),
+    ('psigpu_comm_last_error', C.c_char_p, [_P]),
+    ('psigpu_gather_hits', C.c_int, [_P, _P, C.c_uint64, C.c_int, C.POINTER(_P), _U64P, _P]),
     ('psigpu_host_alloc', _P, [C.c_uint64]),
     ('psigpu_host_free', None, [_P]),
 ]
@@ -652,6 +658,45 @@ class SeedFinder:
         if getattr(self, 'ctx', None) and _lib is not None:
             _lib.psigpu_destroy(self.ctx)
             self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+
+class HitGather:
+    """The gather of hit lists over RCCL / xGMI in C++ (psigpu_comm_*, psigpu_gather_hits): one per rank.  `id_bytes`:
+    the 128 bytes of HitGather.unique_id() made on one rank and handed to all (e.g. torch.distributed.broadcast)."""
+
+    @staticmethod
+    def available() -> bool:
+        return bool(lib().psigpu_comm_available())
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        if lib().psigpu_comm_unique_id(buf):
+            raise PsiGpuError('psigpu_comm_unique_id: ' + lib().psigpu_comm_last_error(None).decode())
+        return bytes(buf)
+
+    def __init__(self, device: int, id_bytes: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(id_bytes)
+        self.rank, self.world = rank, world
+        self.h = lib().psigpu_comm_create(device, buf, rank, world)
+        if not self.h:
+            raise PsiGpuError('psigpu_comm_create: ' + lib().psigpu_comm_last_error(None).decode())
+
+    def gather(self, d_ptr: int, n: int, root: int = 0):
+        """-> (device pointer of all records on the root | 0, total on the root | 0, every rank's count)"""
+        d_all, n_all = C.c_void_p(), C.c_uint64()
+        counts = np.zeros(self.world, np.uint64)
+        if lib().psigpu_gather_hits(self.h, d_ptr, n, root, C.byref(d_all), C.byref(n_all), _ptr(counts)):
+            raise PsiGpuError('psigpu_gather_hits: ' + lib().psigpu_comm_last_error(self.h).decode())
+        return d_all.value or 0, n_all.value, counts
+
+    def close(self):
+        if getattr(self, 'h', None) and _lib is not None:
+            _lib.psigpu_comm_destroy(self.h)
+            self.h = None
 
     def __del__(self):
         self.close()

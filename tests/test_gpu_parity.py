@@ -571,6 +571,33 @@ def test_device_hits_as_a_torch_tensor():
     f.close()
 
 
+def test_cxx_gather_of_hit_lists_one_rank():
+    """psigpu_gather_hits (C++ over RCCL, loaded by the library): a world of one rank -- the communicator comes up,
+    the counts are all-gathered, the root's own records land in the gathered buffer unchanged, twice (the buffer is
+    reused) and with an empty list."""
+    import torch
+    g, reads = _x_case()
+    f = psi_amd.SeedFinder(g, 12)
+    f.create_path_index(1)
+    bases, off = psi_amd.pack_reads(reads[:300])
+    d_bases = torch.from_numpy(bases).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    ptr, n = f.seeds_all_device(d_bases.data_ptr(), d_off.data_ptr(), 300, len(bases), step=5, flags=psi_amd.ALL | psi_amd.SORT_UNIQUE)
+    want = f.copy_hits(ptr, n)
+    assert psi_amd.HitGather.available()
+    hg = psi_amd.HitGather(0, psi_amd.HitGather.unique_id(), 0, 1)
+    for _ in range(2):
+        d_all, n_all, counts = hg.gather(ptr, n, 0)
+        assert n_all == n and list(counts) == [n] and d_all not in (0, ptr)
+        assert _eq(f.copy_hits(d_all, n_all), want)
+    d_all, n_all, counts = hg.gather(0, 0, 0)
+    assert n_all == 0 and list(counts) == [0]
+    with pytest.raises(psi_amd.PsiGpuError):
+        hg.gather(ptr, n, 3)                        # no such root
+    hg.close()
+    f.close()
+
+
 def test_device_resident_entry_matches_host_entry():
     import torch
     sg = synth.snv_graph(200_000, 6000, seed=8)
