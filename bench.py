@@ -41,7 +41,7 @@ PROFILE_ROUND = 'r03'
 TRAFFIC_FILES = {'kmer-table': '%s_k_traffic.json', 'locus-table': '%s_l_traffic.json', 'traverse': '%s_t_traffic.json',
                  # the fm-lf series (tools/profile.sh f1 / f2 / f3): locus-table mode with the LF kernels doing the work
                  'fm-lf/after_ftab': '%s_f1_traffic.json', 'fm-lf/no_ftab': '%s_f2_traffic.json',
-                 'fm-lf/sa32': '%s_f3_traffic.json'}
+                 'fm-lf/sa32': '%s_f3_traffic.json', 'traverse/fm': '%s_t2_traffic.json'}
 
 
 def log(*a):
@@ -65,7 +65,7 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
         if c['n_path_kmers']:
             # k-mer table mode: K2 is a stream -- 16 bytes of probe results + 8 bytes of (read, offset)
             # in per seed, one 32-byte record out per hit (positions were inline in the slots)
-            return 24.0 * c['n_seeds'] + 32.0 * c['n_hits']
+            return 24.0 * c['n_seeds'] + 32.0 * (c['n_hits_on_path'] + c.get('n_hits_table', 0))      # (the traverser writes its own records)
         # SA-order sampling at rate s: expected s-1 LF steps (one block each) + the 4-byte
         # sample, two 64-byte segment-table probes, one 32-byte record out; hits that come from the
         # locus k-mer table: one 16-byte entry in, one 32-byte record out
@@ -294,7 +294,8 @@ def main():
         for i in range(warmup):
             if L.psigpu_find_seeds_device(*calls[i % nb]):
                 raise RuntimeError(L.psigpu_last_error(f.ctx).decode())
-        probe_name = 'k_kmer_probe' if mode == 'kmer-table' else 'k_lkt_probe'
+        # (the on-path phase is a probe of a k-mer table in the default mode, and in traverse mode unless the FM route is asked for)
+        probe_name = 'k_kmer_probe' if (mode == 'kmer-table' or (mode == 'traverse' and c0['n_path_kmers'])) else 'k_lkt_probe'
         kern = {'k_fm_search': 0.0, 'k_fm_locate': 0.0, 'k_traverse': 0.0, 'k_table_insert': 0.0, probe_name: 0.0,
                 'k_seed_pack': 0.0}
         seeds = hits = 0
@@ -525,7 +526,7 @@ def main():
                 'lf_steps_per_step': int(c['n_lf_steps']), 'rows_verified_per_step': int(c['n_rows_verified']),
                 'parallelism': 'reads sharded x%d, index replicated' % world,
             },
-            'roofline': roofline_of(main_res, args.mode, traffic_key=('fm-lf/' + args.series) if args.series else None),
+            'roofline': roofline_of(main_res, args.mode, traffic_key=(('traverse/' if args.mode == 'traverse' else 'fm-lf/') + args.series) if args.series else None),
         }
         if args.tune or args.series:
             out['config']['tune'] = args.tune
@@ -611,12 +612,29 @@ def main():
         for m, res in by_mode.items():
             e = {'ms_per_step': res['elapsed'] / res['steps'] * 1e3, 'seeds_per_s': res['seeds'] / res['elapsed'],
                  'hits_per_step': int(res['c']['n_hits']), 'dominant': roofline_of(res, m)}
-            if m != 'kmer-table':
+            if m == 'locus-table':
                 e['k_fm_search'] = roofline_of(res, m, 'k_fm_search')
                 e['k_fm_locate'] = roofline_of(res, m, 'k_fm_locate')
             if m == 'traverse':
+                # paths: one probe of the table of their k-mers + the emit stream; loci: the chunk's seed table, the traverser
+                e['k_kmer_probe'] = roofline_of(res, m, 'k_kmer_probe')
+                e['k_fm_locate'] = roofline_of(res, m, 'k_fm_locate')
+                e['k_table_insert'] = roofline_of(res, m, 'k_table_insert')
                 e['k_traverse'] = roofline_of(res, m, 'k_traverse')
             rbm[m] = e
+        # traverse mode with the FM index answering the on-path phase: the reference's scheme as written
+        f2 = psi_amd.SeedFinder(g, k, device=local_rank, mode='traverse')
+        f2.set_tuning(psi_amd.TUNE_NO_PATH_TABLE)
+        f2.set_path_index(px)
+        f2.prepare()
+        res = time_mode(f2, 10, 3, 'traverse', False)
+        f2.close()
+        rbm['traverse']['fm_route'] = {
+            'ms_per_step': res['elapsed'] / res['steps'] * 1e3, 'seeds_per_s': res['seeds'] / res['elapsed'],
+            'hits_per_step': int(res['c']['n_hits']), 'tune': psi_amd.TUNE_NO_PATH_TABLE,
+            'k_fm_search': roofline_of(res, 'traverse', 'k_fm_search', traffic_key='traverse/fm'),
+            'k_fm_locate': roofline_of(res, 'traverse', 'k_fm_locate', traffic_key='traverse/fm'),
+            'k_traverse': roofline_of(res, 'traverse', 'k_traverse', traffic_key='traverse/fm')}
         # ---- the LF / rank kernels doing the work (north_star: "FM-index backward-search (LF-mapping via rank
         # over the path-set BWT)"): in the modes above the interval table + the rows' records answer nearly every
         # seed without an LF step.  Three points in locus-table mode: (after_ftab) the interval table, then every

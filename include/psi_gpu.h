@@ -286,8 +286,11 @@ int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr);
  *     the device.  Falls back to LOCUS_TABLE, then TRAVERSE, when the tables do not fit.
  *   PSIGPU_MODE_LOCUS_TABLE: seeds_on_paths by FM-index backward search + locate (K1 / K2),
  *     seeds_off_paths from the table of the starting loci's k-walks.
- *   PSIGPU_MODE_TRAVERSE: the reference's scheme -- FM index, and every starting locus traversed
- *     for every chunk, pruned by the chunk's seeds.
+ *   PSIGPU_MODE_TRAVERSE: nothing about the starting loci is tabulated (graphs with too many k-walks per
+ *     locus): every starting locus is traversed for every chunk, pruned by the chunk's seeds, as in the
+ *     reference.  The on-path phase is one probe of a table of the PATHS' k-mers (one entry per path position
+ *     whatever the graph looks like) when that applies (sa_rate 1, text on the device, k <= 31) and fits, else
+ *     FM-index backward search + locate -- the reference's scheme as written; PSIGPU_TUNE_NO_PATH_TABLE: always.
  * Loci with more than `walk_cap` k-walks (dense, high-degree regions) are left out of the tables
  * and traversed per chunk in every mode.  walk_cap = 0 is the default policy: 256 walks, then
  * further enumeration passes with larger caps (2^16, 2^22) while only few loci are over and a
@@ -306,6 +309,8 @@ int psigpu_set_query_mode(psigpu_ctx* ctx, uint32_t mode, uint32_t walk_cap);
 #define PSIGPU_TUNE_NO_VERIFY 2u     /* every base of a seed by an LF step (fmindex.hpp:851-869 as written): small intervals
                                         are not finished by comparing the rows with the text */
 #define PSIGPU_TUNE_NO_ROWRECS 4u    /* no per-row records (SaRec, located suffix array): locate through SA + segment table */
+#define PSIGPU_TUNE_NO_PATH_TABLE 8u /* traverse mode: the FM index answers the on-path phase (the reference's scheme as written)
+                                        instead of the table of the paths' k-mers */
 int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags);
 
 /* Builds the tables of the current query mode for seed length k now (index load time) instead of

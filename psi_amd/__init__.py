@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('PSI_AMD_LIB') or os.path.join(_HERE, 'libpsi_gpu.so')
 
 ALL, ON_PATHS, OFF_PATHS, SORT_UNIQUE = 3, 1, 2, 4
 MAX_SEED_LEN = 63
-TUNE_NO_DIRECT, TUNE_NO_VERIFY, TUNE_NO_ROWRECS = 1, 2, 4
+TUNE_NO_DIRECT, TUNE_NO_VERIFY, TUNE_NO_ROWRECS, TUNE_NO_PATH_TABLE = 1, 2, 4, 8
 
 
 class PsiGpuError(RuntimeError):
@@ -491,7 +491,8 @@ class SeedFinder:
                  mode: Optional[str] = None, walk_cap: Optional[int] = None):
         """`mode`: 'kmer-table' (default: path k-mers and the starting loci's k-walks tabulated once
         in HBM, one probe per seed), 'locus-table' (FM index on the paths, table for the loci) or
-        'traverse' (FM index + every starting locus traversed per chunk, as the reference does);
+        'traverse' (every starting locus traversed per chunk, as the reference does; paths by a table of their
+        k-mers, or by the FM index: TUNE_NO_PATH_TABLE);
         `walk_cap`: loci with more k-walks than this stay with the traverser (0 = 256)."""
         if mode is None:
             mode = os.environ.get('PSI_AMD_MODE', 'kmer-table')
@@ -512,6 +513,8 @@ class SeedFinder:
         if gocc_threshold:
             self._chk(lib().psigpu_set_gocc_threshold(self.ctx, gocc_threshold))
         self.set_query_mode(mode, walk_cap)
+        if os.environ.get('PSI_AMD_TUNE'):                   # (tests: a measurement switch on every finder)
+            self.set_tuning(int(os.environ['PSI_AMD_TUNE']))
 
     def set_query_mode(self, mode: str, walk_cap: int = 0) -> None:
         self._chk(lib().psigpu_set_query_mode(self.ctx, _MODES[mode], walk_cap))

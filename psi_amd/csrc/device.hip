@@ -2959,6 +2959,7 @@ int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags)
   if (!ctx) return PSIGPU_ERR_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return PSIGPU_ERR_DEVICE;
   if ((flags ^ ctx->tune) & PSIGPU_TUNE_NO_ROWRECS) drop_row_records(ctx);      // made (or not) by the next FM query
+  if (((flags ^ ctx->tune) & PSIGPU_TUNE_NO_PATH_TABLE) && ctx->query_mode == PSIGPU_MODE_TRAVERSE) lkt_release(ctx);
   ctx->tune = flags;
   return PSIGPU_OK;
 }
@@ -3416,6 +3417,29 @@ static int ensure_lkt(psigpu_ctx* ctx, uint32_t k, const GraphView& gv)
     uint32_t cap = 0;
   };
   std::string why;
+  if (ctx->query_mode == PSIGPU_MODE_TRAVERSE) {
+    // Traverse mode: nothing about the LOCI is tabulated (graphs with too many k-walks per locus) -- the paths'
+    // k-mers still are, one entry per path position whatever the graph looks like, so that the on-path phase
+    // is one probe per seed as in the k-mer table mode and the traverser does the rest.  When the table does not
+    // apply or fit, the FM index answers (PSIGPU_TUNE_NO_PATH_TABLE: always).
+    spill_a.drop(); spill_b.drop();
+    if (ctx->sa_rate == 1 && ctx->p0().have_text4 && ctx->n_paths && !(ctx->tune & PSIGPU_TUNE_NO_PATH_TABLE)) {
+      int st = build_kt_direct(ctx, k, nullptr, nullptr, 0, d_dropped);
+      if (st == PSIGPU_ERR_NOMEM) {
+        (void)hipGetLastError();
+        ctx->kt_ht.release(); ctx->kt_ext.release(); ctx->kt_onpos.release();
+        ctx->lkt_note = "k-mer table of the paths does not fit the device: path k-mers stay with the FM index";
+        st = PSIGPU_OK;
+      }
+      if (st != PSIGPU_OK) return st;
+    }
+    HIPCHK(ctx, hipEventRecord(e1, nullptr));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    (void)hipEventElapsedTime(&ctx->lkt_build_ms, e0, e1);
+    ctx->lkt_n_res = n_loci;
+    ctx->lkt_ready = true;
+    return PSIGPU_OK;
+  }
   auto enumerate = [&](Pass& ps, const uint2* roots, uint64_t n_roots, uint32_t cap, uint64_t chunk_budget, bool retry) -> int {
 #define PASS_TRY(call)                                                                         \
   do {                                                                                         \
@@ -3684,7 +3708,11 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   // The seed table and the prefix bitmap are sized from an upper bound on the seed count
   // (every read of length L gives at most L / step + 1 seeds), so their reset can start now, on
   // the second stream, beside seeding -- it depends on nothing.
-  static const bool serial = getenv("PSIGPU_SERIAL") != nullptr;   // profiling: no overlap
+  // One stream: the traverser's kernels behind K1 / K2.  Running them beside each other on a second stream
+  // (PSIGPU_OVERLAP=1, the arrangement of rounds 1-2) buys nothing on this part -- both sides wait for the same
+  // random-access path: 1.91 ms against 1.93 per step in traverse mode -- and makes every event-bracketed kernel
+  // time include the other stream's kernels.
+  static const bool serial = getenv("PSIGPU_OVERLAP") == nullptr;
   // the second stream is made when a call first needs it (traverse mode): the runtime multiplexes
   // streams onto four hardware queues, and two busy streams on one queue serialise
   if (!ctx->stream2 && !serial && (flags & PSIGPU_OFF_PATHS) && ctx->n_loci)
@@ -3696,15 +3724,18 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   // seeds of 32..63 bases are two words: answered by the FM index and the query-time traverser (the reference's
   // scheme); the tables of the other modes hold one-word k-mers
   const bool wide = k > PSIGPU_MAX_TABLE_SEED_LEN;
-  const bool want_kt = ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->index_k == k && n_reads && !wide &&
-                       (want_off || ((flags & PSIGPU_ON_PATHS) && ctx->n_paths));
+  const bool trav_mode = ctx->query_mode == PSIGPU_MODE_TRAVERSE;     // (its table holds the paths' k-mers only: ensure_lkt)
+  const bool want_kt = ctx->index_k == k && n_reads && !wide &&
+                       ((ctx->query_mode == PSIGPU_MODE_KMER_TABLE && (want_off || ((flags & PSIGPU_ON_PATHS) && ctx->n_paths))) ||
+                        (trav_mode && (flags & PSIGPU_ON_PATHS) && ctx->n_paths && ctx->sa_rate == 1 &&
+                         !(ctx->tune & PSIGPU_TUNE_NO_PATH_TABLE)));
   bool use_lkt = false, use_kt = false;
-  if (((want_off && ctx->query_mode != PSIGPU_MODE_TRAVERSE) || want_kt) && !wide) {
+  if (((want_off && !trav_mode) || want_kt) && !wide) {
     const bool had = (ctx->lkt_ready || ctx->lkt_failed) && ctx->lkt_k == k;
     int st = ensure_lkt(ctx, k, gv);
     if (st != PSIGPU_OK) return st;
-    use_lkt = ctx->lkt_ready && want_off;
-    use_kt = ctx->lkt_ready && ctx->kt_ready;
+    use_lkt = ctx->lkt_ready && want_off && !trav_mode;
+    use_kt = ctx->lkt_ready && ctx->kt_ready && want_kt;
     if (!had) EVREC(0, stream);      // a table build just ended: do not time it
   }
   // the per-row records of the FM search / locate kernels, the first time an FM mode answers on-path seeds
@@ -3970,7 +4001,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         if (kprobe) {
           KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
           k_kmer_probe<<<grid, 256, 0, stream>>>(kt, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave,
-                                                 (flags & PSIGPU_ON_PATHS) != 0, want_off, thr, ctx->w_seedres.as<uint4>(),
+                                                 (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr, ctx->w_seedres.as<uint4>(),
                                                  ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), ctr);
           probed = true;
         } else if (on_paths) {
@@ -4361,8 +4392,9 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k)
   if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
   if (ctx->index_k != k || k > PSIGPU_MAX_TABLE_SEED_LEN) return PSIGPU_OK;   // tables exist for the index's seed length only, and for one-word seeds
   int st = PSIGPU_OK;
-  if (ctx->query_mode != PSIGPU_MODE_TRAVERSE &&                           // (nothing is tabulated in traverse mode)
-      !(ctx->n_loci == 0 && !(ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->n_paths)))
+  if (ctx->query_mode == PSIGPU_MODE_TRAVERSE) {                           // (only the paths' k-mers are tabulated in traverse mode)
+    if (ctx->n_paths && ctx->sa_rate == 1 && !(ctx->tune & PSIGPU_TUNE_NO_PATH_TABLE)) st = ensure_lkt(ctx, k, graph_view(ctx));
+  } else if (!(ctx->n_loci == 0 && !(ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->n_paths)))
     st = ensure_lkt(ctx, k, graph_view(ctx));
   // the FM modes' per-row records (the k-mer table mode never reads them)
   if (st == PSIGPU_OK && !(ctx->lkt_ready && ctx->kt_ready) && ctx->n_paths && ctx->fm_ok && !ctx->rows_tried) {

@@ -2,6 +2,7 @@
 golden fixtures.  Bit-exact: hit sets are integer records and must be identical.
 Run with `-m gpu` on an MI355X."""
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -24,7 +25,7 @@ def _eq(a, b):
 
 
 # Every test runs in every query mode: seeds answered from the k-mer table (the default), FM index
-# + locus table, FM index + query-time traverser (the reference's scheme), and the k-mer table with
+# + locus table, query-time traverser (the reference's scheme; paths by their k-mer table or the FM index), and the k-mer table with
 # a walk cap of 1 so that every branching locus is left to the traverser and all three
 # mechanisms contribute to one hit set.
 @pytest.fixture(autouse=True, params=['kmer-table', 'locus-table', 'traverse', 'kmer-table-cap1'])
@@ -32,6 +33,12 @@ def query_mode(request, monkeypatch):
     mode = request.param
     monkeypatch.setenv('PSI_AMD_MODE', mode.replace('-cap1', ''))
     monkeypatch.setenv('PSI_AMD_WALK_CAP', '1' if mode.endswith('-cap1') else '0')
+    # traverse mode answers the on-path phase from a table of the paths' k-mers, or (TUNE_NO_PATH_TABLE) from the
+    # FM index as the reference does: every other test takes the second route
+    if mode == 'traverse' and zlib.crc32(request.node.nodeid.encode()) & 1:
+        monkeypatch.setenv('PSI_AMD_TUNE', str(psi_amd.TUNE_NO_PATH_TABLE))
+    else:
+        monkeypatch.delenv('PSI_AMD_TUNE', raising=False)
     return mode
 
 
@@ -362,6 +369,7 @@ def test_query_modes_split_the_work(query_mode):
     n_walks = None
     f = psi_amd.SeedFinder(g, k)
     f.set_path_index(px)
+    f.set_tuning(0)
     for rep in range(2):                        # second call reuses the tables
         got = psi_amd.sort_unique(f.seeds_all((bases, off), step=5))
         assert _eq(got, want)
@@ -372,13 +380,20 @@ def test_query_modes_split_the_work(query_mode):
             assert 0 < c['n_loci_traversed'] < c['n_loci'] and c['n_locus_kmers'] == c['n_loci'] - c['n_loci_traversed']
         else:
             assert c['n_locus_kmers'] >= c['n_loci'] and c['n_loci_traversed'] == 0 and c['traverse_launches'] == 0
-        if query_mode.startswith('kmer-table'):
+        if query_mode.startswith('kmer-table') or query_mode == 'traverse':      # (traverse mode: a table of the paths' k-mers only)
             assert c['n_path_kmers'] > 0 and c['search_launches'] == 0 and c['n_lf_steps'] == 0
         else:
             assert c['n_path_kmers'] == 0 and c['search_launches'] >= 1
         if n_walks is not None:
             assert c['n_locus_kmers'] == n_walks
         n_walks = c['n_locus_kmers']
+    if query_mode == 'traverse':
+        # the reference's scheme as written -- FM index for the on-path phase -- on request; and back
+        for flags, table in ((psi_amd.TUNE_NO_PATH_TABLE, False), (0, True)):
+            f.set_tuning(flags)
+            assert _eq(psi_amd.sort_unique(f.seeds_all((bases, off), step=5)), want)
+            c = f.counters()
+            assert (c['n_path_kmers'] > 0) == table and (c['search_launches'] == 0) == table and c['n_loci_traversed'] == c['n_loci']
     # the phases alone, and switching the mode on a live finder
     assert _eq(psi_amd.sort_unique(f.seeds_on_paths((bases, off), step=5)), want_on)
     a = psi_amd.sort_unique(f.seeds_off_paths((bases, off), step=5))
@@ -672,7 +687,7 @@ def test_query_modes_agree_at_full_size(query_mode):
         res[mode] = f.seeds_all((bases, off), step=k, sort_unique=True)
         c = f.counters()
         assert c['n_seeds'] == 7_000_000
-        assert (c['n_path_kmers'] > 0) == (mode == 'kmer-table')
+        assert (c['n_path_kmers'] > 0) == (mode != 'locus-table')      # (traverse mode: the paths' k-mers, not the loci's)
         assert (c['n_loci_traversed'] > 0) == (mode == 'traverse')
         f.close()
     assert _eq(res['kmer-table'], res['traverse']) and _eq(res['locus-table'], res['traverse'])

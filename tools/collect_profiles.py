@@ -5,7 +5,7 @@ import csv, glob, json, sys
 
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else 'r03'
-    for tag, mode in (('k', 'kmer_table'), ('l', 'locus_table'), ('t', 'traverse'),
+    for tag, mode in (('k', 'kmer_table'), ('l', 'locus_table'), ('t', 'traverse'), ('t2', 'traverse_fm_route'),
                       ('f1', 'fm_lf_after_ftab'), ('f2', 'fm_lf_no_ftab'), ('f3', 'fm_lf_sa32')):
         d = 'gpurun_out/prof_%s' % tag
         try:

@@ -41,14 +41,21 @@ for f in glob.glob(out+"/stats/**/*kernel_stats.csv", recursive=True):
 # traffic per launch (bytes): FETCH_SIZE / WRITE_SIZE are KiB; random 64-B sector reads are counted
 # exactly, wide coalesced streams at half (profiles/r01_fetch_size_calibration.txt)
 import json
+# per STEP (one call of the pipeline = one k_seed_pack dispatch), not per dispatch: the traverser is launched
+# twice in a step -- the loci, then the few items of its spill queue -- and an average over the dispatches halves it
+calls={}
+for k,c,v,n in rows:
+    if k.startswith("void k_seed_pack") or k.startswith("k_seed_pack"): calls[c]=n
 tr={}
 for k,c,v,n in rows:
     if c in ("FETCH_SIZE","WRITE_SIZE"):
-        tr.setdefault(k,{})[c.lower()+"_bytes"]=v*1024
+        per=max(1.0, round(n/calls[c])) if calls.get(c) else 1.0
+        tr.setdefault(k,{})[c.lower()+"_bytes"]=v*1024*per
+        if per!=1.0: tr[k]["dispatches_per_step"]=per
 mode="kmer-table"
 a="$ARGS".split()
 if "--mode" in a: mode=a[a.index("--mode")+1]
 series=""
 if "--series" in a: series=a[a.index("--series")+1]
-json.dump({"args":"$ARGS","mode":mode,"series":series,"per_launch":tr}, open(out+"/traffic.json","w"), indent=1)
+json.dump({"args":"$ARGS","mode":mode,"series":series,"unit":"bytes per step (FETCH_SIZE / WRITE_SIZE x 1024, summed over the dispatches of a step)","per_launch":tr}, open(out+"/traffic.json","w"), indent=1)
 PY
