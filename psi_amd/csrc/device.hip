@@ -28,7 +28,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <execinfo.h>
 #include <memory>
+#include <signal.h>
+#include <unistd.h>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -2791,7 +2794,8 @@ struct psigpu_ctx {
   hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
   // the pipeline's transfers, each direction on a copy engine of its own (see pipeline_init)
   struct EngineCopy {
-    bool ok = false, hsa_up = false;             // hsa_up: this context holds a reference on the HSA runtime
+    bool ok = false;
+    int n_sig = 0;                               // signals taken from the process-wide pool: sig_in[0..1], then sig_out[0..1]
     hsa_agent_t gpu{}, cpu{};
     uint32_t eng_in = 0, eng_out = 0;            // hsa_amd_sdma_engine_id_t bits
     hsa_signal_t sig_in[2]{}, sig_out[2]{};      // per slot: 1 while the slot's transfer is in flight
@@ -2800,6 +2804,35 @@ struct psigpu_ctx {
 };
 
 static thread_local std::string g_create_err;
+
+// The host entry's HSA objects live as long as the process: one reference on the runtime (HIP holds its own), and the
+// completion signals of the engine copies are handed from context to context instead of being destroyed with one --
+// ROCr may still be retiring a copy on its own thread when the waiter that saw the signal reach 0 is already
+// tearing the context down (a finder closed right after its last chunk, under load: silent SIGSEGVs and
+// "double free or corruption" in one of every ~8 fuzz processes sharing a box, none since).
+namespace {
+struct HsaGlobals {
+  std::mutex mu;
+  bool tried = false, up = false;
+  std::vector<hsa_signal_t> idle;
+  bool init()
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!tried) { tried = true; up = hsa_init() == HSA_STATUS_SUCCESS; }
+    return up;
+  }
+  bool take(hsa_signal_t* sg)
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!idle.empty()) { *sg = idle.back(); idle.pop_back(); hsa_signal_store_relaxed(*sg, 0); return true; }
+    }
+    return hsa_signal_create(0, 0, nullptr, sg) == HSA_STATUS_SUCCESS;
+  }
+  void give(hsa_signal_t sg) { std::lock_guard<std::mutex> lk(mu); idle.push_back(sg); }
+};
+HsaGlobals g_hsa;
+}  // namespace
 
 // Pinned host buffers for returned hits are recycled process-wide: hipHostMalloc of a few
 // hundred MB costs tens of milliseconds, a chunk loop would pay it every call.
@@ -2860,8 +2893,33 @@ static int upload(psigpu_ctx* ctx, DevBuf& b, const T* src, uint64_t n, uint64_t
 
 extern "C" {
 
+// PSIGPU_SEGV_TRACE=1 (debugging aid): a backtrace of the faulting thread on stderr before the process dies
+static void segv_trace(int sig)
+{
+  signal(sig, SIG_DFL);
+  alarm(5);                                       // (a handler stuck behind a lock the dying thread holds must not hang the process)
+  void* frames[64];
+  const int nf = backtrace(frames, 64);
+  static const char msg[] = "[psigpu] fatal signal, backtrace of the faulting thread:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  backtrace_symbols_fd(frames, nf, 2);
+  raise(sig);
+}
+
 psigpu_ctx* psigpu_create(int device)
 {
+  static const bool traced = [] {
+    if (!getenv("PSIGPU_SEGV_TRACE")) return false;
+    static char alt[1 << 16];
+    { void* warm[4]; (void)backtrace(warm, 4); }      // (the first call loads libgcc: not from inside a handler)
+    stack_t ss{}; ss.ss_sp = alt; ss.ss_size = sizeof alt;
+    (void)sigaltstack(&ss, nullptr);
+    struct sigaction sa{};
+    sa.sa_handler = segv_trace; sa.sa_flags = SA_ONSTACK;
+    for (int sg : { SIGSEGV, SIGBUS, SIGABRT, SIGFPE }) (void)sigaction(sg, &sa, nullptr);
+    return true;
+  }();
+  (void)traced;
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -2907,8 +2965,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
     if (sl.out_done) (void)hipEventDestroy(sl.out_done);
   }
   for (hipStream_t st : { ctx->s_in, ctx->s_comp, ctx->s_out }) if (st) (void)hipStreamDestroy(st);
-  if (ctx->ec.ok) for (int i = 0; i < 2; ++i) { (void)hsa_signal_destroy(ctx->ec.sig_in[i]); (void)hsa_signal_destroy(ctx->ec.sig_out[i]); }
-  if (ctx->ec.hsa_up) (void)hsa_shut_down();
+  for (int i = 0; i < ctx->ec.n_sig; ++i) g_hsa.give(i < 2 ? ctx->ec.sig_in[i] : ctx->ec.sig_out[i - 2]);      // (kept for the next context)
   if (ctx->have_events) for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -4490,8 +4547,12 @@ namespace {
 struct Widener {
   struct Job { const uint4* src; psigpu_hit* dst; uint64_t n, id_base, rec_base; int slot; };
   std::vector<Job> jobs;
-  std::atomic<size_t> posted{ 0 }, ready{ 0 }, finished{ 0 };
-  std::atomic<uint64_t> parts{ 0 };
+  std::atomic<size_t> posted{ 0 }, ready{ 0 };
+  // slices done, PER JOB: thread 0 may be a job ahead of a thread that was descheduled inside the job before, so a
+  // count over all jobs reaches "T x (j + 1)" while a slice of job j is still being read (seen under three fuzz
+  // processes on one box: a record of the sub-batch that reused the landing buffer)
+  std::unique_ptr<std::atomic<uint32_t>[]> parts;
+  size_t checked = 0;                           // caller's thread only: jobs [0, checked) are known to be finished
   std::atomic<bool> stop{ false };
   std::vector<std::thread> th;
   std::function<void(int)> wait_copy;           // blocks until the slot's device-to-host transfer is complete
@@ -4500,10 +4561,17 @@ struct Widener {
   void start(unsigned n_threads, size_t n_jobs, std::function<void(int)> wc)
   {
     T = n_threads; jobs.resize(n_jobs); wait_copy = std::move(wc);
+    parts.reset(new std::atomic<uint32_t>[n_jobs ? n_jobs : 1]);
+    for (size_t j = 0; j < n_jobs; ++j) parts[j].store(0, std::memory_order_relaxed);
     for (unsigned t = 0; t < T; ++t) th.emplace_back([this, t] { run(t); });
   }
   void post(size_t j, const Job& job) { jobs[j] = job; posted.store(j + 1, std::memory_order_release); }
-  void wait_finished(size_t upto) const { while (finished.load(std::memory_order_acquire) < upto) std::this_thread::yield(); }
+  // every slice of jobs [0, upto) has been widened (called by the thread that posts)
+  void wait_finished(size_t upto)
+  {
+    for (; checked < upto; ++checked)
+      while (parts[checked].load(std::memory_order_acquire) < T) std::this_thread::yield();
+  }
   void run(unsigned t)
   {
     for (size_t j = 0; j < jobs.size(); ++j) {
@@ -4516,7 +4584,7 @@ struct Widener {
         const uint4 w = job.src[i];
         job.dst[i] = psigpu_hit{ job.id_base + w.x, w.y, job.rec_base + w.z, w.w };
       }
-      if (parts.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint64_t)T * (j + 1)) finished.store(j + 1, std::memory_order_release);
+      parts[j].fetch_add(1, std::memory_order_acq_rel);
     }
   }
   ~Widener() { stop = true; for (auto& x : th) if (x.joinable()) x.join(); }
@@ -4547,8 +4615,7 @@ static void engine_copy_init(psigpu_ctx* ctx)
   psigpu_ctx::EngineCopy& ec = ctx->ec;
   ec.ok = false;
   if (getenv("PSIGPU_NO_ENGINE_COPY")) return;
-  if (hsa_init() != HSA_STATUS_SUCCESS) return;
-  ec.hsa_up = true;                                           // released in psigpu_destroy (hsa_init is counted)
+  if (!g_hsa.init()) return;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return;
   std::vector<hsa_agent_t> agents;
@@ -4575,9 +4642,10 @@ static void engine_copy_init(psigpu_ctx* ctx)
   uint32_t rest = mask_out & ~ec.eng_in;
   if (rest == 0) return;                                      // a single engine: nothing to separate
   ec.eng_out = rest & (~rest + 1);
-  for (int i = 0; i < 2; ++i)
-    if (hsa_signal_create(0, 0, nullptr, &ec.sig_in[i]) != HSA_STATUS_SUCCESS ||
-        hsa_signal_create(0, 0, nullptr, &ec.sig_out[i]) != HSA_STATUS_SUCCESS) return;
+  for (int i = 0; i < 4; ++i) {
+    if (!g_hsa.take(i < 2 ? &ec.sig_in[i] : &ec.sig_out[i - 2])) return;
+    ec.n_sig = i + 1;
+  }
   ec.ok = true;
   if (getenv("PSIGPU_TRACE")) fprintf(stderr, "[psigpu] copy engines: in 0x%x of 0x%x, out 0x%x of 0x%x\n", ec.eng_in, mask_in, ec.eng_out, mask_out);
 }

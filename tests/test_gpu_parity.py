@@ -1119,6 +1119,34 @@ def test_host_entry_pipeline_equals_one_batch(monkeypatch, sub_bytes, pinned):
     f.close()
 
 
+@pytest.mark.parametrize('query_mode', ['kmer-table', 'locus-table'], indirect=True)
+def test_host_entry_with_the_host_oversubscribed(monkeypatch, query_mode):
+    """The host entry's helper threads (widening of the 16-byte wire records, staging of pageable reads) next to
+    as many spinning processes as the box has cores, one read per sub-batch: a thread descheduled in the middle
+    of a sub-batch must not let its landing buffer be reused (found by three fuzz processes sharing a box)."""
+    import subprocess
+    import sys
+    g, reads = _x_case()
+    k, step = 21, 3
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(2, rng_seed=3)
+    rr = reads[:120]
+    monkeypatch.setenv('PSIGPU_SUB_BYTES', str(1 << 30))
+    want = f.seeds_all(rr, step=step, rec_offset=7, sort_unique=True)
+    monkeypatch.setenv('PSIGPU_SUB_BYTES', '16')
+    burners = [subprocess.Popen([sys.executable, '-c', 'while True: pass']) for _ in range(os.cpu_count() or 8)]
+    try:
+        for _ in range(3):
+            assert _eq(f.seeds_all(rr, step=step, rec_offset=7, sort_unique=True), want)
+            assert _eq(psi_amd.sort_unique(f.seeds_all(rr, step=step, rec_offset=7)), psi_amd.sort_unique(want))
+    finally:
+        for b in burners:
+            b.kill()
+        for b in burners:
+            b.wait()
+    f.close()
+
+
 def test_sort_unique_with_unordered_node_ids():
     """Node ids that are not rank + constant: the device sorter orders by id, not by rank."""
     g, reads = _random_graph(77)

@@ -27,6 +27,8 @@ def main():
     import test_gpu_parity as T
     n_cases = 0
     for seed in range(first, last):
+        if os.environ.get('FUZZ_TRACE'):
+            print('seed', seed, flush=True)
         g, reads = T._random_graph(seed)
         rng = random.Random(seed)
         if low_complexity and rng.random() < 0.7:
@@ -43,7 +45,7 @@ def main():
         pg = psi_amd.Graph.from_csr(g.ids, label_off, labels, edge_off, edge_to,
                                     paths=[[rank[v] for v in g.paths[0][1]]])
         for _ in range(2):
-            k = rng.choice([3, 8, 12, 13, 16, 21, 25, 31])
+            k = rng.choice([3, 8, 12, 13, 16, 21, 25, 31, 31, 32, 40])      # (32, 40: two-word seeds)
             step = rng.choice([1, 2, k, k + 3])
             npaths = rng.choice([0, 1, 1, 2, 3, 5])
             patched = npaths > 1 and rng.random() < 0.6
@@ -104,12 +106,14 @@ def main():
             for mode in ('kmer-table', 'locus-table', 'traverse'):
                 for cap in ((0,) if mode == 'traverse' else (0, 1, 3)):
                     f = psi_amd.SeedFinder(pg, k, mode=mode, walk_cap=cap)
+                    if mode == 'traverse' and rng.random() < 0.5:
+                        f.set_tuning(psi_amd.TUNE_NO_PATH_TABLE)        # the FM index on the paths instead of their k-mer table
                     f.set_path_index(px)
                     got = psi_amd.sort_unique(f.seeds_all(reads, step=step))
                     if not (got.shape == want.shape and (got == want).all()):
                         print('MISMATCH', seed, k, step, npaths, mode, cap, got.shape, want.shape, flush=True)
                         sys.exit(1)
-                    if rng.random() < 0.5:
+                    if rng.random() < 0.5 and k <= 31:      # (the oracle's k-mers are one word)
                         # psikt -r T over BOTH phases against the oracle's seeds_all( gocc_thr = T ): on-path k-mers
                         # over the threshold skipped, the traverser not thresholded (index_iter.hpp:826-847);
                         # set on the live finder, i.e. after its tables were made without one
@@ -127,13 +131,17 @@ def main():
                         n_cases += 1
                     if cap == 0:
                         # host entry point in pieces, sorted on the device
-                        os.environ['PSIGPU_SUB_BYTES'] = str(rng.choice([16, 200, 3000, 1 << 30]))
+                        os.environ['PSIGPU_SUB_BYTES'] = sub_b = str(rng.choice([16, 200, 3000, 1 << 30]))
                         su = f.seeds_all(reads, step=step, sort_unique=True, rec_offset=5)
                         os.environ.pop('PSIGPU_SUB_BYTES')
                         w2 = want.copy(); w2[:, 2] += 5
                         w2 = w2[np.lexsort((w2[:, 1], w2[:, 0], w2[:, 3], w2[:, 2]))]
                         if not (su.shape == w2.shape and (su == w2).all()):
-                            print('SORT-UNIQUE MISMATCH', seed, k, step, npaths, mode, flush=True)
+                            print('SORT-UNIQUE MISMATCH', seed, k, step, npaths, mode, 'cap', cap, 'sa_rate', px.view.sa_rate, 'ftab', px.view.ftab_len,
+                                  'patched', patched, 'sub', sub_b, su.shape, w2.shape, f.counters(), flush=True)
+                            a, b = set(map(tuple, su.tolist())), set(map(tuple, w2.tolist()))
+                            print(' extra', sorted(a - b)[:6], 'missing', sorted(b - a)[:6], 'duplicates', len(su) - len(a),
+                                  'sorted', bool((np.lexsort((su[:, 1], su[:, 0], su[:, 3], su[:, 2])) == np.arange(len(su))).all()), flush=True)
                             sys.exit(1)
                     if mode == 'kmer-table' and cap == 0 and npaths and px.view.sa_rate == 1:
                         gocc, mm = rng.choice([0, 0, 2]), rng.choice([0, 0, 3])
