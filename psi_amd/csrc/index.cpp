@@ -10,6 +10,8 @@
 // The data layout produced here is this library's own; results are compared
 // with the reference as hit SETS, never as suffix-array coordinates.
 #include <algorithm>
+#include <omp.h>
+#include <sys/mman.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -94,6 +96,14 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
   if (step == 0) step = 1;
   const uint64_t n = g.n_nodes();
   LociCtx c{ g, k, {}, {}, {}, {}, {}, {}, {}, {} };
+  const bool trace = getenv("PSIGPU_TRACE") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[psigpu]   loci: %s %.2f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
   c.reach.assign(n, 0);
   c.child.assign(n, 0);
   // reach: fixed point of reach(u) = min(k, len(u) + max_child reach(child)); len 0 nodes allowed
@@ -110,29 +120,42 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
       if (r > c.reach[v]) { c.reach[v] = r; changed = true; }
     }
   }
-  // path steps and the steps at every node
+  lap("reach");
+  // path steps and the steps at every node (all loops over the paths / steps / nodes in parallel: 600 M steps at
+  // whole-genome size; a node's steps are sorted so that the lists are what one sequential pass would make)
   {
-    uint64_t total = 0;
-    for (auto& P : paths) total += P.size();
-    c.step_node.reserve(total + 1); c.step_lo.reserve(total + 1); c.step_hi.reserve(total + 1); c.step_last.reserve(total + 1);
+    const int64_t np = (int64_t)paths.size();
+    std::vector<uint64_t> first(paths.size() + 1, 0);            // first step of every path
+    for (size_t p = 0; p < paths.size(); ++p) first[p + 1] = first[p] + paths[p].size();
+    const uint64_t total = first[paths.size()];
+    c.step_node.resize(total); c.step_lo.resize(total); c.step_hi.resize(total); c.step_last.resize(total);
     c.at_off.assign(n + 1, 0);
-    for (size_t p = 0; p < paths.size(); ++p) {
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t p = 0; p < np; ++p) {
       const auto& P = paths[p];
-      for (size_t i = 0; i < P.size(); ++i) {
+      uint64_t s = first[p];
+      for (size_t i = 0; i < P.size(); ++i, ++s) {
         const uint32_t len = (uint32_t)g.node_len(P[i]);
         uint32_t lo = 0, hi = len;
-        if (i == 0 && p < path_head.size()) lo = std::min(len, path_head[p]);
-        if (i + 1 == P.size() && p < path_tail.size() && path_tail[p]) hi = std::min(len, path_tail[p]);
-        c.step_node.push_back(P[i]); c.step_lo.push_back(lo); c.step_hi.push_back(hi);
-        c.step_last.push_back(i + 1 == P.size());
-        ++c.at_off[P[i] + 1];
+        if (i == 0 && (size_t)p < path_head.size()) lo = std::min(len, path_head[p]);
+        if (i + 1 == P.size() && (size_t)p < path_tail.size() && path_tail[p]) hi = std::min(len, path_tail[p]);
+        c.step_node[s] = P[i]; c.step_lo[s] = lo; c.step_hi[s] = hi;
+        c.step_last[s] = i + 1 == P.size();
+        __atomic_fetch_add(&c.at_off[P[i] + 1], 1ull, __ATOMIC_RELAXED);
       }
     }
     for (uint64_t v = 0; v < n; ++v) c.at_off[v + 1] += c.at_off[v];
-    c.at.resize(c.step_node.size());
+    c.at.resize(total);
     std::vector<uint64_t> fill(c.at_off.begin(), c.at_off.end() - 1);
-    for (uint32_t s = 0; s < c.step_node.size(); ++s) c.at[fill[c.step_node[s]]++] = s;
+    const int64_t nt = (int64_t)total;
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < nt; ++s) c.at[__atomic_fetch_add(&fill[c.step_node[s]], 1ull, __ATOMIC_RELAXED)] = (uint32_t)s;
+    const int64_t nn = (int64_t)n;
+#pragma omp parallel for schedule(dynamic, 1 << 16)
+    for (int64_t v = 0; v < nn; ++v)
+      if (c.at_off[v + 1] - c.at_off[v] > 1) std::sort(c.at.begin() + c.at_off[v], c.at.begin() + c.at_off[v + 1]);
   }
+  lap("path steps");
   // Nodes are independent: blocks of nodes in parallel (OpenMP), each block's loci in node order,
   // blocks concatenated in order.
   const uint64_t BLK = 1u << 16;
@@ -194,6 +217,7 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
       }
     }
   }
+  lap("nodes");
   uint64_t total = 0;
   for (auto& v : bn) total += v.size();
   loci_node.reserve(total);
@@ -204,6 +228,7 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
     std::vector<uint32_t>().swap(bn[b]);
     std::vector<uint32_t>().swap(bo[b]);
   }
+  lap("gather");
 }
 
 // ------------------------------------------------------------------------------------
@@ -220,6 +245,25 @@ static inline int base_sym(char ch)
   }
 }
 
+// Fault the pages of a freshly reserved range in from all threads (madvise on page-aligned slices; where the
+// kernel does not know MADV_POPULATE_WRITE the call fails and the first writer faults them in, as before).
+static void populate_pages(void* p, size_t bytes)
+{
+#ifdef MADV_POPULATE_WRITE
+  const uintptr_t PAGE = 4096, SLICE = 64u << 20;
+  const uintptr_t a = ((uintptr_t)p + PAGE - 1) & ~(PAGE - 1), b = ((uintptr_t)p + bytes) & ~(PAGE - 1);
+  if (b <= a || b - a < (8u << 20)) return;
+  const int64_t n = (int64_t)((b - a + SLICE - 1) / SLICE);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t i = 0; i < n; ++i) {
+    const uintptr_t lo = a + (uintptr_t)i * SLICE, hi = std::min<uintptr_t>(b, lo + SLICE);
+    (void)madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE);
+  }
+#else
+  (void)p; (void)bytes;
+#endif
+}
+
 // FM arrays + segment table over the concatenation of paths [p0, p1): one PART of the index (an index
 // is one part unless its text would pass the 32-bit row limit).  `head` / `tail`: per-path trimming.
 static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa_rate, bool keep,
@@ -228,44 +272,121 @@ static int build_part(const Graph& g, const psigpu_index_opts& opts, uint32_t sa
 {
   x->sa_rate = sa_rate;
   // ---- text + segments -----------------------------------------------------------
+  // The concatenation is assembled by work items of ~1 M path steps (several short paths -- patches -- or a slice
+  // of a long one): a counting pass, a prefix sum, a filling pass, both passes over the items in parallel.  What
+  // an item has to know of the text in front of it is one bit -- was the last symbol the separator of an N run
+  // (in_gap) -- which it reads off the steps before its first one.  (One sequential pass of push_backs took 25 of
+  // the 75 s of a whole-genome build.)
   std::vector<uint8_t> T;
-  uint64_t est = 1;
-  for (size_t pi = p0; pi < p1; ++pi) { for (uint32_t v : paths[pi]) est += g.node_len(v); ++est; }
-  T.reserve(est);
+  const auto t_text = std::chrono::steady_clock::now();
   auto& ss = x->seg_start; auto& sn = x->seg_node; auto& so = x->seg_noff;
-  bool first_path = true;
-  for (size_t pi = p0; pi < p1; ++pi) {
-    const auto& P = paths[pi];
-    if (P.empty()) continue;
-    if (!first_path) T.push_back(SYM_SEP);
-    first_path = false;
-    bool in_gap = false;           // last emitted symbol was a separator for an N run
-    for (size_t si = 0; si < P.size(); ++si) {
-      const uint32_t v = P[si];
-      const char* lab = g.labels.data() + g.label_off[v];
-      // a patched path starts at its head offset and ends after its tail length
-      // (Path::left / right, path_base.hpp:113-114, :240-246)
-      const uint64_t o_begin = si == 0 ? head[pi] : 0;
-      const uint64_t len = (si + 1 == P.size() && tail[pi]) ? tail[pi] : g.node_len(v);
-      bool open = false;           // a segment of this node is open
-      for (uint64_t o = o_begin; o < len; ++o) {
-        int s = base_sym(lab[o]);
-        if (s < 0) {
-          if (!in_gap) { T.push_back(SYM_SEP); in_gap = true; }
-          open = false;
-          continue;
-        }
-        if (!open) {
-          ss.push_back((uint32_t)T.size()); sn.push_back(v); so.push_back((uint32_t)o);
-          open = true;
-        }
-        in_gap = false;
-        T.push_back((uint8_t)s);
+  struct Item { size_t pa, pb; size_t s0, s1; bool in_gap; uint64_t n_sym, n_seg; };      // paths [pa, pb); a slice: pb == pa + 1, steps [s0, s1), s1 != 0
+  std::vector<Item> items;
+  std::vector<uint8_t> sep_before(p1 - p0, 0);    // a non-empty path behind another non-empty one starts with a separator
+  {
+    size_t TARGET = 1u << 20;
+    if (const char* e = getenv("PSIGPU_TEST_TEXT_ITEM")) TARGET = std::max<size_t>(1, strtoul(e, nullptr, 10));      // tests: items of a few steps
+    bool any_before = false;
+    size_t ga = p0, gsteps = 0;
+    auto flush_group = [&](size_t pb) {
+      if (pb > ga) items.push_back(Item{ ga, pb, 0, 0, false, 0, 0 });
+      ga = pb; gsteps = 0;
+    };
+    for (size_t pi = p0; pi < p1; ++pi) {
+      const size_t m = paths[pi].size();
+      sep_before[pi - p0] = m && any_before;
+      if (m) any_before = true;
+      if (m > TARGET) {
+        flush_group(pi);
+        for (size_t a0 = 0; a0 < m; a0 += TARGET) items.push_back(Item{ pi, pi + 1, a0, std::min(m, a0 + TARGET), false, 0, 0 });
+        ga = pi + 1;
+      } else {
+        gsteps += m;
+        if (gsteps >= TARGET) flush_group(pi + 1);
       }
     }
+    flush_group(p1);
+  }
+  // the bases [o_begin, len) a step contributes (a patched path starts at its head offset and ends after its
+  // tail length: Path::left / right, path_base.hpp:113-114, :240-246)
+  auto step_range = [&](size_t pi, size_t si, uint64_t* o_begin, uint64_t* len) {
+    const auto& P = paths[pi];
+    *o_begin = si == 0 ? head[pi] : 0;
+    *len = (si + 1 == P.size() && tail[pi]) ? tail[pi] : g.node_len(P[si]);
+  };
+  for (Item& it : items)
+    if (it.s0) {                                  // a slice behind the first: the state the steps before it leave
+      for (size_t si = it.s0; si-- > 0;) {
+        uint64_t ob, ln;
+        step_range(it.pa, si, &ob, &ln);
+        if (ob < ln) { it.in_gap = base_sym(g.labels[g.label_off[paths[it.pa][si]] + ln - 1]) < 0; break; }
+      }
+    }
+  // one item: FILL = false counts symbols and segments, FILL = true writes them at the item's offsets
+  auto run_item = [&](Item& it, bool fill, uint64_t t_at, uint64_t s_at) {
+    uint64_t nt = 0, ns = 0;
+    for (size_t pi = it.pa; pi < it.pb; ++pi) {
+      const auto& P = paths[pi];
+      if (P.empty()) continue;
+      const bool slice = it.s1 != 0;
+      const size_t sa = slice ? it.s0 : 0, sb = slice ? it.s1 : P.size();
+      bool in_gap = false;                        // last emitted symbol was a separator for an N run
+      if (sa == 0) {
+        if (sep_before[pi - p0]) { if (fill) T[t_at + nt] = SYM_SEP; ++nt; }
+      } else in_gap = it.in_gap;
+      for (size_t si = sa; si < sb; ++si) {
+        const uint32_t v = P[si];
+        const char* lab = g.labels.data() + g.label_off[v];
+        uint64_t o_begin, len;
+        step_range(pi, si, &o_begin, &len);
+        bool open = false;                        // a segment of this node is open
+        for (uint64_t o = o_begin; o < len; ++o) {
+          const int sy = base_sym(lab[o]);
+          if (sy < 0) {
+            if (!in_gap) { if (fill) T[t_at + nt] = SYM_SEP; ++nt; in_gap = true; }
+            open = false;
+            continue;
+          }
+          if (!open) {
+            if (fill) { ss[s_at + ns] = (uint32_t)(t_at + nt); sn[s_at + ns] = v; so[s_at + ns] = (uint32_t)o; }
+            ++ns;
+            open = true;
+          }
+          in_gap = false;
+          if (fill) T[t_at + nt] = (uint8_t)sy;
+          ++nt;
+        }
+      }
+    }
+    it.n_sym = nt; it.n_seg = ns;
+  };
+  const int64_t n_items = (int64_t)items.size();
+  const auto t_a = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t i = 0; i < n_items; ++i) run_item(items[i], false, 0, 0);
+  const auto t_b = std::chrono::steady_clock::now();
+  if (getenv("PSIGPU_TRACE")) fprintf(stderr, "[psigpu]   omp threads %d; items %.2f s, count pass %.2f s\n", omp_get_max_threads(), std::chrono::duration<double>(t_a - t_text).count(), std::chrono::duration<double>(t_b - t_a).count());
+  {
+    uint64_t tt = 0, tsg = 0;
+    std::vector<uint64_t> t_at(items.size()), s_at(items.size());
+    for (size_t i = 0; i < items.size(); ++i) { t_at[i] = tt; s_at[i] = tsg; tt += items[i].n_sym; tsg += items[i].n_seg; }
+    if (tt + 1 >= (1ull << 32)) { *err = "index part too large (text beyond 2^32 symbols)"; return PSIGPU_ERR_ARG; }
+    T.reserve(tt + 1);
+    ss.reserve(tsg + 2); sn.reserve(tsg + 1); so.reserve(tsg + 1);
+    // (a dozen GB at whole-genome size: the pages are faulted in by all threads before resize() zeroes them on one)
+    populate_pages(T.data(), tt + 1); populate_pages(ss.data(), (tsg + 2) * 4); populate_pages(sn.data(), (tsg + 1) * 4); populate_pages(so.data(), (tsg + 1) * 4);
+    T.resize(tt);
+    ss.resize(tsg); sn.resize(tsg); so.resize(tsg);
+    const auto t_c = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t i = 0; i < n_items; ++i) run_item(items[i], true, t_at[i], s_at[i]);
+    if (getenv("PSIGPU_TRACE")) fprintf(stderr, "[psigpu]   resize %.2f s, fill pass %.2f s\n", std::chrono::duration<double>(t_c - t_b).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c).count());
   }
   T.push_back(SYM_END);
   const uint64_t n = T.size();
+  if (getenv("PSIGPU_TRACE"))
+    fprintf(stderr, "[psigpu]   part text: %llu symbols, %zu segments, %zu work items, %.2f s\n", (unsigned long long)n, ss.size(), items.size(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_text).count());
   x->n = n;
   x->fm_ok = true;
   x->exc_shift = EXC_SUPER_SHIFT;

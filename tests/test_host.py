@@ -620,6 +620,60 @@ def test_index_in_several_parts_host(tmp_path, ref_data, patched):
         assert sorted(got) == want and want
 
 
+@pytest.mark.parametrize('name', ['x', 'multi'])
+def test_path_text_is_assembled_in_pieces(monkeypatch, ref_data, name):
+    """The builder assembles the paths' text and segment table by work items of ~1 M path steps in parallel
+    (count, prefix sum, fill); PSIGPU_TEST_TEXT_ITEM makes the items one, two or seven steps long, so that patches
+    are grouped and paths are sliced on a small graph: same text, segments, suffix array and rank blocks whatever
+    the item size, and the text is the paths' labels with one separator per N run and between paths."""
+    b, g = _setup(ref_data, name)
+    k = 12
+    # an N run across a node boundary and a node of Ns only, on the first path
+    labels = bytearray(g.labels)
+    p0 = psi_amd.PathIndex.build(g, k, 1, rng_seed=2).paths()[0].tolist()
+    v, w, z = p0[3], p0[4], p0[8]
+    labels[g.label_off[v + 1] - 1] = ord('N'); labels[g.label_off[w]] = ord('N')
+    labels[g.label_off[z]:g.label_off[z + 1]] = b'N' * int(g.label_off[z + 1] - g.label_off[z])
+    gn = psi_amd.Graph.from_csr(g.node_id, g.label_off, bytes(labels), g.edge_off, g.edge_to, paths=[p0])
+    sym = {ord('A'): 2, ord('C'): 3, ord('G'): 4, ord('T'): 5}
+    for npaths, patched in ((3, False), (5, True)):
+        ref = None
+        for item in (None, '1', '2', '7'):
+            if item is None:
+                monkeypatch.delenv('PSIGPU_TEST_TEXT_ITEM', raising=False)
+            else:
+                monkeypatch.setenv('PSIGPU_TEST_TEXT_ITEM', item)
+            px = psi_amd.PathIndex.build(gn, k, npaths, rng_seed=5, patched=patched, context=k + 3 if patched else 0, keep=True)
+            vw = px.view
+            got = (px.text().tobytes(), px.sa().tobytes(), px._arr(vw.seg_start, vw.n_segs + 1, np.uint32).tobytes(),
+                   px._arr(vw.seg_node, vw.n_segs, np.uint32).tobytes(), px._arr(vw.seg_noff, vw.n_segs, np.uint32).tobytes(),
+                   px._arr(vw.bwt_blocks, vw.n_blocks * 64, np.uint8).tobytes(), [p.tolist() for p in px.paths()], px.trims())
+            if ref is None:
+                ref = got
+                # the definition, restated: labels of the paths' nodes between the trims, a separator per N run and per path
+                want, first = [], True
+                for path, (head, tail) in zip(px.paths(), px.trims()):
+                    if not len(path):
+                        continue
+                    if not first:
+                        want.append(1)
+                    first = False
+                    gap = False
+                    for i, node in enumerate(path.tolist()):
+                        lab = labels[gn.label_off[node]:gn.label_off[node + 1]]
+                        lo = head if i == 0 else 0
+                        hi = tail if (i + 1 == len(path) and tail) else len(lab)
+                        for c in lab[lo:hi]:
+                            if c in sym:
+                                want.append(sym[c]); gap = False
+                            elif not gap:
+                                want.append(1); gap = True
+                want.append(0)
+                assert px.text().tolist() == want and 1 in want
+            else:
+                assert got == ref
+
+
 def test_index_argument_checks(ref_data):
     b, g = _setup(ref_data, 'tiny')
     with pytest.raises(psi_amd.PsiGpuError):
