@@ -277,7 +277,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
   }
   GB_CHK(hipDeviceSynchronize());
   if (sa_out && n < 0x7FFFFFF0u) {
-    sa_out->resize(n);
+    resize_populated(*sa_out, n);
     GB_CHK(hipMemcpy(sa_out->data(), sa_cur, (size_t)n * 4, hipMemcpyDeviceToHost));
   }
 
@@ -312,7 +312,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
                                          dsuper.as<uint32_t>());
   x->exc_super.resize(n_super);
   GB_CHK(hipMemcpy(x->exc_super.data(), dsuper.p, n_super * 4, hipMemcpyDeviceToHost));
-  x->blocks.resize(nblk);
+  resize_populated(x->blocks, nblk);
   GB_CHK(hipMemcpy(x->blocks.data(), dblocks.p, (size_t)nblk * sizeof(RankBlock), hipMemcpyDeviceToHost));
   x->exc_row.resize(totE); x->exc_sa.resize(totE);
   if (totE) {
@@ -328,7 +328,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
   }
   // ---- SA samples ---------------------------------------------------------------------------------
   const uint64_t nsamp = ((uint64_t)n + sa_rate - 1) / sa_rate;
-  x->samples.resize(nsamp);
+  resize_populated(x->samples, nsamp);
   if (sa_rate == 1) {
     GB_CHK(hipMemcpy(x->samples.data(), sa_cur, (size_t)n * 4, hipMemcpyDeviceToHost));
   } else {
@@ -347,7 +347,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
     GB_CHK(df.alloc(entries * 8));
     GB_CHK(hipMemset(df.p, 0, entries * 8));
     k_ftab<<<g, 256>>>(dT.as<uint8_t>(), sa_cur, n, q, df.as<uint2>());
-    x->ftab.resize(2 * entries);
+    resize_populated(x->ftab, 2 * entries);
     GB_CHK(hipMemcpy(x->ftab.data(), df.p, entries * 8, hipMemcpyDeviceToHost));
   }
 
@@ -357,7 +357,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
     Buf dt4;
     GB_CHK(dt4.alloc(nwords * 8));
     k_text4<<<grid_for(nwords), 256>>>(dT.as<uint8_t>(), n, nwords, dt4.as<uint64_t>());
-    x->text4.resize(nwords);
+    resize_populated(x->text4, nwords);
     GB_CHK(hipMemcpy(x->text4.data(), dt4.p, nwords * 8, hipMemcpyDeviceToHost));
   }
   GB_CHK(hipDeviceSynchronize());
@@ -599,8 +599,8 @@ int gpu_find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_
   uint32_t total = 0;
   GB_CHK(hipMemcpy(&total, d_first.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
   // (a 32-bit scan: more than 2^32 loci cannot be indexed by the u32 locus ids used downstream either)
-  loci_node.resize(total);
-  loci_off.resize(total);
+  resize_populated(loci_node, total);
+  resize_populated(loci_off, total);
   if (total) {
     GB_CHK(d_out_n.alloc((size_t)total * 4)); GB_CHK(d_out_o.alloc((size_t)total * 4));
     k_loci_fill<<<gn, 256>>>(lg, d_unc.as<unsigned long long>(), d_first.as<uint32_t>(), d_cnt.as<uint32_t>(),

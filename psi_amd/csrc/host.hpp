@@ -5,6 +5,12 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include <sys/mman.h>
+
 #include "../../include/psi_gpu.h"
 
 namespace psigpu {
@@ -84,6 +90,42 @@ bool index_fits_graph(const Index& x, const Graph& g);
 Index* build_index(const Graph& g, const psigpu_index_opts& opts,
                    const std::vector<std::vector<uint32_t>>& paths, const std::vector<uint32_t>& head,
                    const std::vector<uint32_t>& tail, int* status, std::string* err);
+// Fault the pages of a freshly reserved range in from all threads (madvise on page-aligned slices; where the
+// kernel does not know MADV_POPULATE_WRITE the call fails and the first writer faults them in, as before).
+// v.resize( n ) of a whole-genome array is otherwise a page fault per 4 KB on ONE thread: seconds per array.
+inline void populate_pages(void* p, size_t bytes)
+{
+#ifdef MADV_POPULATE_WRITE
+  const uintptr_t PAGE = 4096, SLICE = 64u << 20;
+  const uintptr_t a = ((uintptr_t)p + PAGE - 1) & ~(PAGE - 1), b = ((uintptr_t)p + bytes) & ~(PAGE - 1);
+  if (b <= a || b - a < (8u << 20)) return;
+  const uint64_t n = (b - a + SLICE - 1) / SLICE;
+  unsigned hw = std::thread::hardware_concurrency();
+  const unsigned nt = (unsigned)std::min<uint64_t>(n, std::min<unsigned>(hw ? hw : 1, 32));
+  std::atomic<uint64_t> next{ 0 };
+  auto work = [&] {
+    for (uint64_t i; (i = next.fetch_add(1)) < n;) {
+      const uintptr_t lo = a + (uintptr_t)i * SLICE, hi = lo + SLICE < b ? lo + SLICE : b;
+      (void)madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE);
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+#else
+  (void)p; (void)bytes;
+#endif
+}
+
+// v.resize( n ) (value-initialised) with the pages faulted in by all threads first
+template <typename V>
+inline void resize_populated(V& v, size_t n)
+{
+  if (n > v.capacity()) { v.reserve(n); populate_pages(v.data(), n * sizeof(typename V::value_type)); }
+  v.resize(n);
+}
+
 void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>& paths,
                         const std::vector<uint32_t>& path_head, const std::vector<uint32_t>& path_tail,
                         uint32_t k, uint32_t step, std::vector<uint32_t>& loci_node,

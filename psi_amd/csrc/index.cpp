@@ -11,7 +11,6 @@
 // with the reference as hit SETS, never as suffix-array coordinates.
 #include <algorithm>
 #include <omp.h>
-#include <sys/mman.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -104,8 +103,8 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
     fprintf(stderr, "[psigpu]   loci: %s %.2f s\n", what, std::chrono::duration<double>(now - t_prev).count());
     t_prev = now;
   };
-  c.reach.assign(n, 0);
-  c.child.assign(n, 0);
+  resize_populated(c.reach, n);
+  resize_populated(c.child, n);
   // reach: fixed point of reach(u) = min(k, len(u) + max_child reach(child)); len 0 nodes allowed
   for (uint64_t v = 0; v < n; ++v) c.reach[v] = (uint32_t)std::min<uint64_t>(k, g.node_len((uint32_t)v));
   bool changed = true;
@@ -128,8 +127,9 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
     std::vector<uint64_t> first(paths.size() + 1, 0);            // first step of every path
     for (size_t p = 0; p < paths.size(); ++p) first[p + 1] = first[p] + paths[p].size();
     const uint64_t total = first[paths.size()];
-    c.step_node.resize(total); c.step_lo.resize(total); c.step_hi.resize(total); c.step_last.resize(total);
-    c.at_off.assign(n + 1, 0);
+    resize_populated(c.step_node, total); resize_populated(c.step_lo, total); resize_populated(c.step_hi, total);
+    resize_populated(c.step_last, total);
+    resize_populated(c.at_off, n + 1);
 #pragma omp parallel for schedule(dynamic, 4096)
     for (int64_t p = 0; p < np; ++p) {
       const auto& P = paths[p];
@@ -145,8 +145,14 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
       }
     }
     for (uint64_t v = 0; v < n; ++v) c.at_off[v + 1] += c.at_off[v];
-    c.at.resize(total);
-    std::vector<uint64_t> fill(c.at_off.begin(), c.at_off.end() - 1);
+    resize_populated(c.at, total);
+    std::vector<uint64_t> fill;
+    resize_populated(fill, n);
+    {
+      const int64_t nn2 = (int64_t)n;
+#pragma omp parallel for schedule(static)
+      for (int64_t v = 0; v < nn2; ++v) fill[v] = c.at_off[v];
+    }
     const int64_t nt = (int64_t)total;
 #pragma omp parallel for schedule(static)
     for (int64_t s = 0; s < nt; ++s) c.at[__atomic_fetch_add(&fill[c.step_node[s]], 1ull, __ATOMIC_RELAXED)] = (uint32_t)s;
@@ -243,25 +249,6 @@ static inline int base_sym(char ch)
     case 'T': case 't': return SYM_T;
     default: return -1;
   }
-}
-
-// Fault the pages of a freshly reserved range in from all threads (madvise on page-aligned slices; where the
-// kernel does not know MADV_POPULATE_WRITE the call fails and the first writer faults them in, as before).
-static void populate_pages(void* p, size_t bytes)
-{
-#ifdef MADV_POPULATE_WRITE
-  const uintptr_t PAGE = 4096, SLICE = 64u << 20;
-  const uintptr_t a = ((uintptr_t)p + PAGE - 1) & ~(PAGE - 1), b = ((uintptr_t)p + bytes) & ~(PAGE - 1);
-  if (b <= a || b - a < (8u << 20)) return;
-  const int64_t n = (int64_t)((b - a + SLICE - 1) / SLICE);
-#pragma omp parallel for schedule(dynamic, 1)
-  for (int64_t i = 0; i < n; ++i) {
-    const uintptr_t lo = a + (uintptr_t)i * SLICE, hi = std::min<uintptr_t>(b, lo + SLICE);
-    (void)madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE);
-  }
-#else
-  (void)p; (void)bytes;
-#endif
 }
 
 // FM arrays + segment table over the concatenation of paths [p0, p1): one PART of the index (an index

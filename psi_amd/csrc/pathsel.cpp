@@ -20,6 +20,9 @@
 //       index holds does not change the hit set: every k-walk the indexed text does not spell
 //       makes its first base a starting locus (find_starting_loci, index.cpp).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <random>
 #include <unordered_map>
@@ -131,8 +134,14 @@ public:
   {
     Walk w;
     w.sorted = current_;
-    std::sort(w.sorted.begin(), w.sorted.end());
-    w.sorted.erase(std::unique(w.sorted.begin(), w.sorted.end()), w.sorted.end());
+    // (a walk through a graph whose ranks follow the topology -- vg's do -- is increasing already: the sort of a
+    // 300 M-node walk was a fifth of a whole-genome index build)
+    bool increasing = true;
+    for (size_t i = 1; i < w.sorted.size() && increasing; ++i) increasing = w.sorted[i - 1] < w.sorted[i];
+    if (!increasing) {
+      std::sort(w.sorted.begin(), w.sorted.end());
+      w.sorted.erase(std::unique(w.sorted.begin(), w.sorted.end()), w.sorted.end());
+    }
     w.bits.assign((g_.n_nodes() >> 6) + 1, 0);
     for (uint32_t v : w.sorted) w.bits[v >> 6] |= 1ull << (v & 63);
     visited_.push_back(std::move(w));
@@ -207,12 +216,14 @@ std::vector<Patch> cut_patches(const Graph& g, const std::vector<uint32_t>& walk
   const size_t m = walk.size();
   std::vector<Patch> out;
   if (m == 0) return out;
-  std::vector<uint64_t> pos(m + 1, 0);             // first base of walk[i] in the walk's sequence
+  std::vector<uint64_t> pos;                       // first base of walk[i] in the walk's sequence
+  resize_populated(pos, m + 1);
   for (size_t i = 0; i < m; ++i) pos[i + 1] = pos[i] + g.node_len(walk[i]);
   const uint64_t L = pos[m];
   if (L == 0) return out;
   // run[i]: the longest j - i + 1 such that walk[i..j] is a contiguous run of some earlier walk
-  std::vector<uint32_t> run(m, 0), cur(m, 0);
+  std::vector<uint32_t> run, cur;
+  resize_populated(run, m); resize_populated(cur, m);
   for (const auto& V : earlier) {
     // node -> its (first) position in V: a plain array over the nodes (a hash map of a whole-genome walk's
     // 300 M nodes took longer than everything else in the index build)
@@ -273,16 +284,25 @@ void pick_paths(const Graph& g, uint32_t n_per_region, bool patched, uint32_t co
     std::vector<std::vector<uint32_t>> walks;      // this region's walks so far (whole, also when patches are kept)
     if (patched && n_per_region > 1 && at.empty()) at.assign(g.n_nodes(), NO_NODE);
     for (uint32_t i = 0; i < n_per_region; ++i) {
+      const auto t0 = std::chrono::steady_clock::now();
       std::vector<uint32_t> walk = full_walk(g, hp);
+      const auto t1 = std::chrono::steady_clock::now();
       hp.save();
+      if (getenv("PSIGPU_TRACE_PICK")) fprintf(stderr, "[psigpu]   walk %u: %zu nodes, walk %.2f s, save %.2f s\n", i, walk.size(),
+                                               std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
       if (walk.empty()) continue;
       if (!patched || walks.empty()) {             // get_uniq_patched_haplotype: level 0 gives a full haplotype (:568-571)
         out.push_back(walk); head.push_back(0); tail.push_back(0);
       } else {
-        for (const Patch& p : cut_patches(g, walk, walks, context, at)) {
+        const auto t2 = std::chrono::steady_clock::now();
+        const std::vector<Patch> pt = cut_patches(g, walk, walks, context, at);
+        const auto t3 = std::chrono::steady_clock::now();
+        for (const Patch& p : pt) {
           out.emplace_back(walk.begin() + p.first, walk.begin() + p.last + 1);
           head.push_back(p.head); tail.push_back(p.tail);
         }
+        if (getenv("PSIGPU_TRACE_PICK")) fprintf(stderr, "[psigpu]   patches %zu: cut %.2f s, copy %.2f s\n", pt.size(),
+                                                 std::chrono::duration<double>(t3 - t2).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t3).count());
       }
       walks.push_back(std::move(walk));
     }
