@@ -669,8 +669,8 @@ k_sb_count(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ p
 
 __global__ void __launch_bounds__(256)
 k_sb_scatter(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params, uint64_t seeds_cap, SeedBuckets sb,
-             const uint64_t* __restrict__ off /* exclusive scan of cnt */, uint64_t* __restrict__ out_key,
-             uint32_t* __restrict__ out_seed, uint32_t* __restrict__ seed_next)
+             const uint64_t* __restrict__ off /* exclusive scan of cnt */, ulonglong2* __restrict__ out_rec /* (k-mer, seed) */,
+             uint32_t* __restrict__ seed_next)
 {
   extern __shared__ uint32_t cur[];
   for (uint32_t i = threadIdx.x; i < sb.n_buckets; i += 256) cur[i] = (uint32_t)off[(uint64_t)i * sb.n_wg + blockIdx.x];
@@ -686,15 +686,16 @@ k_sb_scatter(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__
       if (s + 256 * j < s1) seed_next[s + 256 * j] = NIL;
       if (key[j] == KEY_INVALID) continue;
       const uint32_t at = atomicAdd(&cur[sb_bucket(key[j], sb.k, sb.pb)], 1u);
-      out_key[at] = key[j];
-      out_seed[at] = (uint32_t)(s + 256 * j);
+      // one 16-byte store per seed: the stores of a bucket's run come from all over the tile and leave L2 as partial
+      // lines, one request each -- k-mer and seed number in two arrays were two requests (0.19 -> 0.1x ms)
+      out_rec[at] = make_ulonglong2(key[j], s + 256 * j);
     }
   }
 }
 
 // one workgroup per bucket
 __global__ void __launch_bounds__(256)
-k_sb_build(const uint64_t* __restrict__ bkey, const uint32_t* __restrict__ bseed, const uint64_t* __restrict__ off, SeedBuckets sb,
+k_sb_build(const ulonglong2* __restrict__ brec, const uint64_t* __restrict__ off, SeedBuckets sb,
            TableSlot* __restrict__ ht, uint32_t* __restrict__ seed_next, uint32_t* __restrict__ pfx_bits, uint32_t pfx_len,
            uint32_t* __restrict__ pfx12)
 {
@@ -716,8 +717,9 @@ k_sb_build(const uint64_t* __restrict__ bkey, const uint32_t* __restrict__ bseed
   const uint32_t sh = 2 * (sb.k - pfx_len);
   const uint32_t sub_mask = (1u << (2 * sub)) - 1u;
   for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    const uint64_t key = bkey[lo + i];
-    const uint32_t s = bseed[lo + i];
+    const ulonglong2 rec = brec[lo + i];
+    const uint64_t key = rec.x;
+    const uint32_t s = (uint32_t)rec.y;
     const uint32_t pf = (uint32_t)(key >> sh) & sub_mask;
     atomicOr(&bm[pf >> 5], 1u << (pf & 31));
     uint32_t h = sb_home(key, m);
@@ -2416,14 +2418,16 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
         KEY body = it.kmer ^ ((KEY)1 << (2 * depth));
         body = (body << (2 * take)) | b;
         uint32_t nd = depth + take;
-        // seed-prefix filter, once per level, when the walk first reaches that many bases;
-        // both probes are issued together
+        // seed-prefix filter, once per level, when the walk first reaches that many bases.  The long map is
+        // only asked when the short one (2 MiB, L2-resident) lets the walk pass: the kernel runs at the fabric's
+        // request rate, not at a latency, and a probe of the 32-MiB map is a request that leaves L2
         bool c12 = tb.pfx12 && depth < PFX_SHORT && nd >= PFX_SHORT;
         bool c14 = tb.pfx_bits && depth < tb.pfx_len && nd >= tb.pfx_len;
         uint32_t w12 = 0xFFFFFFFFu, w14 = 0xFFFFFFFFu, p12 = 0, p14 = 0;
         if (c12) { p12 = (uint32_t)(body >> (2 * (nd - PFX_SHORT))); w12 = tb.pfx12[p12 >> 5]; }
-        if (c14) { p14 = (uint32_t)(body >> (2 * (nd - tb.pfx_len))); w14 = tb.pfx_bits[p14 >> 5]; }
-        dead = !((w12 >> (p12 & 31)) & (w14 >> (p14 & 31)) & 1u);
+        const bool pass12 = (w12 >> (p12 & 31)) & 1u;
+        if (c14 && pass12) { p14 = (uint32_t)(body >> (2 * (nd - tb.pfx_len))); w14 = tb.pfx_bits[p14 >> 5]; }
+        dead = !(pass12 && ((w14 >> (p14 & 31)) & 1u));
         depth = nd;
         it.kmer = body | ((KEY)1 << (2 * depth));
       }
@@ -2763,7 +2767,7 @@ struct psigpu_ctx {
   DevBuf w_bases, w_read_off, w_cnt, w_tiles, w_seed_off, w_seed_key, w_seed_info,
       w_seed_next, w_ht, w_pfx, w_pfx12, w_iv_lo, w_iv_cnt, w_iv_aux, w_hit_off, w_iv_tiles,
       w_chunks, w_chunk_fill, w_chunk_off, w_chunk_tiles, w_hits, w_spill_a, w_spill_b, w_ctr, w_total,
-      w_sb_cnt, w_sb_off, w_sb_tiles, w_sb_key, w_sb_seed,      // the partition of a chunk's seeds (k_sb_*)
+      w_sb_cnt, w_sb_off, w_sb_tiles, w_sb_key,      // the partition of a chunk's seeds (k_sb_*): counts, offsets, (k-mer, seed) records
       w_seed_wide, w_seed_pfx;                                  // two-word seeds: the k-mers themselves, their first 14 bases
   uint64_t hits_cap_hint = 0, chunks_cap_hint = 0;
   uint64_t spill_cap = 1u << 22;   // traverser spill queue entries (grows when a chunk overflows it)
@@ -2954,7 +2958,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
   for (auto* b : all) b->release();
   ctx->ids_sorted.release(); ctx->w_sorted[0].release(); ctx->w_sorted[1].release(); ctx->w_count.release();
   ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release();
-  for (DevBuf* b : { &ctx->w_sb_cnt, &ctx->w_sb_off, &ctx->w_sb_tiles, &ctx->w_sb_key, &ctx->w_sb_seed, &ctx->w_seed_wide, &ctx->w_seed_pfx }) b->release();
+  for (DevBuf* b : { &ctx->w_sb_cnt, &ctx->w_sb_off, &ctx->w_sb_tiles, &ctx->w_sb_key, &ctx->w_seed_wide, &ctx->w_seed_pfx }) b->release();
   for (auto& m : ctx->parts) m->release();
   ctx->w_hits_alt.release();
   for (auto& sl : ctx->slot) {
@@ -3834,8 +3838,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     HIPCHK(ctx, ctx->w_sb_cnt.ensure((sb_cnt + 1) * 4));
     HIPCHK(ctx, ctx->w_sb_off.ensure((sb_cnt + 2) * 8));
     HIPCHK(ctx, ctx->w_sb_tiles.ensure((sb_cnt / SCAN_TILE + 2) * 8));
-    HIPCHK(ctx, ctx->w_sb_key.ensure((seeds_ub + 1) * 8));
-    HIPCHK(ctx, ctx->w_sb_seed.ensure((seeds_ub + 1) * 4));
+    HIPCHK(ctx, ctx->w_sb_key.ensure((seeds_ub + 1) * 16));
   }
 
   // ---- K0: seeds ---------------------------------------------------------------------
@@ -3982,10 +3985,10 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
       k_scan_final<<<(unsigned)tiles, SCAN_THREADS, 0, ts>>>(ctx->w_sb_cnt.as<uint32_t>(), sb_cnt, ctx->w_sb_tiles.as<uint64_t>(),
                                                            ctx->w_sb_off.as<uint64_t>());
       k_sb_scatter<<<sb.n_wg, 256, lds, ts>>>(ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, sb, ctx->w_sb_off.as<uint64_t>(),
-                                             ctx->w_sb_key.as<uint64_t>(), ctx->w_sb_seed.as<uint32_t>(), ctx->w_seed_next.as<uint32_t>());
+                                             ctx->w_sb_key.as<ulonglong2>(), ctx->w_seed_next.as<uint32_t>());
       if ((1u << (2 * (pfx_len - sb.pb))) < 32)              // (prefix maps of short seeds: buckets share words)
         HIPCHK(ctx, hipMemsetAsync(ctx->w_pfx.p, 0, pfx_words * 4, ts));
-      k_sb_build<<<sb.n_buckets, 256, 0, ts>>>(ctx->w_sb_key.as<uint64_t>(), ctx->w_sb_seed.as<uint32_t>(), ctx->w_sb_off.as<uint64_t>(), sb,
+      k_sb_build<<<sb.n_buckets, 256, 0, ts>>>(ctx->w_sb_key.as<ulonglong2>(), ctx->w_sb_off.as<uint64_t>(), sb,
                                               ctx->w_ht.as<TableSlot>(), ctx->w_seed_next.as<uint32_t>(), ctx->w_pfx.as<uint32_t>(), pfx_len,
                                               use_pfx12 ? ctx->w_pfx12.as<uint32_t>() : nullptr);
       EVREC(6, ts);
