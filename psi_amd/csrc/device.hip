@@ -2195,7 +2195,9 @@ struct GraphView {
   const uint64_t* lab2;      // 2-bit bases, 32 per word, first base most significant
   const uint64_t* labn;      // N mask, 64 per word, first base most significant
   const uint32_t* edge_to;
-  const uint64_t* node_id;
+  const uint64_t* node_id;      // rank -> external id ...
+  uint64_t id_base;             // ... or id = rank + id_base when the ids are consecutive (no load)
+  bool id_affine;
 };
 
 struct TableView {
@@ -2268,7 +2270,7 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
   }
   if (!__any(s != NIL)) return;
   uint64_t nid = 0, noff = 0;
-  if (s != NIL) { uint2 lc = loci[locus]; nid = g.node_id[lc.x]; noff = lc.y; }
+  if (s != NIL) { uint2 lc = loci[locus]; nid = g.id_affine ? g.id_base + lc.x : g.node_id[lc.x]; noff = lc.y; }
   while (__any(s != NIL)) {
     bool has = s != NIL;
     uint64_t rid = 0, roff = 0;
@@ -3720,6 +3722,7 @@ static GraphView graph_view(const psigpu_ctx* ctx)
   GraphView gv;
   gv.nodes = ctx->nodes.as<NodeRec>(); gv.lite = ctx->lite.as<NodeLite>(); gv.lab2 = ctx->lab2.as<uint64_t>(); gv.labn = ctx->labn.as<uint64_t>();
   gv.edge_to = ctx->edge_to.as<uint32_t>(); gv.node_id = ctx->node_id.as<uint64_t>();
+  gv.id_base = ctx->id_base; gv.id_affine = ctx->id_affine;
   return gv;
 }
 
