@@ -1670,6 +1670,25 @@ __global__ void k_build_sarec(const uint32_t* __restrict__ sa, uint64_t n, uint3
   out[row] = r;
 }
 
+// The interval table with the first row's record inside its entries: one 32-byte entry per q-mer -- (l, r) and
+// the SaRec of row l -- so that K1 of the FM modes learns a seed's interval AND verifies its first row (the only
+// one for most q-mers: 1.45 rows on average) from ONE sector.  k_fm_search_direct runs at the fabric's request
+// rate; this takes one of its ~3.4 requests per seed away.
+struct FtabX { uint32_t l, r, node, noff; uint64_t ctx, pad; };
+static_assert(sizeof(FtabX) == 32, "two 16-byte loads from one sector");
+
+__global__ void k_build_ftabx(const uint2* __restrict__ ftab, uint64_t n_entries, const SaRec* __restrict__ sarec, FtabX* __restrict__ out)
+{
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_entries) return;
+  const uint2 iv = ftab[c];
+  FtabX e = { iv.x, iv.y, 0, 0, 0, 0 };
+  if (iv.y > iv.x) { const SaRec rec = sarec[iv.x]; e.node = rec.node; e.noff = rec.noff; e.ctx = rec.ctx; }
+  uint4* o = reinterpret_cast<uint4*>(out + c);
+  o[0] = make_uint4(e.l, e.r, e.node, e.noff);
+  o[1] = make_uint4((uint32_t)e.ctx, (uint32_t)(e.ctx >> 32), 0, 0);
+}
+
 // 16 text symbols (4 bits each, first on top) starting `rem` symbols in front of `pos`; both words
 // are always loaded (the text carries two words of padding), so several windows can be in flight
 __device__ __forceinline__ bool window_matches(uint64_t w0, uint64_t w1, uint32_t a, uint32_t rem, uint64_t key, uint32_t k)
@@ -1698,7 +1717,7 @@ __device__ __forceinline__ bool window_matches(uint64_t w0, uint64_t w1, uint32_
 // records four at a time.  Seeds with a larger interval are appended to `defer` for k_fm_search
 // (quad kernel, list mode).
 __global__ void __launch_bounds__(256)
-k_fm_search_direct(FMView fm, LktView lk, const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
+k_fm_search_direct(FMView fm, const FtabX* __restrict__ ftabx, LktView lk, const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
                    uint64_t seeds_cap, uint32_t per_wave, uint32_t k, uint32_t gocc_thr, SeedOut so,
                    uint64_t* __restrict__ wave_total, uint64_t* __restrict__ wave_total_off,
                    uint32_t* __restrict__ defer, DevCounters* ctr)
@@ -1722,7 +1741,14 @@ k_fm_search_direct(FMView fm, LktView lk, const uint64_t* __restrict__ seed_key,
     const bool probing = lk.ht != nullptr && valid;
     if (probing) { h = lkt_home(key, lk.n_slots); sl = lk.ht[h]; }
     uint32_t l = 0, r = 0;
-    if (valid) { uint2 iv = fm.ftab[key & qmask]; l = iv.x; r = iv.y; }
+    SaRec first = { 0, 0, 0 };                  // row l's record, when the interval table carries it
+    if (valid) {
+      if (ftabx) {
+        const uint4* e = reinterpret_cast<const uint4*>(ftabx + (key & qmask));
+        const uint4 a = e[0], b = e[1];           // (one sector)
+        l = a.x; r = a.y; first.node = a.z; first.noff = a.w; first.ctx = (uint64_t)b.x | ((uint64_t)b.y << 32);
+      } else { uint2 iv = fm.ftab[key & qmask]; l = iv.x; r = iv.y; }
+    }
     uint32_t cnt = r > l ? r - l : 0u, aux = 0, on_node = 0, on_noff = 0;
     const bool deferred = rem != 0 && cnt > VERIFY_ROWS;
     if (rem != 0 && cnt != 0 && !deferred) {
@@ -1736,6 +1762,7 @@ k_fm_search_direct(FMView fm, LktView lk, const uint64_t* __restrict__ seed_key,
         for (uint32_t j = 0; j < 4; ++j) {
           c[j] = SaRec{ 0, 0, 0 };
           if (t0 + j < cnt) {
+            if (ftabx && t0 + j == 0) { c[j] = first; continue; }
             uint4 v = *reinterpret_cast<const uint4*>(&fm.sarec[l + t0 + j]);
             c[j].node = v.x; c[j].noff = v.y; c[j].ctx = (uint64_t)v.z | ((uint64_t)v.w << 32);
           }
@@ -2734,14 +2761,15 @@ struct psigpu_ctx {
     DevBuf blocks, samples, exc_row, exc_sa, ftab, text4, seg, seg_dir, seg_rank;      // (exc_row: + the super-block counts)
     DevBuf saloc;                    // (node rank, offset) per SA row (sa_rate 1, when memory is plentiful)
     DevBuf sarec;                    // per-row records for seed length sarec_k (sa_rate 1, interval table, text resident)
+    DevBuf ftabx;                    // interval table with the first row's record in its entries (FtabX), for seed length ftabx_k
     uint64_t text_len = 0, n_exc = 0, n_segs = 0;
     uint64_t C[4] = { 0, 0, 0, 0 };
-    uint32_t ftab_len = 0, exc_shift = EXC_SUPER_SHIFT, sarec_k = 0;
+    uint32_t ftab_len = 0, exc_shift = EXC_SUPER_SHIFT, sarec_k = 0, ftabx_k = 0;
     bool have_text4 = false, have_saloc = false;
     void release()
     {
-      for (DevBuf* b : { &blocks, &samples, &exc_row, &exc_sa, &ftab, &text4, &seg, &seg_dir, &seg_rank, &saloc, &sarec }) b->release();
-      text_len = n_exc = n_segs = 0; ftab_len = sarec_k = 0; have_text4 = have_saloc = false;
+      for (DevBuf* b : { &blocks, &samples, &exc_row, &exc_sa, &ftab, &text4, &seg, &seg_dir, &seg_rank, &saloc, &sarec, &ftabx }) b->release();
+      text_len = n_exc = n_segs = 0; ftab_len = sarec_k = ftabx_k = 0; have_text4 = have_saloc = false;
     }
   };
   std::vector<std::unique_ptr<FmPart>> parts;      // parts[0] always exists
@@ -3306,6 +3334,7 @@ static int build_row_records(psigpu_ctx* ctx, uint32_t k)
   for (auto& pp : ctx->parts) {
     psigpu_ctx::FmPart& fp = *pp;
     fp.sarec_k = 0; fp.sarec.release();
+    fp.ftabx_k = 0; fp.ftabx.release();
     fp.have_saloc = false; fp.saloc.release();
     const uint64_t n_rows = (fp.text_len + ctx->sa_rate - 1) / ctx->sa_rate;
     if (ctx->sa_rate == 1 && fp.have_text4 && fp.ftab_len && k >= fp.ftab_len && k - fp.ftab_len <= 29 && fp.n_segs && !no_sarec) {
@@ -3316,6 +3345,19 @@ static int build_row_records(psigpu_ctx* ctx, uint32_t k)
             fp.seg_dir.as<uint32_t>(), fp.text4.as<uint64_t>(), fp.sarec.as<SaRec>());
         HIPCHK(ctx, hipDeviceSynchronize());
         fp.sarec_k = k;
+        // the interval table with row l's record in its entries: 32 bytes per q-mer, when that is a small part of what is free
+        static const bool env_no_ftabx = getenv("PSIGPU_NO_FTABX") != nullptr;      // A/B
+        const uint64_t n_ent = 1ull << (2 * fp.ftab_len);
+        size_t free_b = 0, total_b = 0;
+        if (!env_no_ftabx && hipMemGetInfo(&free_b, &total_b) == hipSuccess && n_ent * sizeof(FtabX) * 4 < free_b &&
+            fp.ftabx.ensure(n_ent * sizeof(FtabX)) == hipSuccess) {
+          k_build_ftabx<<<(unsigned)((n_ent + 255) / 256), 256>>>(fp.ftab.as<uint2>(), n_ent, fp.sarec.as<SaRec>(), fp.ftabx.as<FtabX>());
+          HIPCHK(ctx, hipDeviceSynchronize());
+          fp.ftabx_k = k;
+        } else {
+          (void)hipGetLastError();
+          fp.ftabx.release();
+        }
       } else {
         (void)hipGetLastError();
         fp.sarec.release();
@@ -3343,7 +3385,7 @@ static int build_row_records(psigpu_ctx* ctx, uint32_t k)
 // the row records of every part, dropped (room for the k-mer table; psigpu_set_tuning)
 static void drop_row_records(psigpu_ctx* ctx)
 {
-  for (auto& pp : ctx->parts) { pp->sarec.release(); pp->saloc.release(); pp->sarec_k = 0; pp->have_saloc = false; }
+  for (auto& pp : ctx->parts) { pp->sarec.release(); pp->saloc.release(); pp->ftabx.release(); pp->sarec_k = pp->ftabx_k = 0; pp->have_saloc = false; }
   ctx->rows_tried = false;
 }
 
@@ -4078,7 +4120,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
               if (p) HIPCHK(ctx, hipMemsetAsync(&ctr->n_defer.v, 0, 8, stream));
               const bool ride = probe && p == 0;            // the locus-table probe rides in the first part's kernel
               k_fm_search_direct<<<grid, 256, 0, stream>>>(
-                  fm, ride ? lk : LktView{ nullptr, 0, nullptr }, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1, so,
+                  fm, ctx->parts[p]->ftabx_k == k ? ctx->parts[p]->ftabx.as<FtabX>() : nullptr,
+                  ride ? lk : LktView{ nullptr, 0, nullptr }, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1, so,
                   tiles_of(p), ride ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, ctx->w_defer.as<uint32_t>(), ctr);
               k_fm_search<true, uint64_t><<<256, 256, 0, stream>>>(fm, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave, k, thr_k1,
                                                    so.iv_lo, so.iv_cnt, so.iv_aux, tiles_of(p), ctr,
