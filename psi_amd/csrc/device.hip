@@ -324,6 +324,13 @@ __global__ void __launch_bounds__(256) k_publish(const uint4* __restrict__ src, 
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
 
+// read offsets of a sub-batch, straight from the caller's (pinned) array: out[i] = in[i] - in[0]
+__global__ void __launch_bounds__(256) k_rebase_offsets(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n)
+{
+  const uint64_t b0 = in[0];
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = in[i] - b0;
+}
+
 // ------------------------------------------------------------------------------------
 // K0: seeding
 // ------------------------------------------------------------------------------------
@@ -2794,6 +2801,7 @@ struct psigpu_ctx {
   std::string lkt_note;
   DevBuf w_seedout, w_seedres, w_iv_tiles_off, w_defer, w_hit_a, w_hit_seed;
   // per-call workspace (grow-only)
+  DevBuf in_bases;                 // host entry, reads in pinned memory: the chunk's reads (transfers queued ahead of the compute loop)
   DevBuf w_bases, w_read_off, w_cnt, w_tiles, w_seed_off, w_seed_key, w_seed_info,
       w_seed_next, w_ht, w_pfx, w_pfx12, w_iv_lo, w_iv_cnt, w_iv_aux, w_hit_off, w_iv_tiles,
       w_chunks, w_chunk_fill, w_chunk_off, w_chunk_tiles, w_hits, w_spill_a, w_spill_b, w_ctr, w_total,
@@ -2829,10 +2837,11 @@ struct psigpu_ctx {
   // the pipeline's transfers, each direction on a copy engine of its own (see pipeline_init)
   struct EngineCopy {
     bool ok = false;
-    int n_sig = 0;                               // signals taken from the process-wide pool: sig_in[0..1], then sig_out[0..1]
+    int n_sig = 0;                               // signals taken from the process-wide pool: sig_in[0..IN_RING-1], then sig_out[0..1]
+    static constexpr int IN_RING = 8;            // transfers of reads that may be queued ahead of the compute loop
     hsa_agent_t gpu{}, cpu{};
     uint32_t eng_in = 0, eng_out = 0;            // hsa_amd_sdma_engine_id_t bits
-    hsa_signal_t sig_in[2]{}, sig_out[2]{};      // per slot: 1 while the slot's transfer is in flight
+    hsa_signal_t sig_in[IN_RING]{}, sig_out[2]{};      // 1 while the transfer is in flight (two-slot path: sig_in[0..1])
   } ec;
   double hits_per_read_hint = 0.0;
 };
@@ -2990,7 +2999,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
   ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release();
   for (DevBuf* b : { &ctx->w_sb_cnt, &ctx->w_sb_off, &ctx->w_sb_tiles, &ctx->w_sb_key, &ctx->w_seed_wide, &ctx->w_seed_pfx }) b->release();
   for (auto& m : ctx->parts) m->release();
-  ctx->w_hits_alt.release();
+  ctx->w_hits_alt.release(); ctx->in_bases.release();
   for (auto& sl : ctx->slot) {
     sl.bases.release(); sl.off.release(); sl.d_wire.release();
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
@@ -2999,7 +3008,8 @@ void psigpu_destroy(psigpu_ctx* ctx)
     if (sl.out_done) (void)hipEventDestroy(sl.out_done);
   }
   for (hipStream_t st : { ctx->s_in, ctx->s_comp, ctx->s_out }) if (st) (void)hipStreamDestroy(st);
-  for (int i = 0; i < ctx->ec.n_sig; ++i) g_hsa.give(i < 2 ? ctx->ec.sig_in[i] : ctx->ec.sig_out[i - 2]);      // (kept for the next context)
+  for (int i = 0; i < ctx->ec.n_sig; ++i)      // (kept for the next context)
+    g_hsa.give(i < psigpu_ctx::EngineCopy::IN_RING ? ctx->ec.sig_in[i] : ctx->ec.sig_out[i - psigpu_ctx::EngineCopy::IN_RING]);
   if (ctx->have_events) for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -4691,8 +4701,9 @@ static void engine_copy_init(psigpu_ctx* ctx)
   uint32_t rest = mask_out & ~ec.eng_in;
   if (rest == 0) return;                                      // a single engine: nothing to separate
   ec.eng_out = rest & (~rest + 1);
-  for (int i = 0; i < 4; ++i) {
-    if (!g_hsa.take(i < 2 ? &ec.sig_in[i] : &ec.sig_out[i - 2])) return;
+  constexpr int R = psigpu_ctx::EngineCopy::IN_RING;
+  for (int i = 0; i < R + 2; ++i) {
+    if (!g_hsa.take(i < R ? &ec.sig_in[i] : &ec.sig_out[i - R])) return;
     ec.n_sig = i + 1;
   }
   ec.ok = true;
@@ -4763,6 +4774,17 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   // (PSIGPU_SUB_BYTES: tests force many sub-batches on small inputs)
   const char* sub_env = getenv("PSIGPU_SUB_BYTES");
   const uint64_t SUB_BYTES = sub_env ? std::max<uint64_t>(1, strtoull(sub_env, nullptr, 10)) : (16ull << 20);
+  { int st = pipeline_init(ctx); if (st != PSIGPU_OK) return st; }
+  // Reads AND offsets in pinned memory (psi::Records of the shim, psikt): the chunk's reads go to one device buffer
+  // and their transfers are queued up to IN_RING sub-batches ahead of the compute loop, so that the copy engine
+  // never waits for the host thread between two of them (with two slots it does whenever a sub-batch's kernels,
+  // sort and synchronisations take longer than its transfer); the offsets are rebased by a kernel that reads the
+  // caller's array in place.  150 calls of either path alternated in one process (tools/e2e_ab3.py; the boxes are
+  // shared and a call varies between 3.6 and 5.3 ms): median 4.37 ms against 4.56, minimum 3.64 against 3.80.
+  ptrdiff_t pin_delta = 0, off_delta = 0;
+  const bool pinned_in = n_bases == 0 || host_ptr_is_pinned(bases, &pin_delta);
+  const bool env_no_ahead = getenv("PSIGPU_NO_AHEAD") != nullptr;      // A/B: the two-slot path (read per call: tools/e2e_ab3.py alternates)
+  const bool ahead_ok = pinned_in && n_bases && ctx->ec.ok && !env_no_ahead && host_ptr_is_pinned(read_off, &off_delta);
   std::vector<uint64_t> cut{ 0 };
   {
     // piece sizes in bytes of bases: SUB/8, SUB/4, SUB/2, SUB ... SUB -- small at the start: what precedes the first
@@ -4779,6 +4801,9 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     if (pieces.size() > n_head + 1 && pieces.back() < SUB_BYTES / 4) {      // no tiny tail
       const uint64_t t = pieces.back(); pieces.pop_back(); pieces.back() += t;
     }
+    // (With the reads' transfers queued ahead -- below -- small pieces at the end were tried again: SUB/2, SUB/4, SUB/4
+    // instead of the last full piece.  150 calls of each variant alternated in one process, tools/e2e_ab3.py: median
+    // 4.53 ms against 4.37 without, minimum 3.56 against 3.64: not kept.)
     uint64_t target = 0;
     for (size_t pi = 0; pi < pieces.size() && cut.back() < n_reads; ++pi) {
       target += pieces[pi];
@@ -4790,9 +4815,23 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     if (cut.back() < n_reads) cut.push_back(n_reads);
   }
   const size_t n_sub = cut.size() - 1;
-  ptrdiff_t pin_delta = 0;
-  const bool pinned_in = n_bases == 0 || host_ptr_is_pinned(bases, &pin_delta);
-  { int st = pipeline_init(ctx); if (st != PSIGPU_OK) return st; }
+  const bool ahead = ahead_ok && n_sub > 1;
+  constexpr size_t IN_RING = psigpu_ctx::EngineCopy::IN_RING;
+  size_t issued = 0;
+  auto issue_in = [&](size_t j) -> bool {
+    const uint64_t b0 = read_off[cut[j]], nb = read_off[cut[j + 1]] - b0;
+    if (nb == 0) { hsa_signal_store_relaxed(ctx->ec.sig_in[j % IN_RING], 0); return true; }
+    return engine_copy(ctx, true, (char*)ctx->in_bases.p + b0, bases + pin_delta + b0, nb, ctx->ec.sig_in[j % IN_RING]);
+  };
+  if (ahead) {
+    HIPCHK(ctx, ctx->in_bases.ensure(n_bases + 64));
+    for (; issued < std::min(n_sub, IN_RING); ++issued)
+      if (!issue_in(issued)) {
+        for (size_t j = 0; j < issued; ++j) engine_wait(ctx->ec.sig_in[j]);
+        ctx->err = "staging the reads: engine copy failed";
+        return PSIGPU_ERR_DEVICE;
+      }
+  }
 
   std::function<void(int)> trace_in;
   // staging of sub-batch j into slot j % 2 and its H2D on the copy-in stream
@@ -4861,6 +4900,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   psigpu_hit* hp = nullptr;
   Widener* wd = nullptr;                            // set once the widener runs: hp must not move or go while it writes
   auto fail = [&](int st) {
+    if (ahead) for (size_t j = 0; j < IN_RING; ++j) engine_wait(ctx->ec.sig_in[j]);      // transfers of reads still queued
     if (wd) wd->wait_finished(wd->posted.load());
     if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }      // transfers into hp still in flight
     else if (ctx->s_out) (void)hipStreamSynchronize(ctx->s_out);
@@ -4914,7 +4954,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   }
   bool host_sort = false;            // some sub-batch did not fit the device sorter's key
   hipStream_t sc = ctx->s_comp;
-  if (!use_thread) {
+  if (!use_thread && !ahead) {
     hipError_t e = stage_in(0);
     if (e != hipSuccess) { ctx->err = std::string("staging the reads: ") + hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
   }
@@ -4926,12 +4966,20 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
         ctx->err = std::string("staging the reads: ") + hipGetErrorString((hipError_t)stage_err.load());
         return fail(PSIGPU_ERR_DEVICE);
       }
+    } else if (ahead) {
+      // (signal j % IN_RING was last used by sub-batch j - IN_RING, waited for below IN_RING iterations ago)
+      for (; issued < std::min(n_sub, i + IN_RING); ++issued)
+        if (!issue_in(issued)) { ctx->err = "staging the reads: engine copy failed"; return fail(PSIGPU_ERR_DEVICE); }
     } else if (i + 1 < n_sub) {
       hipError_t e = stage_in(i + 1);           // slot (i + 1) & 1: its last user, sub-batch i - 1, has been synchronised
       if (e != hipSuccess) { ctx->err = std::string("staging the reads: ") + hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
     }
     const uint64_t r0 = cut[i], nr = cut[i + 1] - r0, nb = read_off[cut[i + 1]] - read_off[r0];
-    if (ctx->ec.ok) {
+    if (ahead) {
+      if (sl.off.ensure((nr + 1) * 8) != hipSuccess) { ctx->err = "out of device memory (read offsets)"; return fail(PSIGPU_ERR_NOMEM); }
+      engine_wait(ctx->ec.sig_in[i % IN_RING]);
+      if (i >= 2) engine_wait(ctx->ec.sig_out[i & 1]);
+    } else if (ctx->ec.ok) {
       engine_wait(ctx->ec.sig_in[i & 1]);
       if (i >= 2) engine_wait(ctx->ec.sig_out[i & 1]);    // the hit buffer about to be written was the source of the D2H two sub-batches ago
     } else {
@@ -4940,9 +4988,12 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     }
     uint64_t n = 0;
     if (trace) { tr.push_back(now_ms() - t_call); tmark(sc); }
-    k_publish<<<64, 256, 0, sc>>>(reinterpret_cast<const uint4*>(sl.h_stage_dev), sl.off.as<uint4>(), (uint32_t)(((nr + 1) * 8 + 15) / 16));
+    if (ahead)
+      k_rebase_offsets<<<64, 256, 0, sc>>>(reinterpret_cast<const uint64_t*>((const char*)(read_off + r0) + off_delta), sl.off.as<uint64_t>(), nr + 1);
+    else
+      k_publish<<<64, 256, 0, sc>>>(reinterpret_cast<const uint4*>(sl.h_stage_dev), sl.off.as<uint4>(), (uint32_t)(((nr + 1) * 8 + 15) / 16));
     if (wire16 && i >= 2) widener.wait_finished(i - 1);          // the slot's landing buffer: job i - 2 has been widened
-    int st = run_pipeline(ctx, sl.bases.as<char>(), sl.off.as<uint64_t>(), nr, nb, k, step, rec_offset + r0,
+    int st = run_pipeline(ctx, ahead ? (const char*)ctx->in_bases.p + read_off[r0] : sl.bases.as<char>(), sl.off.as<uint64_t>(), nr, nb, k, step, rec_offset + r0,
                           flags | ((want_sort && !host_sort && getenv("PSIGPU_NO_GROUPED_SORT") == nullptr) ? PSIGPU_SORT_UNIQUE : 0u), sc, &n,
                           wire16 ? &sl.d_wire : nullptr);
     if (st != PSIGPU_OK) return fail(st);
