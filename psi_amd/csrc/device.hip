@@ -2708,16 +2708,31 @@ __global__ void __launch_bounds__(256) k_rand_loads(const uint4* __restrict__ t,
 // ------------------------------------------------------------------------------------
 // Host-side plumbing
 // ------------------------------------------------------------------------------------
+// PSIGPU_POISON=<byte> (debugging aid): every fresh device allocation is filled with that byte, so that a kernel reading
+// what nobody wrote gives the same wrong answer every time instead of whatever the memory held before
+static int poison_byte()
+{
+  static const int b = [] { const char* e = getenv("PSIGPU_POISON"); return e ? (int)(strtoul(e, nullptr, 0) & 0xFF) : -1; }();
+  return b;
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  // uncached: device memory the GPU's L2 does not keep (MTYPE UC) -- for buffers that a copy ENGINE writes or reads
+  // behind the runtime's back (hsa_amd_memory_async_copy_on_engine in the host entry): HIP orders its own copies
+  // against kernels with cache invalidates / write-backs, it knows nothing of these, and a line of the buffer's
+  // previous contents left in an XCD's L2 would be read instead of what the engine just wrote
+  bool uncached = false;
   hipError_t ensure(size_t bytes)
   {
     if (bytes <= cap) return hipSuccess;
     if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
+    hipError_t e = hipErrorUnknown;
+    if (uncached) { e = hipExtMallocWithFlags(&p, want, hipDeviceMallocUncached); if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; } }
+    if (e != hipSuccess) e = hipMalloc(&p, want);
+    if (e == hipSuccess) { cap = want; if (poison_byte() >= 0) { (void)hipMemset(p, poison_byte(), want); (void)hipDeviceSynchronize(); } }
     return e;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -2728,7 +2743,13 @@ struct TmpBuf {           // scoped device allocation (table construction)
   void* p = nullptr;
   ~TmpBuf() { drop(); }
   void drop() { if (p) (void)hipFree(p); p = nullptr; }
-  hipError_t alloc(size_t bytes) { drop(); return hipMalloc(&p, bytes ? bytes : 16); }
+  hipError_t alloc(size_t bytes)
+  {
+    drop();
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e == hipSuccess && poison_byte() >= 0) { (void)hipMemset(p, poison_byte(), bytes ? bytes : 16); (void)hipDeviceSynchronize(); }
+    return e;
+  }
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -2973,6 +2994,10 @@ psigpu_ctx* psigpu_create(int device)
   if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
   psigpu_ctx* ctx = new psigpu_ctx;
   ctx->device = device;
+  if (!getenv("PSIGPU_CACHED_IO")) {            // (A/B) the buffers the copy engines write / read
+    ctx->in_bases.uncached = true;
+    for (auto& sl : ctx->slot) { sl.bases.uncached = true; sl.d_wire.uncached = true; }
+  }
   ctx->parts.emplace_back(new psigpu_ctx::FmPart);
   for (auto& ev : ctx->ev)
     if (hipEventCreate(&ev) != hipSuccess) { g_create_err = "hipEventCreate failed"; delete ctx; return nullptr; }
@@ -4293,6 +4318,10 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     for (int i = 0; i < STRIPES; ++i) ctx->last_max_read_len = std::max<uint64_t>(ctx->last_max_read_len, h.max_read_len.s[i].v);
     if (true_seeds > n_seeds) { ctx->err = "n_bases does not cover the reads"; return PSIGPU_ERR_ARG; }
     total_hits = h.n_hits_tab.v + h.n_hits_off.v;
+    if (getenv("PSIGPU_DEBUG"))
+      fprintf(stderr, "[psigpu] attempt %d: seeds %llu of %llu, hits on %llu tab %llu off %llu, chunks %llu of %llu, spill %llu, cap %llu (kprobe %d on %d off %d probe %d)\n",
+              attempt, (unsigned long long)true_seeds, (unsigned long long)n_seeds, h.n_hits_on.v, h.n_hits_tab.v, h.n_hits_off.v, h.n_chunks.v,
+              (unsigned long long)cap_chunks, h.n_spill.v, (unsigned long long)cap, (int)kprobe, (int)on_paths, (int)off_paths, (int)probe);
     if (total_hits > cap) { overflow = true; cap = total_hits + total_hits / 16 + 1024; }
     if (!overflow) break;
     if (attempt == MAX_ATTEMPTS - 1) { ctx->err = "hit buffer / spill queue overflow"; return PSIGPU_ERR_NOMEM; }
@@ -4755,6 +4784,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
                       uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, psigpu_hits* out)
 {
   if (!ctx || !out || (n_reads && (!read_off))) return PSIGPU_ERR_ARG;
+  const auto t_entry = std::chrono::steady_clock::now();
   out->n = 0; out->data = nullptr;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if ((flags & PSIGPU_ALL) == 0) flags |= PSIGPU_ALL;
@@ -5079,6 +5109,8 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   else if (hipStreamSynchronize(ctx->s_out) != hipSuccess) { ctx->err = "hipStreamSynchronize (copy-out stream)"; return fail(PSIGPU_ERR_DEVICE); }
   if (wire16) widener.wait_finished(n_sub);
   if (trace) {
+    fprintf(stderr, "[psigpu] host entry: %.3f ms from entry to the first sub-batch\n",
+            t_call - std::chrono::duration<double, std::milli>(t_entry.time_since_epoch()).count());
     fprintf(stderr, "[psigpu] host entry: %zu sub-batches, %.3f ms; per sub-batch (ms since call): pipeline begin, end, D2H enqueue begin, end\n", n_sub, now_ms() - t_call);
     for (size_t j = 0; j + 3 < tr.size(); j += 4) fprintf(stderr, "[psigpu]   %.3f %.3f %.3f %.3f\n", tr[j], tr[j + 1], tr[j + 2], tr[j + 3]);
     (void)hipDeviceSynchronize();

@@ -25,7 +25,8 @@ hits = psi_amd.Hits()
 calls = [(f.ctx, psi_amd._ptr(p[0].array), psi_amd._ptr(p[1].array), 1_000_000, 21, 21, 0, psi_amd.ALL | psi_amd.SORT_UNIQUE, C.byref(hits)) for p in pin]
 variants = [('run-ahead, tapered tail', {}), ('run-ahead', {'PSIGPU_NO_TAPER': '1'}), ('two slots', {'PSIGPU_NO_AHEAD': '1'})]
 if len(sys.argv) > 1:
-    variants = [(a, dict(x.split('=') for x in a.split(',') if x)) for a in sys.argv[1:]]
+    # e.g.  "cached io,PSIGPU_CACHED_IO=1"  "default"
+    variants = [(a.split(',')[0], dict(x.split('=') for x in a.split(',')[1:] if '=' in x)) for a in sys.argv[1:]]
 times = {name: [] for name, _ in variants}
 for rnd in range(int(os.environ.get('ROUNDS', '40')) + 3):
     for name, env in variants:

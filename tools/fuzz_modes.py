@@ -111,7 +111,17 @@ def main():
                     f.set_path_index(px)
                     got = psi_amd.sort_unique(f.seeds_all(reads, step=step))
                     if not (got.shape == want.shape and (got == want).all()):
-                        print('MISMATCH', seed, k, step, npaths, mode, cap, got.shape, want.shape, flush=True)
+                        print('MISMATCH', seed, k, step, npaths, mode, cap, got.shape, want.shape, 'sa_rate', px.view.sa_rate, 'ftab', px.view.ftab_len,
+                              'patched', patched, f.counters(), flush=True)
+                        a, b = set(map(tuple, got.tolist())), set(map(tuple, want.tolist()))
+                        print(' extra', sorted(a - b)[:6], 'missing', sorted(b - a)[:6], flush=True)
+                        # the same finder again (a glitch of that call, or of what the finder built?), then a new finder
+                        again = psi_amd.sort_unique(f.seeds_all(reads, step=step))
+                        print(' same finder again:', 'ok' if (again.shape == want.shape and (again == want).all()) else 'WRONG AGAIN', flush=True)
+                        f3 = psi_amd.SeedFinder(pg, k, mode=mode, walk_cap=cap)
+                        f3.set_path_index(px)
+                        fresh = psi_amd.sort_unique(f3.seeds_all(reads, step=step))
+                        print(' new finder:', 'ok' if (fresh.shape == want.shape and (fresh == want).all()) else 'WRONG TOO', flush=True)
                         sys.exit(1)
                     if rng.random() < 0.5 and k <= 31:      # (the oracle's k-mers are one word)
                         # psikt -r T over BOTH phases against the oracle's seeds_all( gocc_thr = T ): on-path k-mers

@@ -6,10 +6,10 @@ mkdir -p gpurun_out
 pids=()
 for i in $(seq 0 $((N-1))); do
   a=$((F + i*1000)); b=$((a + E))
-  PSIGPU_SEGV_TRACE=1 FUZZ_TRACE=1 timeout ${FUZZ_TIMEOUT:-400} python tools/fuzz_modes.py $a $b > gpurun_out/fuzz_p$i.log 2>&1 &
+  PSIGPU_SEGV_TRACE=1 FUZZ_TRACE=1 timeout ${FUZZ_TIMEOUT:-400} python tools/fuzz_modes.py $a $b > gpurun_out/fuzz_${TAG:-r}_p$i.log 2>&1 &
   pids+=($!)
 done
 rc=0
 for p in "${pids[@]}"; do wait $p || rc=1; done
-for i in $(seq 0 $((N-1))); do echo "== p$i"; grep -v "^seed" gpurun_out/fuzz_p$i.log | tail -n 25; grep "^seed" gpurun_out/fuzz_p$i.log | tail -n 1; done
+for i in $(seq 0 $((N-1))); do echo "== p$i"; grep -v "^seed" gpurun_out/fuzz_${TAG:-r}_p$i.log | tail -n 70; grep "^seed" gpurun_out/fuzz_${TAG:-r}_p$i.log | tail -n 1; done
 exit $rc
