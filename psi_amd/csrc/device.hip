@@ -2719,10 +2719,8 @@ static int poison_byte()
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
-  // uncached: device memory the GPU's L2 does not keep (MTYPE UC) -- for buffers that a copy ENGINE writes or reads
-  // behind the runtime's back (hsa_amd_memory_async_copy_on_engine in the host entry): HIP orders its own copies
-  // against kernels with cache invalidates / write-backs, it knows nothing of these, and a line of the buffer's
-  // previous contents left in an XCD's L2 would be read instead of what the engine just wrote
+  // uncached: device memory the GPU's L2 does not keep (MTYPE UC); an experiment for the buffers that a copy ENGINE
+  // writes or reads behind the runtime's back (PSIGPU_UNCACHED_IO, see psigpu_create)
   bool uncached = false;
   hipError_t ensure(size_t bytes)
   {
@@ -2994,9 +2992,9 @@ psigpu_ctx* psigpu_create(int device)
   if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
   psigpu_ctx* ctx = new psigpu_ctx;
   ctx->device = device;
-  if (!getenv("PSIGPU_CACHED_IO")) {            // (A/B) the buffers the copy engines write / read
-    ctx->in_bases.uncached = true;
-    for (auto& sl : ctx->slot) { sl.bases.uncached = true; sl.d_wire.uncached = true; }
+  if (getenv("PSIGPU_UNCACHED_IO")) {           // experiment: the buffers the copy engines write / read as MTYPE UC memory
+    ctx->in_bases.uncached = true;              // (tried as the default against rare wrong records under load: a test that
+    for (auto& sl : ctx->slot) { sl.bases.uncached = true; sl.d_wire.uncached = true; }      // had never failed failed 3 times in 24 -- not kept)
   }
   ctx->parts.emplace_back(new psigpu_ctx::FmPart);
   for (auto& ev : ctx->ev)
