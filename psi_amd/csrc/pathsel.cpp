@@ -224,17 +224,63 @@ std::vector<Patch> cut_patches(const Graph& g, const std::vector<uint32_t>& walk
   // run[i]: the longest j - i + 1 such that walk[i..j] is a contiguous run of some earlier walk
   std::vector<uint32_t> run, cur;
   resize_populated(run, m); resize_populated(cur, m);
+  const bool sequential = getenv("PSIGPU_TEST_SEQ_PATCHES") != nullptr;      // tests: the one-thread formulation
   for (const auto& V : earlier) {
     // node -> its (first) position in V: a plain array over the nodes (a hash map of a whole-genome walk's
     // 300 M nodes took longer than everything else in the index build)
-    for (size_t q = V.size(); q-- > 0;) at[V[q]] = (uint32_t)q;
-    for (size_t i = m; i-- > 0;) {
-      const uint32_t q = at[walk[i]];
-      if (q == NO_NODE) { cur[i] = 0; continue; }
-      cur[i] = (i + 1 < m && (size_t)q + 1 < V.size() && V[q + 1] == walk[i + 1] && cur[i + 1]) ? cur[i + 1] + 1 : 1;
-      run[i] = std::max(run[i], cur[i]);
+    const int64_t nv = (int64_t)V.size(), mm = (int64_t)m;
+    bool increasing = !sequential;
+    if (increasing) {
+#pragma omp parallel for reduction(&& : increasing)
+      for (int64_t q = 1; q < nv; ++q) increasing = increasing && V[q - 1] < V[q];
     }
-    for (uint32_t v : V) at[v] = NO_NODE;
+    if (!increasing) {
+      for (size_t q = V.size(); q-- > 0;) at[V[q]] = (uint32_t)q;
+      for (size_t i = m; i-- > 0;) {
+        const uint32_t q = at[walk[i]];
+        if (q == NO_NODE) { cur[i] = 0; continue; }
+        cur[i] = (i + 1 < m && (size_t)q + 1 < V.size() && V[q + 1] == walk[i + 1] && cur[i + 1]) ? cur[i + 1] + 1 : 1;
+        run[i] = std::max(run[i], cur[i]);
+      }
+      for (uint32_t v : V) at[v] = NO_NODE;
+      continue;
+    }
+    // The same in parallel (V visits no node twice).  cur[i] = 1 + (link(i) ? cur[i + 1] : 0) for a node of V, where
+    // link(i) -- walk[i + 1] follows walk[i] in V -- depends on V and the walk alone: a run is a chain of links that
+    // ends in a node without one, and cur[i] is the distance to that node.  State per node (0 not in V, 1 no link,
+    // 2 link), then a backward pass per chunk that carries the position of the next state-1 node, seeded with the
+    // first such node behind the chunk.
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < nv; ++q) at[V[q]] = (uint32_t)q;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < mm; ++i) {
+      const uint32_t q = at[walk[i]];
+      cur[i] = q == NO_NODE ? 0u : ((i + 1 < mm && (int64_t)q + 1 < nv && V[q + 1] == walk[i + 1]) ? 2u : 1u);
+    }
+    const int64_t CH = 1 << 20, n_ch = (mm + CH - 1) / CH;
+    std::vector<int64_t> next_one(n_ch + 1, mm);        // first state-1 node at or behind the chunk's start
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < n_ch; ++c) {
+      const int64_t a = c * CH, b = std::min(mm, a + CH);
+      int64_t f = mm;
+      for (int64_t i = a; i < b; ++i) if (cur[i] == 1u) { f = i; break; }
+      next_one[c] = f;
+    }
+    for (int64_t c = n_ch - 1; c >= 0; --c) if (next_one[c] == mm) next_one[c] = next_one[c + 1];
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < n_ch; ++c) {
+      const int64_t a = c * CH, b = std::min(mm, a + CH);
+      int64_t carry = next_one[c + 1];
+      for (int64_t i = b; i-- > a;) {
+        const uint32_t st = cur[i];
+        if (st == 1u) carry = i;
+        const uint32_t v = st ? (uint32_t)(carry - i + 1) : 0u;
+        cur[i] = v;
+        if (v > run[i]) run[i] = v;
+      }
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < nv; ++q) at[V[q]] = NO_NODE;
   }
   // Windows start at x in [0, x_max]; the one starting in node i at x ends in the node holding base
   // x + c - 1, and is uncovered iff that node lies behind walk[i + run[i] - 1]

@@ -674,6 +674,35 @@ def test_path_text_is_assembled_in_pieces(monkeypatch, ref_data, name):
                 assert got == ref
 
 
+def test_patches_cut_in_parallel_equal_the_sequential_cut(monkeypatch, ref_data):
+    """cut_patches computes, per earlier walk, how far each node of the new walk continues a contiguous run of that
+    walk -- a backward recurrence; the parallel formulation (link states, chunked backward pass) gives the same patches,
+    head offsets and tail lengths as the one-thread recurrence (PSIGPU_TEST_SEQ_PATCHES), on the reference's graphs and
+    on an SNV graph with thousands of patches."""
+    from psi_amd import synth
+    cases = []
+    for name in ('x', 'multi', 'm'):
+        b, g = _setup(ref_data, name)
+        cases.append((g, 12, 6, 14))
+        cases.append((g, 21, 4, 21))
+    sg = synth.snv_graph(400_000, 12_000, n_block=30_000, seed=7)
+    cases.append((psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path]), 21, 5, 24))
+    n_patches = 0
+    for g, k, n, ctx in cases:
+        got = []
+        for seq in (False, True):
+            if seq:
+                monkeypatch.setenv('PSIGPU_TEST_SEQ_PATCHES', '1')
+            else:
+                monkeypatch.delenv('PSIGPU_TEST_SEQ_PATCHES', raising=False)
+            px = psi_amd.PathIndex.build(g, k, n, rng_seed=4, patched=True, context=ctx)
+            got.append(([p.tolist() for p in px.paths()], px.trims()))
+        assert got[0] == got[1]
+        n_patches = max(n_patches, len(got[0][0]) - n)
+    assert n_patches > 1000                     # (the SNV graph: thousands of patches, trimmed)
+    monkeypatch.delenv('PSIGPU_TEST_SEQ_PATCHES', raising=False)
+
+
 def test_index_argument_checks(ref_data):
     b, g = _setup(ref_data, 'tiny')
     with pytest.raises(psi_amd.PsiGpuError):
