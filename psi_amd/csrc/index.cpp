@@ -59,28 +59,34 @@ inline void mark(uint64_t* unc, uint32_t lo, uint32_t hi)      // bits lo .. hi 
 // The walk has spelled S bases behind its first node and now enters u; `state` = the steps the walk is
 // still a run of, standing on the node before u.  Marks in `unc` (bit i = need i) every extension
 // length for which an uncovered walk exists.
-void explore(const LociCtx& c, uint32_t u, uint32_t S, const std::vector<uint32_t>& state, uint64_t* unc, uint32_t depth)
+void explore(const LociCtx& c, uint32_t u, uint32_t S, const uint32_t* state, size_t n_state, uint64_t* unc, uint32_t depth)
 {
   if (depth > 4 * c.k) return;      // guards cycles of empty nodes
   const uint32_t len = (uint32_t)c.g.node_len(u);
-  std::vector<uint32_t> next;
+  // the candidate steps that go on through u: at most as many as there were, nearly always a handful -- kept on the
+  // stack (a heap vector per call made 128 threads queue at the allocator: 4.4 s for 300 M nodes)
+  uint32_t small[32];
+  std::vector<uint32_t> big;
+  uint32_t* next = small;
+  if (n_state > 32) { big.resize(n_state); next = big.data(); }
+  size_t n_next = 0;
   uint32_t hi_max = 0;              // most bases of u any candidate path still spells
-  for (uint32_t s : state) {
-    const uint32_t t = s + 1;       // (s is never the last step of its path)
+  for (size_t i = 0; i < n_state; ++i) {
+    const uint32_t t = state[i] + 1;       // (a candidate is never the last step of its path)
     if (c.step_node[t] != u) continue;
     hi_max = std::max(hi_max, c.step_hi[t]);
-    if (!c.step_last[t]) next.push_back(t);
+    if (!c.step_last[t]) next[n_next++] = t;
   }
   const uint32_t kmax = c.k - 1;    // needs are 1 .. k-1
   // needs that end inside u: covered while some candidate spells that many of u's bases
   if (len && S + hi_max < kmax && hi_max < len) mark(unc, S + hi_max + 1, std::min(kmax, S + len));
   const uint32_t S2 = S + len;
   if (S2 >= kmax) return;
-  if (next.empty()) {               // every longer walk through u is uncovered
+  if (n_next == 0) {                // every longer walk through u is uncovered
     if (c.child[u]) mark(unc, S2 + 1, std::min(kmax, S2 + c.child[u]));
     return;
   }
-  for (uint64_t e = c.g.edge_off[u]; e < c.g.edge_off[u + 1]; ++e) explore(c, c.g.edge_to[e], S2, next, unc, depth + 1);
+  for (uint64_t e = c.g.edge_off[u]; e < c.g.edge_off[u + 1]; ++e) explore(c, c.g.edge_to[e], S2, next, n_next, unc, depth + 1);
 }
 
 }  // namespace
@@ -196,7 +202,7 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
         uint64_t unc = 0;
         if (state.empty()) { if (c.child[v]) mark(&unc, 1, std::min(k - 1, c.child[v])); }
         else
-          for (uint64_t e = g.edge_off[v]; e < g.edge_off[v + 1]; ++e) explore(c, g.edge_to[e], 0, state, &unc, 0);
+          for (uint64_t e = g.edge_off[v]; e < g.edge_off[v + 1]; ++e) explore(c, g.edge_to[e], 0, state.data(), state.size(), &unc, 0);
         unc_of[h] = unc;
       }
       uint32_t since = 0;            // locus subsampling (psikt -e): every step-th starting locus per node
