@@ -2944,10 +2944,64 @@ PinnedPool g_pinned;
     }                                                                                        \
   } while (0)
 
+// A large array of ordinary (pageable) host memory to the device: hipMemcpy stages such a copy on one thread
+// (6-10 GB/s: a whole-genome index, 45 GB, took 7 of the 11 s of psigpu_load_index); here a few threads copy
+// 32-MiB pieces into two pinned buffers while the previous piece is on its way.
+static void copy_on_threads(char* dst, const char* src, size_t n)
+{
+  const unsigned hw = std::thread::hardware_concurrency();
+  const unsigned parts = (unsigned)std::min<size_t>(std::min<unsigned>(8, hw ? hw : 1), std::max<size_t>(1, n / (2u << 20)));
+  if (parts <= 1) { memcpy(dst, src, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n / parts + 63) & ~(size_t)63;
+  for (unsigned t = 1; t < parts; ++t) {
+    const size_t a = std::min(n, t * per), b = std::min(n, (t + 1) * per);
+    th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
+  }
+  memcpy(dst, src, std::min(n, per));
+  for (auto& t : th) t.join();
+}
+
+static int upload_large(psigpu_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  constexpr size_t PIECE = 32u << 20;
+  struct Stage {
+    void* buf[2] = { nullptr, nullptr };
+    hipEvent_t done[2] = { nullptr, nullptr };
+    hipStream_t s = nullptr;
+    ~Stage()
+    {
+      for (int i = 0; i < 2; ++i) { if (buf[i]) (void)hipHostFree(buf[i]); if (done[i]) (void)hipEventDestroy(done[i]); }
+      if (s) (void)hipStreamDestroy(s);
+    }
+  } st;
+  bool ok = hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && ok; ++i)
+    ok = hipHostMalloc(&st.buf[i], PIECE, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&st.done[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {                                        // no pinned memory to spare: the plain copy
+    (void)hipGetLastError();
+    HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return PSIGPU_OK;
+  }
+  size_t piece = 0;
+  for (size_t off = 0; off < bytes; off += PIECE, ++piece) {
+    const size_t len = std::min(PIECE, bytes - off);
+    const int i = (int)(piece & 1);
+    if (piece >= 2) HIPCHK(ctx, hipEventSynchronize(st.done[i]));
+    copy_on_threads((char*)st.buf[i], (const char*)src + off, len);
+    HIPCHK(ctx, hipMemcpyAsync((char*)dst + off, st.buf[i], len, hipMemcpyHostToDevice, st.s));
+    HIPCHK(ctx, hipEventRecord(st.done[i], st.s));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(st.s));
+  return PSIGPU_OK;
+}
+
 template <typename T>
 static int upload(psigpu_ctx* ctx, DevBuf& b, const T* src, uint64_t n, uint64_t pad_elems = 0)
 {
   HIPCHK(ctx, b.ensure((n + pad_elems) * sizeof(T) + 16));
+  if (n * sizeof(T) >= (64u << 20)) { int st = upload_large(ctx, b.p, src, n * sizeof(T)); if (st != PSIGPU_OK) return st; }
+  else
   if (n) HIPCHK(ctx, hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
   if (pad_elems) HIPCHK(ctx, hipMemset((char*)b.p + n * sizeof(T), 0, pad_elems * sizeof(T)));
   return PSIGPU_OK;
@@ -3228,7 +3282,8 @@ static int build_row_records(psigpu_ctx* ctx, uint32_t k);
 static int upload_segments(psigpu_ctx* ctx, const psigpu_index_view* x, const std::vector<uint64_t>& ids, DevBuf& seg,
                            DevBuf& seg_dir, DevBuf& seg_rank)
 {
-  std::vector<SegRec> segs(x->n_segs + 1);
+  std::vector<SegRec> segs;
+  psigpu::resize_populated(segs, x->n_segs + 1);
   std::atomic<bool> foreign{ false };
   const uint64_t n_nodes = ctx->n_nodes;
   parallel_for(x->n_segs, 1u << 16, [&](uint64_t i0, uint64_t i1) {      // (300 M segments at whole-genome size)
