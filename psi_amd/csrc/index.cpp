@@ -113,16 +113,25 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
   resize_populated(c.child, n);
   // reach: fixed point of reach(u) = min(k, len(u) + max_child reach(child)); len 0 nodes allowed
   for (uint64_t v = 0; v < n; ++v) c.reach[v] = (uint32_t)std::min<uint64_t>(k, g.node_len((uint32_t)v));
+  // (sweeps from the last node to the first, chunks of nodes in parallel: a chunk may read a neighbour's value of
+  // the sweep before -- values only grow towards the one least fixed point, and the loop ends with a sweep in which
+  // nothing changed, whose `child` values are therefore final.  A walk of k bases reaches a handful of nodes ahead,
+  // so stale values matter at chunk borders only: two or three sweeps.)
   bool changed = true;
+  const int64_t RCH = 1 << 18, n_rch = ((int64_t)n + RCH - 1) / RCH;
   while (changed) {
     changed = false;
-    for (uint64_t v = n; v-- > 0;) {
-      uint32_t best = 0;
-      for (uint64_t e = g.edge_off[v]; e < g.edge_off[v + 1]; ++e)
-        best = std::max(best, c.reach[g.edge_to[e]]);
-      uint32_t r = (uint32_t)std::min<uint64_t>(k, g.node_len((uint32_t)v) + best);
-      c.child[v] = best;
-      if (r > c.reach[v]) { c.reach[v] = r; changed = true; }
+#pragma omp parallel for schedule(dynamic, 1) reduction(|| : changed)
+    for (int64_t ch = n_rch - 1; ch >= 0; --ch) {
+      const uint64_t v0 = (uint64_t)ch * RCH, v1 = std::min<uint64_t>(n, v0 + RCH);
+      for (uint64_t v = v1; v-- > v0;) {
+        uint32_t best = 0;
+        for (uint64_t e = g.edge_off[v]; e < g.edge_off[v + 1]; ++e)
+          best = std::max(best, __atomic_load_n(&c.reach[g.edge_to[e]], __ATOMIC_RELAXED));
+        uint32_t r = (uint32_t)std::min<uint64_t>(k, g.node_len((uint32_t)v) + best);
+        c.child[v] = best;
+        if (r > c.reach[v]) { __atomic_store_n(&c.reach[v], r, __ATOMIC_RELAXED); changed = true; }
+      }
     }
   }
   lap("reach");
