@@ -239,13 +239,15 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
     }
   }
   lap("nodes");
-  uint64_t total = 0;
-  for (auto& v : bn) total += v.size();
-  loci_node.reserve(total);
-  loci_off.reserve(total);
-  for (uint64_t b = 0; b < n_blk; ++b) {
-    loci_node.insert(loci_node.end(), bn[b].begin(), bn[b].end());
-    loci_off.insert(loci_off.end(), bo[b].begin(), bo[b].end());
+  std::vector<uint64_t> at_blk(n_blk + 1, 0);
+  for (uint64_t b = 0; b < n_blk; ++b) at_blk[b + 1] = at_blk[b] + bn[b].size();
+  const uint64_t total = at_blk[n_blk];
+  resize_populated(loci_node, total);
+  resize_populated(loci_off, total);
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t b = 0; b < (int64_t)n_blk; ++b) {
+    std::copy(bn[b].begin(), bn[b].end(), loci_node.begin() + at_blk[b]);
+    std::copy(bo[b].begin(), bo[b].end(), loci_off.begin() + at_blk[b]);
     std::vector<uint32_t>().swap(bn[b]);
     std::vector<uint32_t>().swap(bo[b]);
   }

@@ -352,6 +352,7 @@ void pick_paths(const Graph& g, uint32_t n_per_region, bool patched, uint32_t co
         const auto t2 = std::chrono::steady_clock::now();
         const std::vector<Patch> pt = cut_patches(g, walk, walks, context, at);
         const auto t3 = std::chrono::steady_clock::now();
+        out.reserve(out.size() + pt.size()); head.reserve(head.size() + pt.size()); tail.reserve(tail.size() + pt.size());
         for (const Patch& p : pt) {
           out.emplace_back(walk.begin() + p.first, walk.begin() + p.last + 1);
           head.push_back(p.head); tail.push_back(p.tail);
