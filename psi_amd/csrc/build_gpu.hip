@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host.hpp"
@@ -216,6 +217,63 @@ int scan_u32(uint32_t* in, uint32_t* out, size_t n, bool exclusive_sum, Buf& tmp
 
 // T: the text in builder coding (0 sentinel, 1 separator, 2..5 ACGT), sentinel last.
 // Fills x->blocks, samples, exc_row, exc_sa, C, ftab, text4 (and *sa_out when requested).
+// A large array from the device into ordinary (pageable) host memory: hipMemcpy moves such a copy through one staging
+// thread (a whole-genome part, 33 GB of suffix array, interval table, rank blocks and text, took several seconds);
+// here 32-MiB pieces land in two pinned buffers and a few threads copy each into place while the next one is on
+// its way.  Small arrays and any failure to get pinned memory: the plain copy.
+static hipError_t download(void* dst, const void* src, size_t bytes)
+{
+  constexpr size_t PIECE = 32u << 20;
+  if (bytes < 2 * PIECE) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+  struct Stage {
+    void* buf[2] = { nullptr, nullptr };
+    hipEvent_t done[2] = { nullptr, nullptr };
+    hipStream_t s = nullptr;
+    ~Stage()
+    {
+      if (s) (void)hipStreamSynchronize(s);       // (an error path may leave a piece in flight)
+      for (int i = 0; i < 2; ++i) { if (buf[i]) (void)hipHostFree(buf[i]); if (done[i]) (void)hipEventDestroy(done[i]); }
+      if (s) (void)hipStreamDestroy(s);
+    }
+  } st;
+  bool ok = hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && ok; ++i)
+    ok = hipHostMalloc(&st.buf[i], PIECE, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&st.done[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); }
+  hipError_t e = hipDeviceSynchronize();          // (the producers ran on the default stream)
+  if (e != hipSuccess) return e;
+  auto copy_out = [&](size_t piece) {             // pinned piece -> its place, on a few threads
+    const size_t off = piece * PIECE, len = std::min(PIECE, bytes - off);
+    const char* from = (const char*)st.buf[piece & 1];
+    char* to = (char*)dst + off;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned parts = std::min<unsigned>(8, hw ? hw : 1);
+    std::vector<std::thread> th;
+    const size_t per = (len / parts + 63) & ~(size_t)63;
+    for (unsigned t = 1; t < parts; ++t) {
+      const size_t a = std::min(len, t * per), b = std::min(len, (t + 1) * per);
+      if (b > a) th.emplace_back([=] { memcpy(to + a, from + a, b - a); });
+    }
+    memcpy(to, from, std::min(len, per));
+    for (auto& t : th) t.join();
+  };
+  const size_t n_pieces = (bytes + PIECE - 1) / PIECE;
+  for (size_t piece = 0; piece <= n_pieces; ++piece) {
+    if (piece < n_pieces) {                       // start piece `piece` (its buffer was emptied two iterations ago)
+      const size_t off = piece * PIECE, len = std::min(PIECE, bytes - off);
+      e = hipMemcpyAsync(st.buf[piece & 1], (const char*)src + off, len, hipMemcpyDeviceToHost, st.s);
+      if (e == hipSuccess) e = hipEventRecord(st.done[piece & 1], st.s);
+      if (e != hipSuccess) return e;
+    }
+    if (piece >= 1) {                             // while it is on its way, piece - 1 goes into place
+      e = hipEventSynchronize(st.done[(piece - 1) & 1]);
+      if (e != hipSuccess) return e;
+      copy_out(piece - 1);
+    }
+  }
+  return hipSuccess;
+}
+
 int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, int device, Index* x,
                  std::vector<int32_t>* sa_out, std::string* err)
 {
@@ -278,7 +336,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
   GB_CHK(hipDeviceSynchronize());
   if (sa_out && n < 0x7FFFFFF0u) {
     resize_populated(*sa_out, n);
-    GB_CHK(hipMemcpy(sa_out->data(), sa_cur, (size_t)n * 4, hipMemcpyDeviceToHost));
+    GB_CHK(download(sa_out->data(), sa_cur, (size_t)n * 4));
   }
 
   {
@@ -313,7 +371,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
   x->exc_super.resize(n_super);
   GB_CHK(hipMemcpy(x->exc_super.data(), dsuper.p, n_super * 4, hipMemcpyDeviceToHost));
   resize_populated(x->blocks, nblk);
-  GB_CHK(hipMemcpy(x->blocks.data(), dblocks.p, (size_t)nblk * sizeof(RankBlock), hipMemcpyDeviceToHost));
+  GB_CHK(download(x->blocks.data(), dblocks.p, (size_t)nblk * sizeof(RankBlock)));
   x->exc_row.resize(totE); x->exc_sa.resize(totE);
   if (totE) {
     GB_CHK(hipMemcpy(x->exc_row.data(), dexc_row.p, totE * 4, hipMemcpyDeviceToHost));
@@ -330,12 +388,12 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
   const uint64_t nsamp = ((uint64_t)n + sa_rate - 1) / sa_rate;
   resize_populated(x->samples, nsamp);
   if (sa_rate == 1) {
-    GB_CHK(hipMemcpy(x->samples.data(), sa_cur, (size_t)n * 4, hipMemcpyDeviceToHost));
+    GB_CHK(download(x->samples.data(), sa_cur, (size_t)n * 4));
   } else {
     Buf ds;
     GB_CHK(ds.alloc(nsamp * 4));
     k_samples<<<grid_for(nsamp), 256>>>(sa_cur, n, sa_rate, ds.as<uint32_t>());
-    GB_CHK(hipMemcpy(x->samples.data(), ds.p, nsamp * 4, hipMemcpyDeviceToHost));
+    GB_CHK(download(x->samples.data(), ds.p, nsamp * 4));
   }
 
   // ---- interval table --------------------------------------------------------------------------------
@@ -348,7 +406,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
     GB_CHK(hipMemset(df.p, 0, entries * 8));
     k_ftab<<<g, 256>>>(dT.as<uint8_t>(), sa_cur, n, q, df.as<uint2>());
     resize_populated(x->ftab, 2 * entries);
-    GB_CHK(hipMemcpy(x->ftab.data(), df.p, entries * 8, hipMemcpyDeviceToHost));
+    GB_CHK(download(x->ftab.data(), df.p, entries * 8));
   }
 
   // ---- 4-bit text ------------------------------------------------------------------------------------------
@@ -358,7 +416,7 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
     GB_CHK(dt4.alloc(nwords * 8));
     k_text4<<<grid_for(nwords), 256>>>(dT.as<uint8_t>(), n, nwords, dt4.as<uint64_t>());
     resize_populated(x->text4, nwords);
-    GB_CHK(hipMemcpy(x->text4.data(), dt4.p, nwords * 8, hipMemcpyDeviceToHost));
+    GB_CHK(download(x->text4.data(), dt4.p, nwords * 8));
   }
   GB_CHK(hipDeviceSynchronize());
   return PSIGPU_OK;
@@ -605,8 +663,8 @@ int gpu_find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_
     GB_CHK(d_out_n.alloc((size_t)total * 4)); GB_CHK(d_out_o.alloc((size_t)total * 4));
     k_loci_fill<<<gn, 256>>>(lg, d_unc.as<unsigned long long>(), d_first.as<uint32_t>(), d_cnt.as<uint32_t>(),
                              d_out_n.as<uint32_t>(), d_out_o.as<uint32_t>());
-    GB_CHK(hipMemcpy(loci_node.data(), d_out_n.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-    GB_CHK(hipMemcpy(loci_off.data(), d_out_o.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    GB_CHK(download(loci_node.data(), d_out_n.p, (size_t)total * 4));
+    GB_CHK(download(loci_off.data(), d_out_o.p, (size_t)total * 4));
   }
   GB_CHK(hipDeviceSynchronize());
   return PSIGPU_OK;

@@ -2971,6 +2971,7 @@ static int upload_large(psigpu_ctx* ctx, void* dst, const void* src, size_t byte
     hipStream_t s = nullptr;
     ~Stage()
     {
+      if (s) (void)hipStreamSynchronize(s);       // (an error path may leave a piece in flight)
       for (int i = 0; i < 2; ++i) { if (buf[i]) (void)hipHostFree(buf[i]); if (done[i]) (void)hipEventDestroy(done[i]); }
       if (s) (void)hipStreamDestroy(s);
     }
