@@ -1122,7 +1122,7 @@ def test_host_entry_pipeline_equals_one_batch(monkeypatch, sub_bytes, pinned):
 @pytest.mark.parametrize('query_mode', ['kmer-table', 'locus-table'], indirect=True)
 def test_host_entry_with_the_host_oversubscribed(monkeypatch, query_mode):
     """The host entry's helper threads (widening of the 16-byte wire records, staging of pageable reads) next to
-    as many spinning processes as the box has cores, one read per sub-batch: a thread descheduled in the middle
+    three times as many spinning processes as the cores the test allows itself, one read per sub-batch: a thread descheduled in the middle
     of a sub-batch must not let its landing buffer be reused (found by three fuzz processes sharing a box)."""
     import subprocess
     import sys
@@ -1134,8 +1134,13 @@ def test_host_entry_with_the_host_oversubscribed(monkeypatch, query_mode):
     monkeypatch.setenv('PSIGPU_SUB_BYTES', str(1 << 30))
     want = f.seeds_all(rr, step=step, rec_offset=7, sort_unique=True)
     monkeypatch.setenv('PSIGPU_SUB_BYTES', '16')
-    burners = [subprocess.Popen([sys.executable, '-c', 'while True: pass']) for _ in range(os.cpu_count() or 8)]
+    # this process, the library's helper threads and the spinners all on four cores: oversubscribed without taking
+    # the whole box
+    cores = sorted(os.sched_getaffinity(0))
+    os.sched_setaffinity(0, set(cores[:4]))
+    burners = []
     try:
+        burners = [subprocess.Popen([sys.executable, '-c', 'while True: pass']) for _ in range(12)]
         for _ in range(3):
             assert _eq(f.seeds_all(rr, step=step, rec_offset=7, sort_unique=True), want)
             assert _eq(psi_amd.sort_unique(f.seeds_all(rr, step=step, rec_offset=7)), psi_amd.sort_unique(want))
@@ -1144,6 +1149,7 @@ def test_host_entry_with_the_host_oversubscribed(monkeypatch, query_mode):
             b.kill()
         for b in burners:
             b.wait()
+        os.sched_setaffinity(0, set(cores))
     f.close()
 
 
