@@ -145,18 +145,40 @@ void find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>
     resize_populated(c.step_node, total); resize_populated(c.step_lo, total); resize_populated(c.step_hi, total);
     resize_populated(c.step_last, total);
     resize_populated(c.at_off, n + 1);
-#pragma omp parallel for schedule(dynamic, 4096)
-    for (int64_t p = 0; p < np; ++p) {
-      const auto& P = paths[p];
-      uint64_t s = first[p];
-      for (size_t i = 0; i < P.size(); ++i, ++s) {
-        const uint32_t len = (uint32_t)g.node_len(P[i]);
-        uint32_t lo = 0, hi = len;
-        if (i == 0 && (size_t)p < path_head.size()) lo = std::min(len, path_head[p]);
-        if (i + 1 == P.size() && (size_t)p < path_tail.size() && path_tail[p]) hi = std::min(len, path_tail[p]);
-        c.step_node[s] = P[i]; c.step_lo[s] = lo; c.step_hi[s] = hi;
-        c.step_last[s] = i + 1 == P.size();
-        __atomic_fetch_add(&c.at_off[P[i] + 1], 1ull, __ATOMIC_RELAXED);
+    // work items: runs of short paths (patches), slices of long ones (a whole-genome walk is one path of 200 M steps)
+    struct StepItem { size_t pa, pb, i0, i1; };
+    std::vector<StepItem> items;
+    {
+      const size_t TARGET = 1u << 20;
+      size_t ga = 0, gsteps = 0;
+      for (size_t p = 0; p < paths.size(); ++p) {
+        const size_t m = paths[p].size();
+        if (m > TARGET) {
+          if (p > ga) items.push_back({ ga, p, 0, 0 });
+          for (size_t a0 = 0; a0 < m; a0 += TARGET) items.push_back({ p, p + 1, a0, std::min(m, a0 + TARGET) });
+          ga = p + 1; gsteps = 0;
+        } else if ((gsteps += m) >= TARGET) { items.push_back({ ga, p + 1, 0, 0 }); ga = p + 1; gsteps = 0; }
+      }
+      if (paths.size() > ga) items.push_back({ ga, paths.size(), 0, 0 });
+    }
+    (void)np;
+    const int64_t n_items = (int64_t)items.size();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t it = 0; it < n_items; ++it) {
+      const StepItem w = items[it];
+      for (size_t p = w.pa; p < w.pb; ++p) {
+        const auto& P = paths[p];
+        const size_t i0 = w.i1 ? w.i0 : 0, i1 = w.i1 ? w.i1 : P.size();
+        uint64_t s = first[p] + i0;
+        for (size_t i = i0; i < i1; ++i, ++s) {
+          const uint32_t len = (uint32_t)g.node_len(P[i]);
+          uint32_t lo = 0, hi = len;
+          if (i == 0 && p < path_head.size()) lo = std::min(len, path_head[p]);
+          if (i + 1 == P.size() && p < path_tail.size() && path_tail[p]) hi = std::min(len, path_tail[p]);
+          c.step_node[s] = P[i]; c.step_lo[s] = lo; c.step_hi[s] = hi;
+          c.step_last[s] = i + 1 == P.size();
+          __atomic_fetch_add(&c.at_off[P[i] + 1], 1ull, __ATOMIC_RELAXED);
+        }
       }
     }
     for (uint64_t v = 0; v < n; ++v) c.at_off[v + 1] += c.at_off[v];
