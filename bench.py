@@ -692,9 +692,13 @@ def main():
         if 'cpu_baseline' not in out:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if cxx_stuck:                 # a thread is still inside RCCL: leave without tearing anything down under it
+    if cxx_stuck:
+        # a thread is still inside RCCL: leave without tearing anything down under it -- and NOT as a success: the line
+        # above is printed (it carries 'error': 'timed out'), the launcher and the driver see a failed rank, and the
+        # peers that may still be blocked in ncclSend / ncclRecv are taken down by the launcher instead of lingering
         sys.stdout.flush()
-        os._exit(0)
+        sys.stderr.flush()
+        os._exit(3)
     finder.close()
     if world > 1:
         dist.destroy_process_group()

@@ -441,7 +441,14 @@ void psigpu_comm_destroy(psigpu_comm* comm);
 const char* psigpu_comm_last_error(const psigpu_comm* comm);      /* comm may be NULL: last create / id error on this thread */
 /* d_hits: `n` records in this rank's HBM.  On the root *d_all points at library-owned device memory (valid until the
  * next gather on this communicator) holding *n_all records, rank 0's first; elsewhere NULL / 0.  counts (may be NULL):
- * every rank's record count. */
+ * every rank's record count.
+ * PRECONDITION: the records are COMPLETE when the call is made -- the gather runs on a stream of the communicator's
+ * own, which is not ordered against the stream that produced d_hits.  psigpu_find_seeds_device synchronises its stream
+ * before it returns, so records that came from it qualify; a caller that fills d_hits itself synchronises first.
+ * Collective: every rank of the communicator calls it.  Errors: a rank that cannot take part (the root out of device
+ * memory) makes the call return PSIGPU_ERR_NOMEM on EVERY rank before any transfer is posted, and the communicator
+ * stays usable; a failure of the collective calls themselves aborts the communicator (ncclCommAbort: the peers'
+ * pending operations fail instead of hanging) and later gathers on it return PSIGPU_ERR_STATE. */
 int psigpu_gather_hits(psigpu_comm* comm, const psigpu_hit* d_hits, uint64_t n, int root, const psigpu_hit** d_all,
                        uint64_t* n_all, uint64_t* counts);
 

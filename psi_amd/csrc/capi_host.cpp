@@ -194,14 +194,25 @@ psigpu_index* psigpu_index_from_reference_paths(const psigpu_graph* g, const psi
   uint64_t context = 0;
   bool forward = false;
   std::string err;
-  int st = read_reference_paths(paths_file, g->g, &context, &forward, paths, head, tail, &err);
-  if (st != PSIGPU_OK) { g_host_err = err; if (status) *status = st; return nullptr; }
-  if (context_out) *context_out = context;
-  if (forward_out) *forward_out = forward ? 1u : 0u;
-  psigpu_index_opts o = *opts;
-  o.context = (uint32_t)std::min<uint64_t>(context, 0xFFFFFFFFull);        // PathIndex::load_paths_set takes the file's (pathindex.hpp:286-289)
-  Index* x = build_index(g->g, o, paths, head, tail, &st, &err);
-  return wrap_index(x, st, err, status);
+  // nothing may leave an extern "C" function by exception: a file this reader cannot make sense of, or one whose
+  // (checked) sizes still exhaust memory, is an error code
+  try {
+    int st = read_reference_paths(paths_file, g->g, &context, &forward, paths, head, tail, &err);
+    if (st != PSIGPU_OK) { g_host_err = err; if (status) *status = st; return nullptr; }
+    if (context_out) *context_out = context;
+    if (forward_out) *forward_out = forward ? 1u : 0u;
+    psigpu_index_opts o = *opts;
+    o.context = (uint32_t)std::min<uint64_t>(context, 0xFFFFFFFFull);        // PathIndex::load_paths_set takes the file's (pathindex.hpp:286-289)
+    Index* x = build_index(g->g, o, paths, head, tail, &st, &err);
+    return wrap_index(x, st, err, status);
+  } catch (const std::bad_alloc&) {
+    g_host_err = std::string(paths_file) + ": out of memory";
+    if (status) *status = PSIGPU_ERR_NOMEM;
+  } catch (const std::exception& e) {
+    g_host_err = std::string(paths_file) + ": " + e.what();
+    if (status) *status = PSIGPU_ERR_FORMAT;
+  }
+  return nullptr;
 }
 
 void psigpu_index_free(psigpu_index* x) { delete x; }
@@ -246,7 +257,12 @@ int psigpu_index_save(const psigpu_index* x, const char* prefix)
 psigpu_index* psigpu_index_load(const char* prefix, int* status)
 {
   int st = PSIGPU_ERR_ARG;
-  Index* x = prefix ? load_index(prefix, &st) : nullptr;
+  Index* x = nullptr;
+  try {
+    x = prefix ? load_index(prefix, &st) : nullptr;
+  } catch (const std::exception&) {               // (sizes are checked against the file; memory can still run out)
+    st = PSIGPU_ERR_NOMEM;
+  }
   return wrap_index(x, st, "cannot load index", status);
 }
 

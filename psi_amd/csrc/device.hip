@@ -5007,7 +5007,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   {
     const double ratio = ctx->hits_per_read_hint > 0 ? ctx->hits_per_read_hint * 1.1 : 10.0;
     int st = out_reserve((uint64_t)(ratio * (double)n_reads) + 1024);
-    if (st != PSIGPU_OK) return st;
+    if (st != PSIGPU_OK) return fail(st);      // (reads may already be on their way in: fail() waits for them)
   }
 
   // 16-byte records over the link, widened on the host (k_hits_wire16): when the node ids are rank + constant

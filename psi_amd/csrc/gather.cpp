@@ -29,6 +29,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -54,6 +55,7 @@ Rccl& rccl()
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
     r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
@@ -133,8 +135,13 @@ int psigpu_gather_hits(psigpu_comm* c, const psigpu_hit* d_hits, uint64_t n, int
 {
   if (!c || root < 0 || root >= c->world || (n && !d_hits)) return PSIGPU_ERR_ARG;
   Rccl& r = rccl();
-  auto fail = [&](const char* what, ncclResult_t st) { c->err = std::string(what) + ": " + r.GetErrorString(st); return PSIGPU_ERR_DEVICE; };
-  auto hfail = [&](const char* what, hipError_t e) { c->err = std::string(what) + ": " + hipGetErrorString(e); return PSIGPU_ERR_DEVICE; };
+  if (!c->comm) { c->err = "the communicator was aborted by an earlier failure"; return PSIGPU_ERR_STATE; }
+  // A failure of the collective calls themselves leaves the communicator in an unknown state on this rank and the
+  // peers possibly blocked in theirs: abort it (ncclCommAbort makes the peers' pending operations fail instead of
+  // hang), every later gather on it returns PSIGPU_ERR_STATE.
+  auto abort_comm = [&] { if (c->comm) { (void)r.CommAbort(c->comm); c->comm = nullptr; } };
+  auto fail = [&](const char* what, ncclResult_t st) { c->err = std::string(what) + ": " + r.GetErrorString(st); abort_comm(); return PSIGPU_ERR_DEVICE; };
+  auto hfail = [&](const char* what, hipError_t e) { c->err = std::string(what) + ": " + hipGetErrorString(e); abort_comm(); return PSIGPU_ERR_DEVICE; };
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return hfail("hipSetDevice", e);
   // 1. everybody learns everybody's count
@@ -147,16 +154,33 @@ int psigpu_gather_hits(psigpu_comm* c, const psigpu_hit* d_hits, uint64_t n, int
   uint64_t total = 0;
   for (uint64_t x : cnt) total += x;
   if (counts) memcpy(counts, cnt.data(), (size_t)c->world * 8);
-  // 2. payloads: point to point into the root's buffer, in rank order, one group
+  // 2. the root makes room; whether it could is agreed on by everybody BEFORE any transfer is posted (a root that
+  // returned early used to leave the senders blocked in ncclSend with nothing to time them out): a second all-gather of
+  // one status word per rank -- 0 = ready -- and every rank returns the same error when one is not
+  uint64_t my_status = 0;
+  std::string local_err;
   if (c->rank == root) {
     const size_t need = (size_t)(total + 1) * sizeof(psigpu_hit);
     if (need > c->all_cap) {
       if (c->d_all) (void)hipFree(c->d_all);
       c->d_all = nullptr; c->all_cap = 0;
-      if ((e = hipMalloc(&c->d_all, need + need / 8)) != hipSuccess) return hfail("hipMalloc (gathered hits)", e);
-      c->all_cap = need + need / 8;
+      if ((e = hipMalloc(&c->d_all, need + need / 8)) != hipSuccess) {
+        (void)hipGetLastError();
+        my_status = 1; local_err = std::string("hipMalloc (gathered hits): ") + hipGetErrorString(e);
+      } else c->all_cap = need + need / 8;
     }
   }
+  if ((e = hipMemcpyAsync(c->d_mine, &my_status, 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return hfail("hipMemcpyAsync", e);
+  if ((st = r.AllGather(c->d_mine, c->d_counts, 1, NCCL_UINT64, c->comm, c->stream)) != 0) return fail("ncclAllGather (status)", st);
+  std::vector<uint64_t> status((size_t)c->world);
+  if ((e = hipMemcpyAsync(status.data(), c->d_counts, (size_t)c->world * 8, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return hfail("hipMemcpyAsync", e);
+  if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return hfail("hipStreamSynchronize", e);
+  for (int p = 0; p < c->world; ++p)
+    if (status[(size_t)p]) {
+      c->err = p == c->rank ? local_err : "rank " + std::to_string(p) + " could not take part in the gather (out of device memory)";
+      return PSIGPU_ERR_NOMEM;                 // on every rank alike; the communicator stays usable
+    }
+  // 3. payloads: point to point into the root's buffer, in rank order, one group
   if ((st = r.GroupStart()) != 0) return fail("ncclGroupStart", st);
   if (c->rank == root) {
     uint64_t at = 0;

@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <sys/stat.h>
 #include <random>
 
 #include "host.hpp"
@@ -726,11 +728,20 @@ template <typename T> bool wr(FILE* f, const std::vector<T>& v)
   if (fwrite(&n, 8, 1, f) != 1) return false;
   return n == 0 || fwrite(v.data(), sizeof(T), n, f) == n;
 }
+// bytes of the file behind the read position (a length field of an untrusted file is checked against it BEFORE
+// anything is allocated)
+uint64_t bytes_left(FILE* f)
+{
+  struct stat st;
+  const off_t at = ftello(f);
+  if (at < 0 || fstat(fileno(f), &st) != 0 || st.st_size < at) return 0;
+  return (uint64_t)(st.st_size - at);
+}
 template <typename T> bool rd(FILE* f, std::vector<T>& v)
 {
   uint64_t n;
   if (fread(&n, 8, 1, f) != 1) return false;
-  if (n > (1ull << 40) / sizeof(T)) return false;
+  if (n > bytes_left(f) / sizeof(T)) return false;
   v.resize(n);
   return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
@@ -788,11 +799,12 @@ Index* load_index(const std::string& prefix, int* status)
 {
   FILE* f = fopen((prefix + ".psigpu").c_str(), "rb");
   if (!f) { *status = PSIGPU_ERR_IO; return nullptr; }
-  Index* x = new Index;
+  struct Closer { FILE*& f; ~Closer() { if (f) fclose(f); } } closer{ f };      // (an allocation below may throw)
+  std::unique_ptr<Index> x(new Index);
   char magic[8];
   uint64_t hdr[8], np = 0;
   bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, MAGIC, 8) == 0 &&
-            fread(hdr, 8, 8, f) == 8 && fread(&np, 8, 1, f) == 1 && np < (1ull << 32);
+            fread(hdr, 8, 8, f) == 8 && fread(&np, 8, 1, f) == 1 && np < (1ull << 32) && np <= bytes_left(f) / 8;
   if (ok) {
     x->k = (uint32_t)hdr[0]; x->sa_rate = (uint32_t)hdr[1]; x->context = (uint32_t)hdr[2]; x->ftab_len = (uint32_t)(hdr[2] >> 32);
     x->n = hdr[3];
@@ -825,7 +837,7 @@ Index* load_index(const std::string& prefix, int* status)
       m.exc_shift = (uint32_t)xs;
     }
   }
-  fclose(f);
+  fclose(f); f = nullptr;
   // a corrupt or truncated file must not reach the device: every array length follows from the header
   if (ok) {
     ok = x->k >= 1 && x->k <= PSIGPU_MAX_SEED_LEN && x->sa_rate && !(x->sa_rate & (x->sa_rate - 1)) &&
@@ -835,9 +847,9 @@ Index* load_index(const std::string& prefix, int* status)
     x->fm_ok = !x->blocks.empty();
     for (Index& m : x->more) m.fm_ok = !m.blocks.empty();
   }
-  if (!ok) { delete x; *status = PSIGPU_ERR_FORMAT; return nullptr; }
+  if (!ok) { *status = PSIGPU_ERR_FORMAT; return nullptr; }
   *status = PSIGPU_OK;
-  return x;
+  return x.release();
 }
 
 }  // namespace psigpu

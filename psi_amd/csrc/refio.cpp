@@ -25,6 +25,7 @@
 // What cannot be verified here: gum's id / offset widths never reach this file (ids are enc_vector values,
 // the trims explicit u64), but an sdsl version that lays int_vector out differently would not be read.
 #include <cstdio>
+#include <sys/types.h>
 #include <cstring>
 #include <unordered_map>
 
@@ -33,19 +34,37 @@
 namespace psigpu {
 namespace {
 
+// The file is untrusted: every size field is checked against the bytes the file still holds BEFORE anything is
+// allocated for it (a garbage header must not ask for 128 GiB), and the handle closes itself on every way out.
 struct Reader {
-  FILE* f;
+  FILE* f = nullptr;
   bool ok = true;
-  uint64_t u64() { uint64_t v = 0; if (ok && fread(&v, 8, 1, f) != 1) ok = false; return v; }
-  uint8_t u8() { uint8_t v = 0; if (ok && fread(&v, 1, 1, f) != 1) ok = false; return v; }
+  uint64_t left = 0;                            // bytes of the file not read yet
+  explicit Reader(const char* path) : f(fopen(path, "rb"))
+  {
+    if (!f) { ok = false; return; }
+    if (fseeko(f, 0, SEEK_END) == 0) { const off_t e = ftello(f); if (e > 0) left = (uint64_t)e; }
+    if (fseeko(f, 0, SEEK_SET) != 0) ok = false;
+  }
+  ~Reader() { if (f) fclose(f); }
+  Reader(const Reader&) = delete;
+  Reader& operator=(const Reader&) = delete;
+  bool take(void* dst, uint64_t bytes)
+  {
+    if (!ok || bytes > left || (bytes && fread(dst, 1, bytes, f) != bytes)) return ok = false;
+    left -= bytes;
+    return true;
+  }
+  uint64_t u64() { uint64_t v = 0; take(&v, 8); return ok ? v : 0; }
+  uint8_t u8() { uint8_t v = 0; take(&v, 1); return ok ? v : 0; }
   // `bits` bits of payload as u64 words
   bool words(uint64_t bits, std::vector<uint64_t>& out)
   {
+    if (!ok || bits > left * 8) return ok = false;          // (left < 2^61: no overflow)
     const uint64_t nw = (bits + 63) / 64;
-    if (!ok || nw > (1ull << 34)) return ok = false;
+    if (nw * 8 > left) return ok = false;
     out.assign(nw + 1, 0);                      // (+1: reads that straddle the last word stay inside)
-    if (nw && fread(out.data(), 8, nw, f) != nw) ok = false;
-    return ok;
+    return take(out.data(), nw * 8);
   }
 };
 
@@ -91,7 +110,8 @@ bool read_enc_vector(Reader& r, std::vector<uint64_t>& out)
 {
   const uint64_t size = r.u64();
   IntVector z, sp;
-  if (!r.ok || size > (1ull << 34) || !read_int_vector0(r, z) || !read_int_vector0(r, sp)) return false;
+  // (a value costs at least one code bit or a share of a sample: `size` beyond the bits left is garbage)
+  if (!r.ok || size > r.left * 8 || !read_int_vector0(r, z) || !read_int_vector0(r, sp)) return false;
   out.clear();
   if (size == 0) return true;
   constexpr uint64_t DENS = 128;
@@ -120,13 +140,13 @@ int read_reference_paths(const std::string& file, const Graph& g, uint64_t* cont
                          std::vector<std::vector<uint32_t>>& paths, std::vector<uint32_t>& head,
                          std::vector<uint32_t>& tail, std::string* err)
 {
-  FILE* f = fopen(file.c_str(), "rb");
-  if (!f) { *err = "cannot open " + file; return PSIGPU_ERR_IO; }
-  Reader r{ f };
-  auto fail = [&](const std::string& why) { fclose(f); *err = file + ": " + why; return PSIGPU_ERR_FORMAT; };
+  Reader r(file.c_str());
+  if (!r.f) { *err = "cannot open " + file; return PSIGPU_ERR_IO; }
+  auto fail = [&](const std::string& why) { *err = file + ": " + why; return PSIGPU_ERR_FORMAT; };
   *context = r.u64();
   const uint64_t dir = r.u64(), n_paths = r.u64();
-  if (!r.ok || dir > 1 || n_paths > (1ull << 32)) return fail("not a path-set file");
+  // (a path costs at least 8 + 9 + 9 + 8 + 8 + 8 bytes of headers)
+  if (!r.ok || dir > 1 || n_paths > (1ull << 32) || n_paths > r.left / 50) return fail("not a path-set file");
   *forward = dir == 1;
   std::unordered_map<uint64_t, uint32_t> rank;
   rank.reserve(g.n_nodes() * 2);
@@ -164,7 +184,6 @@ int read_reference_paths(const std::string& file, const Graph& g, uint64_t* cont
     paths.push_back(std::move(nodes));
     head.push_back(h); tail.push_back(t);
   }
-  fclose(f);
   return PSIGPU_OK;
 }
 

@@ -3,6 +3,7 @@ the FM-index / segment-table layout handed to the GPU, starting loci, (de)serial
 No GPU compute is called here."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -500,6 +501,63 @@ def test_reference_paths_file(tmp_path, ref_data, golden_dir):
         psi_amd.PathIndex.from_reference_paths(g, 10, fn)
     with pytest.raises(psi_amd.PsiGpuError):
         psi_amd.PathIndex.from_reference_paths(g, 10, str(tmp_path / 'missing_paths'))
+
+
+def test_untrusted_files_cannot_ask_for_memory(tmp_path, ref_data, golden_dir):
+    """A garbage or truncated `<prefix>_paths` / `<prefix>.psigpu` whose header claims enormous arrays is a format
+    error at once: every size field is checked against the bytes the file still holds before anything is
+    allocated (round-3 advisor finding: a 2^34-word int_vector header made the reader zero-fill 128 GiB, and the
+    exception crossed the C boundary).  Run in a child process under an address-space limit so that a regression
+    is a failed allocation, not the OOM killer."""
+    import struct
+    import subprocess
+    raw = open(os.path.join(golden_dir, 'ref_paths_x_trimmed.bin'), 'rb').read()
+    files = {}
+    # enc_vector: size 2^33; its code-bit vector: 2^39 bits; the node-break vector: 2^40 bits; 2^31 paths
+    files['size'] = raw[:24] + struct.pack('<Q', 1 << 33) + raw[32:]
+    files['zbits'] = raw[:32] + struct.pack('<QB', 1 << 39, 1) + raw[41:]
+    files['bv'] = raw[:82] + struct.pack('<Q', 1 << 40) + raw[90:]
+    files['npaths'] = struct.pack('<QQQ', 10, 0, 1 << 31) + raw[24:]
+    files['random'] = np.random.default_rng(5).integers(0, 256, 4096, dtype=np.uint8).tobytes()
+    for name, blob in files.items():
+        open(str(tmp_path / ('bad_' + name)), 'wb').write(blob)
+    # the product's own container with a length field of 2^39 entries behind a good header
+    b, g = _setup(ref_data, 'x')
+    px = psi_amd.PathIndex.build(g, 12, 2)
+    px.save(str(tmp_path / 'good'))
+    good = open(str(tmp_path / 'good.psigpu'), 'rb').read()
+    open(str(tmp_path / 'huge.psigpu'), 'wb').write(good[:8 + 64] + struct.pack('<Q', (1 << 32) - 1) + good[80:])
+    open(str(tmp_path / 'huge2.psigpu'), 'wb').write(good[:8 + 64 + 8] + struct.pack('<Q', 1 << 39) + good[88:])
+    open(str(tmp_path / 'short.psigpu'), 'wb').write(good[:len(good) // 2])
+    code = (
+        "import resource, sys, os\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['PSI_AMD_NO_TORCH'] = '1'\n"
+        "import psi_amd\n"
+        "g = psi_amd.Graph.load(%r)\n"
+        "lim = 6 << 30\n"
+        "resource.setrlimit(resource.RLIMIT_AS, (lim, lim))\n"
+        "d = %r\n"
+        "for n in ('size', 'zbits', 'bv', 'npaths', 'random'):\n"
+        "    try:\n"
+        "        psi_amd.PathIndex.from_reference_paths(g, 10, os.path.join(d, 'bad_' + n))\n"
+        "        print('ACCEPTED', n)\n"
+        "    except psi_amd.PsiGpuError as e:\n"
+        "        print('rejected', n)\n"
+        "for n in ('huge', 'huge2', 'short'):\n"
+        "    try:\n"
+        "        psi_amd.PathIndex.load(os.path.join(d, n))\n"
+        "        print('ACCEPTED', n)\n"
+        "    except psi_amd.PsiGpuError as e:\n"
+        "        print('rejected', n)\n"
+        "psi_amd.PathIndex.load(os.path.join(d, 'good'))\n"
+        "print('done')\n"
+    ) % (ROOT, os.path.join(ref_data, 'x.gfa'), str(tmp_path))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.split('\n')
+    assert 'done' in out and not any(l.startswith('ACCEPTED') for l in out), r.stdout
+    assert sum(l.startswith('rejected') for l in out) == 8
 
 
 def test_reference_loci_file_format(tmp_path, ref_data):
