@@ -272,7 +272,7 @@ def main():
     L = psi_amd.lib()
     dev = [(torch.from_numpy(b).cuda(), torch.from_numpy(o.astype(np.int64)).cuda(), len(b)) for b, o in batches]
 
-    def time_mode(f, steps, warmup, mode, sync_ranks):
+    def time_mode(f, steps, warmup, mode, sync_ranks, blocks=False):
         """K timed steps of the device-resident entry over the alternating batches; per-kernel times from
         the library's HIP events (recorded on the streams the kernels run on)."""
         # untimed: every k-walk from the starting loci (the unit SURVEY 8(d) prices the traverser by).
@@ -298,28 +298,56 @@ def main():
         probe_name = 'k_kmer_probe' if (mode == 'kmer-table' or (mode == 'traverse' and c0['n_path_kmers'])) else 'k_lkt_probe'
         kern = {'k_fm_search': 0.0, 'k_fm_locate': 0.0, 'k_traverse': 0.0, 'k_table_insert': 0.0, probe_name: 0.0,
                 'k_seed_pack': 0.0}
+        # BLOCKS of exactly `steps` steps, each bracketed by barrier + synchronize on both sides and each giving one
+        # ms_per_step; enough blocks that the timed region is >= ~0.6 s whatever --steps is (a 20-step block of the
+        # default mode is 9 ms: one scheduling hiccup on a shared box moved round 3's `value` by 10 %).  The line
+        # reports the MEDIAN block (value, ms_per_step) and the spread (min / max / all blocks).
+        n_blocks = 1
+        if blocks:
+            t_est = time.perf_counter()
+            for i in range(3):
+                if L.psigpu_find_seeds_device(*calls[i % nb]):
+                    raise RuntimeError(L.psigpu_last_error(f.ctx).decode())
+            torch.cuda.synchronize()
+            est = (time.perf_counter() - t_est) / 3
+            n_blocks = int(min(400, max(3, -(-0.6 // (steps * max(est, 1e-6))))))
+            if sync_ranks and world > 1:
+                nbt = torch.tensor([n_blocks], dtype=torch.int64, device=red_dev)
+                dist.all_reduce(nbt, op=dist.ReduceOp.MAX)
+                n_blocks = int(nbt.item())
         seeds = hits = 0
-        torch.cuda.synchronize()
-        if sync_ranks and world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t_begin = time.perf_counter()
-        for i in range(steps):
-            if L.psigpu_find_seeds_device(*calls[i % nb]):
-                raise RuntimeError(L.psigpu_last_error(f.ctx).decode())
-            L.psigpu_get_counters(f.ctx, C.byref(cs))
-            kern['k_fm_search'] += cs.ms_search; kern['k_fm_locate'] += cs.ms_locate; kern['k_traverse'] += cs.ms_traverse
-            kern['k_table_insert'] += cs.ms_table; kern[probe_name] += cs.ms_probe; kern['k_seed_pack'] += cs.ms_pack
-            seeds += cs.n_seeds; hits += cs.n_hits
-        torch.cuda.synchronize()
-        if sync_ranks and world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t_begin
+        block_s = []
+        for _ in range(n_blocks):
+            torch.cuda.synchronize()
+            if sync_ranks and world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t_begin = time.perf_counter()
+            for i in range(steps):
+                if L.psigpu_find_seeds_device(*calls[i % nb]):
+                    raise RuntimeError(L.psigpu_last_error(f.ctx).decode())
+                L.psigpu_get_counters(f.ctx, C.byref(cs))
+                kern['k_fm_search'] += cs.ms_search; kern['k_fm_locate'] += cs.ms_locate; kern['k_traverse'] += cs.ms_traverse
+                kern['k_table_insert'] += cs.ms_table; kern[probe_name] += cs.ms_probe; kern['k_seed_pack'] += cs.ms_pack
+                seeds += cs.n_seeds; hits += cs.n_hits
+            torch.cuda.synchronize()
+            if sync_ranks and world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            block_s.append(time.perf_counter() - t_begin)
+        if sync_ranks and world > 1:              # every block's time = the slowest rank's
+            bt = torch.tensor(block_s, dtype=torch.float64, device=red_dev)
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+            block_s = [float(x) for x in bt.tolist()]
+        elapsed = float(np.median(block_s))       # of ONE block of `steps` steps
+        seeds //= n_blocks; hits //= n_blocks
+        for n_ in kern:
+            kern[n_] /= n_blocks
         c = f.counters()
         c['n_kwalks_all'] = kwalks_all
         c['n_hits_table'] = c['n_hits_off_path'] if c['n_locus_kmers'] and not c['n_loci_traversed'] else 0
-        return {'elapsed': elapsed, 'kern': kern, 'seeds': seeds, 'hits': hits, 'c': c, 'steps': steps}
+        return {'elapsed': elapsed, 'kern': kern, 'seeds': seeds, 'hits': hits, 'c': c, 'steps': steps,
+                'block_ms_per_step': [b / steps * 1e3 for b in block_s]}
 
     rand_peak = {}
 
@@ -401,13 +429,10 @@ def main():
     if rank == 0 and not lean:
         random_load_peak(False); random_load_peak(True)
         time.sleep(0.3)                   # (4 GiB of scratch just freed: see above)
-    main_res = time_mode(finder, args.steps, args.warmup, args.mode, True)
+    main_res = time_mode(finder, args.steps, args.warmup, args.mode, True, blocks=True)
     elapsed = main_res['elapsed']
     seeds_total, hits_total = float(main_res['seeds']), float(main_res['hits'])
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if world > 1:                 # (elapsed is already the max over the ranks, block by block)
         tot = torch.tensor([seeds_total, hits_total], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         seeds_total, hits_total = float(tot[0].item()), float(tot[1].item())
@@ -498,6 +523,12 @@ def main():
             'steps': steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / steps * 1e3,
+            'timing': {'what': 'blocks of exactly `steps` steps, each bracketed by barrier + synchronize on both sides (max over '
+                               'ranks per block); value and ms_per_step are the MEDIAN block',
+                       'blocks': len(main_res['block_ms_per_step']), 'timed_region_s': sum(main_res['block_ms_per_step']) * steps / 1e3,
+                       'ms_per_step_min': min(main_res['block_ms_per_step']), 'ms_per_step_max': max(main_res['block_ms_per_step']),
+                       'ms_per_step_median': elapsed / steps * 1e3,
+                       'ms_per_step_blocks': [round(x, 4) for x in main_res['block_ms_per_step']][:64]},
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSIGPU_ABI_VERSION 4
+#define PSIGPU_ABI_VERSION 5
 #define PSIGPU_MAX_SEED_LEN 63u   /* psikt takes any -l (src/psikt.cpp:327); seeds are 2-bit packed into one 64-bit word up
                                     to 31 bases and into two words from 32 to 63 */
 #define PSIGPU_MAX_TABLE_SEED_LEN 31u   /* the tabulating query modes (k-mer table, locus table) hold one-word k-mers: longer
@@ -313,6 +313,18 @@ int psigpu_set_query_mode(psigpu_ctx* ctx, uint32_t mode, uint32_t walk_cap);
                                         instead of the table of the paths' k-mers */
 int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags);
 
+/* Per-context switches of the host entry (psigpu_find_seeds / _packed), by name -- what the PSIGPU_* environment
+ * variables of the same meaning set for a whole process, settable per context and at run time (a test that flips an
+ * environment variable while library threads are running races with their getenv).  The records returned never depend
+ * on them.  PSIGPU_ERR_ARG for an unknown name.
+ *   "sub_bytes"       bases per sub-batch of the pipeline (0 = default 16 Mi; tests cut small inputs into many)
+ *   "no_ahead"        1: two-slot pipeline even when reads and offsets are pinned (no transfers queued ahead)
+ *   "no_engine_copy"  1: every transfer through hipMemcpyAsync on the pipeline's streams instead of a named SDMA engine;
+ *                     takes effect when set before the context's first host-entry call
+ *   "wire"            bytes per record on the device-to-host link: 0 = the narrowest that fits (8, 16, 32), or 8 / 16 / 32 =
+ *                     nothing narrower than that */
+int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value);
+
 /* Builds the tables of the current query mode for seed length k now (index load time) instead of
  * inside the first query: the k-walks of the starting loci enumerated by the traverser kernel, the
  * path k-mers read off the suffix array, sorted and hashed.  Blocks until the device is idle (it
@@ -346,6 +358,24 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
                       uint64_t n_reads, uint32_t k, uint32_t step, uint64_t rec_offset,
                       uint32_t flags, psigpu_hits* out);
 void psigpu_free_hits(psigpu_hits* hits);
+
+/* The same chunk with the reads PACKED to 2 bits per base -- what crosses the host link is then a quarter of the ASCII
+ * bases (psikt's reader packs while it parses: psi::Records, psi_amd/include/psi/sequence.hpp; the reference holds reads
+ * as seqan2::Dna5QString, one byte per base: sequence.hpp:1130-1294).  Base i of the chunk (reads back to back; read_off
+ * counts BASES exactly as for psigpu_find_seeds) is the two bits 63 - 2 (i % 32), 62 - 2 (i % 32) of packed[i / 32]:
+ * A 0, C 1, G 2, T 3, first base most significant.  n_mask (may be NULL: every base of the chunk is ACGT): bit i % 64 of
+ * n_mask[i / 64] set = base i is not ACGT (its two code bits are ignored; a seed that covers it yields nothing, as an N
+ * does in psigpu_find_seeds).  packed holds ceil(n / 32) words, n_mask ceil(n / 64), n = read_off[n_reads]; both may be
+ * pinned (DMA'd in place) or pageable (staged).  Same records, same order, same flags as psigpu_find_seeds on the
+ * corresponding ASCII bases.  psigpu_pack_reads makes the two arrays from ASCII bases on the calling thread. */
+int psigpu_find_seeds_packed(psigpu_ctx* ctx, const uint64_t* packed, const uint64_t* n_mask, const uint64_t* read_off,
+                             uint64_t n_reads, uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags,
+                             psigpu_hits* out);
+/* ASCII bases [first, first + n) of a chunk -> their bits in packed / n_mask (arrays for the whole chunk, zeroed by the
+ * caller or filled front to back: the words that [first, first + n) touches only partly are or-ed into).  Any byte that
+ * is not one of ACGTacgt sets its mask bit.  Returns the number of non-ACGT bases in the range.  Host only, no GPU needed;
+ * ranges that do not share a 64-base block may be packed by different threads at once. */
+uint64_t psigpu_pack_reads(const char* bases, uint64_t first, uint64_t n, uint64_t* packed, uint64_t* n_mask);
 
 /* MEM mode -- SeedFinder::seeds_on_paths( sequence, callback ) -> find_mems
  * (seed_finder.hpp:1459-1479, index_iter.hpp:854-906): per read, from `start` the pattern grows
@@ -383,6 +413,12 @@ int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_
                              uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step,
                              uint64_t rec_offset, uint32_t flags, void* stream,
                              const psigpu_hit** d_hits, uint64_t* n_hits);
+/* ... with the device-resident reads packed (layout of psigpu_find_seeds_packed; d_packed holds ceil(n_bases / 32) + 2
+ * words, d_n_mask -- may be NULL -- ceil(n_bases / 64) + 1: the seeding kernel loads the word behind a seed's last). */
+int psigpu_find_seeds_device_packed(psigpu_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_n_mask,
+                                    const uint64_t* d_read_off, uint64_t n_reads, uint64_t n_bases, uint32_t k,
+                                    uint32_t step, uint64_t rec_offset, uint32_t flags, void* stream,
+                                    const psigpu_hit** d_hits, uint64_t* n_hits);
 
 /* Copies `n` records that psigpu_find_seeds_device left in HBM into host memory (blocking;
  * through this library's HIP runtime, so that a binding never has to load one of its own). */
@@ -410,8 +446,9 @@ typedef struct psigpu_counters {
   uint32_t search_launches, traverse_launches;
   uint32_t sorted_in_place;                    /* PSIGPU_SORT_UNIQUE: sub-batches whose hits, emitted seed by seed, only needed
                                                 * the hits of each seed put in order (no radix sort) */
-  uint32_t wire_bytes_per_hit;                 /* psigpu_find_seeds: bytes per record on the device-to-host link (16: packed, widened
-                                                * on the host; 32: as returned); 0 for the device-resident entry */
+  uint32_t wire_bytes_per_hit;                 /* psigpu_find_seeds: bytes per record on the device-to-host link (8 or 16: packed, widened
+                                                * on the host; 32: as returned; the widest any sub-batch of the call used); 0 for the
+                                                * device-resident entry */
   uint64_t n_locate_steps;                     /* LF steps K2 walked from occurrences to sampled suffix-array rows (sa_rate > 1) */
 } psigpu_counters;
 int psigpu_get_counters(const psigpu_ctx* ctx, psigpu_counters* out);

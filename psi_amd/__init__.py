@@ -135,6 +135,12 @@ ABI = [
     ('psigpu_find_seeds', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                     C.c_uint32, C.POINTER(Hits)]),
     ('psigpu_free_hits', None, [C.POINTER(Hits)]),
+    ('psigpu_find_seeds_packed', C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
+                                           C.c_uint32, C.POINTER(Hits)]),
+    ('psigpu_pack_reads', C.c_uint64, [_P, C.c_uint64, C.c_uint64, _P, _P]),
+    ('psigpu_find_seeds_device_packed', C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                  C.c_uint64, C.c_uint32, _P, C.POINTER(_P), _U64P]),
+    ('psigpu_set_option', C.c_int, [_P, C.c_char_p, C.c_uint64]),
     ('psigpu_find_seeds_device', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_uint64, C.c_uint32, _P, C.POINTER(_P), _U64P]),
     ('psigpu_get_counters', C.c_int, [_P, C.POINTER(Counters)]),
@@ -225,6 +231,41 @@ def pack_reads(reads: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
         off[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
     bases = np.frombuffer(''.join(reads).encode(), dtype=np.uint8).copy()
     return bases, off
+
+
+class PackedReads:
+    """A chunk of reads as psigpu_find_seeds_packed takes it: 2-bit codes (32 bases per u64 word, first base most
+    significant), a "not ACGT" bit per base (None when every base is ACGT) and the read offsets in BASES.  `pinned`:
+    the arrays live in page-locked memory (DMA'd in place)."""
+
+    def __init__(self, bases: np.ndarray, off: np.ndarray, pinned: bool = False, threads: int = 1):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = int(off[-1]) if len(off) else 0
+        nw, nm = (n + 31) // 32 + 2, (n + 63) // 64 + 2          # (+ the words the seeding kernel loads behind the last seed)
+        if pinned:
+            self._pw, self._pm, self._po = PinnedArray(nw, np.uint64), PinnedArray(nm, np.uint64), pinned_copy(off)
+            self.words, mask, self.off = self._pw.array, self._pm.array, self._po.array
+            self.words[:] = 0
+            mask[:] = 0
+        else:
+            self.words, mask, self.off = np.zeros(nw, np.uint64), np.zeros(nm, np.uint64), off
+        self.n_bases = n
+        self.n_not_acgt = 0
+        if n:
+            # (pieces of whole 64-base blocks may be packed by different threads at once)
+            piece = max(64, ((n + threads - 1) // max(1, threads) + 63) // 64 * 64)
+            cuts = list(range(0, n, piece)) + [n]
+            if threads > 1 and len(cuts) > 2:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(threads) as ex:
+                    bad = list(ex.map(lambda ab: lib().psigpu_pack_reads(bases[ab[0]:].ctypes.data_as(C.c_void_p), ab[0], ab[1] - ab[0],
+                                                                          _ptr(self.words), _ptr(mask)), zip(cuts[:-1], cuts[1:])))
+                self.n_not_acgt = int(sum(bad))
+            else:
+                self.n_not_acgt = int(lib().psigpu_pack_reads(_ptr(bases), 0, n, _ptr(self.words), _ptr(mask)))
+        self.mask = mask if self.n_not_acgt else None
+        self._mask_store = mask
 
 
 class Graph:
@@ -603,6 +644,25 @@ class SeedFinder:
     def seeds_all(self, reads, step: int = 0, rec_offset: int = 0, sort_unique: bool = False):
         return self._find(reads, step, rec_offset, ALL | (SORT_UNIQUE if sort_unique else 0))
 
+    def seeds_all_packed(self, pr: 'PackedReads', step: int = 0, rec_offset: int = 0, sort_unique: bool = False,
+                         flags: int = ALL) -> np.ndarray:
+        """psigpu_find_seeds_packed: the chunk's reads as 2-bit words (a quarter of the ASCII bytes on the host link)."""
+        out = Hits()
+        self._chk(lib().psigpu_find_seeds_packed(self.ctx, _ptr(pr.words), _ptr(pr.mask), _ptr(pr.off), len(pr.off) - 1,
+                                                 self.seed_len, step, rec_offset, flags | (SORT_UNIQUE if sort_unique else 0),
+                                                 C.byref(out)))
+        if out.n:
+            buf = (C.c_uint64 * (4 * out.n)).from_address(C.addressof(out.data.contents))
+            arr = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
+        else:
+            arr = np.zeros((0, 4), np.uint64)
+        lib().psigpu_free_hits(C.byref(out))
+        return arr
+
+    def set_option(self, name: str, value: int) -> None:
+        """psigpu_set_option: per-context switches of the host entry ('sub_bytes', 'no_ahead', 'no_engine_copy', 'wire')."""
+        self._chk(lib().psigpu_set_option(self.ctx, name.encode(), int(value)))
+
     def seeds_on_paths(self, reads, step: int = 0, rec_offset: int = 0):
         return self._find(reads, step, rec_offset, ON_PATHS)
 
@@ -639,6 +699,16 @@ class SeedFinder:
         self._chk(lib().psigpu_find_seeds_device(self.ctx, d_bases_ptr, d_read_off_ptr, n_reads, n_bases,
                                                  self.seed_len, step, rec_offset, flags, stream,
                                                  C.byref(d_hits), C.byref(n)))
+        return d_hits.value, n.value
+
+    def seeds_all_device_packed(self, d_words_ptr: int, d_mask_ptr: int, d_read_off_ptr: int, n_reads: int, n_bases: int,
+                                step: int = 0, rec_offset: int = 0, flags: int = ALL, stream: int = 0):
+        """Device-resident PACKED chunk in (psigpu_find_seeds_device_packed), device-resident hits out."""
+        d_hits = C.c_void_p()
+        n = C.c_uint64()
+        self._chk(lib().psigpu_find_seeds_device_packed(self.ctx, d_words_ptr, d_mask_ptr, d_read_off_ptr, n_reads, n_bases,
+                                                        self.seed_len, step, rec_offset, flags, stream,
+                                                        C.byref(d_hits), C.byref(n)))
         return d_hits.value, n.value
 
     def copy_hits(self, d_ptr: int, n: int) -> np.ndarray:

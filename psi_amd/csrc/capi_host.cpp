@@ -391,6 +391,54 @@ const int32_t* psigpu_index_sa(const psigpu_index* x)
   return x && !x->x.sa.empty() ? x->x.sa.data() : nullptr;
 }
 
+// ASCII bases -> 2-bit words + "not ACGT" bits (layout: psigpu_find_seeds_packed).  Eight bases at a time with the SWAR
+// arithmetic the device's ASCII packer uses (k_seed_pack): the two code bits of a letter are bits 1..2 of its byte.
+uint64_t psigpu_pack_reads(const char* bases, uint64_t first, uint64_t n, uint64_t* packed, uint64_t* n_mask)
+{
+  if (!bases || !packed || n == 0) return 0;
+  uint64_t bad = 0;
+  uint64_t i = first;
+  const uint64_t end = first + n;
+  auto one = [&](uint64_t at) {
+    const unsigned char ch = (unsigned char)bases[at - first];
+    const unsigned u = ch & 0xDFu, d = u - 0x41u;
+    const bool ok = d < 20u && ((0x80045u >> d) & 1u);
+    unsigned c = (u >> 1) & 3u;
+    c ^= c >> 1;
+    if (ok) packed[at >> 5] |= (uint64_t)c << (62 - 2 * (at & 31));
+    else { ++bad; if (n_mask) n_mask[at >> 6] |= 1ull << (at & 63); }
+  };
+  while (i < end && (i & 31)) one(i++);                     // to a word boundary
+  for (; i + 32 <= end; i += 32) {
+    uint64_t word = 0;
+    uint32_t nbits = 0;                                      // mask bits of these 32 bases, base j in bit j
+    for (int q = 0; q < 4; ++q) {
+      uint64_t x;
+      memcpy(&x, bases + (i - first) + 8 * q, 8);            // first base in the low byte
+      const uint64_t u = x & 0xDFDFDFDFDFDFDFDFull;
+      const uint64_t y = (x >> 1) & 0x0303030303030303ull;
+      const uint64_t b0 = y & 0x0101010101010101ull, b1 = (y >> 1) & 0x0101010101010101ull, t = b0 & b1;
+      const uint64_t e = 0x4141414141414141ull + (b0 << 1) + (b1 << 4) + (b1 << 1) + b1 - (t << 4) + t;
+      uint64_t c = y ^ b1;                                   // per byte: A 0, C 1, G 2, T 3
+      const uint64_t diff = u ^ e;                           // a non-zero byte = not ACGT
+      if (diff) {
+        for (int j = 0; j < 8; ++j)
+          if ((diff >> (8 * j)) & 0xFF) { nbits |= 1u << (8 * q + j); c &= ~(0xFFull << (8 * j)); ++bad; }
+      }
+      // gather the eight 2-bit codes, FIRST base (low byte) most significant
+      c = __builtin_bswap64(c);                              // first base in the top byte
+      c = (c | (c >> 6)) & 0x000F000F000F000Full;
+      c = (c | (c >> 12)) & 0x000000FF000000FFull;
+      c = (c | (c >> 24)) & 0xFFFFull;
+      word |= c << (48 - 16 * q);
+    }
+    packed[i >> 5] = word;                                   // (a whole word: nobody else writes it)
+    if (n_mask && nbits) n_mask[i >> 6] |= (uint64_t)nbits << (i & 63);
+  }
+  while (i < end) one(i++);
+  return bad;
+}
+
 int psigpu_suffix_array(const uint8_t* text, uint64_t n, uint32_t sigma, int32_t* sa_out)
 {
   if (!text || !sa_out || n == 0 || n >= 0x7FFFFFF0ull || sigma == 0 || sigma > 256) return PSIGPU_ERR_ARG;

@@ -525,12 +525,20 @@ constexpr int SP = 1;        // seeds a thread works on at a time (more were mea
 
 // WIDE (seeds of 32..63 bases): the 128-bit k-mer goes to seed_wide, its fingerprint (table_key) to seed_key -- what the
 // chunk's seed table is keyed by -- and its first pfx_len bases to seed_pfx (the prefix maps).
-template <bool WIDE>
+//
+// PACKED (psigpu_find_seeds_packed): the reads arrive as 2-bit codes, 32 bases per u64 word, base i of the buffer in bits
+// 63 - 2 (i % 32), 62 - 2 (i % 32) of word i / 32 -- first base most significant, so a k-mer is one funnel shift away from
+// its key -- plus (optionally) one bit per base that says "not ACGT" (bit i % 64 of mask word i / 64).  `bases` is then
+// the word array, `pk.bias2` / `pk.biasm` what to add to a base index of the call (read_off[r] + offset) to get its index
+// in the word / mask buffers as they lie on the device (a sub-batch is transferred from a word boundary).
+struct PackedIn { const uint64_t* mask; uint64_t bias2, biasm; };
+
+template <bool WIDE, bool PACKED = false>
 __global__ void __launch_bounds__(256)
 k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_off,
             const uint64_t* __restrict__ seed_off, uint64_t n_reads, const uint64_t* __restrict__ params,
             uint64_t seeds_cap, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t* __restrict__ seed_key, uint2* __restrict__ seed_info,
-            DevCounters* ctr, u128* __restrict__ seed_wide, uint32_t* __restrict__ seed_pfx, uint32_t pfx_len)
+            DevCounters* ctr, u128* __restrict__ seed_wide, uint32_t* __restrict__ seed_pfx, uint32_t pfx_len, PackedIn pk = PackedIn{ nullptr, 0, 0 })
 {
   typedef typename std::conditional<WIDE, u128, uint64_t>::type KEY;
   constexpr uint32_t NW = WIDE ? 8 : 4;
@@ -576,6 +584,42 @@ k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
     uint64_t x[SP][NW];
     uint64_t st[SP];
     bool fast[SP];
+    if constexpr (PACKED) {
+      static_assert(SP == 1, "one seed per thread");
+      if (!in[0]) continue;
+      const uint64_t s = s0;
+      st[0] = (s - so0[0]) * step;
+      const uint64_t* __restrict__ P = reinterpret_cast<const uint64_t*>(bases);
+      const uint64_t q = ro[0] + st[0] + pk.bias2;
+      const uint64_t w = q >> 5;
+      const uint32_t sh = 2u * (uint32_t)(q & 31);
+      // (the buffer is padded: the words behind the window are loaded but none of their bits is used)
+      const uint64_t w0 = P[w], w1 = P[w + 1];
+      const uint64_t hi = sh ? (w0 << sh) | (w1 >> (64 - sh)) : w0;
+      KEY key;
+      if constexpr (WIDE) {
+        const uint64_t w2 = P[w + 2];
+        const uint64_t lo2 = sh ? (w1 << sh) | (w2 >> (64 - sh)) : w1;
+        key = (((u128)hi << 64) | (u128)lo2) >> (128 - 2 * k);
+      } else key = hi >> (64 - 2 * k);
+      uint32_t ok = 1;
+      if (pk.mask) {
+        const uint64_t qm = ro[0] + st[0] + pk.biasm;
+        const uint32_t ms = (uint32_t)(qm & 63);
+        const uint64_t m0 = pk.mask[qm >> 6], m1 = pk.mask[(qm >> 6) + 1];
+        const uint64_t win = ms ? (m0 >> ms) | (m1 << (64 - ms)) : m0;
+        ok = (win & ((k < 64 ? (1ull << k) : 0ull) - 1ull)) == 0;
+      }
+      if constexpr (WIDE) {
+        seed_wide[s] = ok ? key : key_invalid<u128>();
+        seed_pfx[s] = (uint32_t)(key >> (2 * (k - pfx_len)));
+        seed_key[s] = ok ? table_key(key) : KEY_INVALID;
+      } else
+      seed_key[s] = ok ? key : KEY_INVALID;
+      seed_info[s] = make_uint2((uint32_t)lo[0], (uint32_t)st[0]);
+      nok += ok;
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < SP; ++j) {
       const uint64_t s = s0 + (uint64_t)j * stride;
@@ -2683,6 +2727,38 @@ k_hits_wire16(const psigpu_hit* __restrict__ hits, const unsigned long long* __r
   }
 }
 
+// Round 4: 8 bytes per record.  The four fields of a hit need far fewer than 64 bits together -- the device sorter
+// already packs them into one 64-bit key (hits_gpu.hip) -- so a sub-batch's records cross the link as ONE u64 each:
+//     [ read id - the sub-batch's first | read offset | node id - the graph's first id | node offset ]
+// with the node fields sized by the graph (bits for its largest node length and its node count), and the read offset
+// given every bit the read id of the sub-batch leaves (chr22-like: 17 + 19 + 22 + 6).  The kernel CHECKS that every
+// field fits -- the longest read is not known to the host when the kernel is queued -- and raises a flag in mapped host
+// memory when one does not; the host entry then makes 16-byte records of that sub-batch instead.  56 MB instead of
+// 112 (round 3) or 224 (rounds 1-2) per 1 M-read chunk.
+struct WireFmt {
+  uint32_t bytes = 0;                          // 8 or 16 (0: no wire records)
+  uint32_t noff_bits = 0, node_bits = 0, roff_bits = 0;      // W8; the read id has the remaining 64 - sum bits
+};
+
+__global__ void __launch_bounds__(256)
+k_hits_wire8(const psigpu_hit* __restrict__ hits, const unsigned long long* __restrict__ n_a, const unsigned long long* __restrict__ n_b,
+             uint64_t n_fixed, uint64_t cap, uint64_t id_base, uint64_t rec_base, WireFmt f, uint64_t* __restrict__ out,
+             unsigned long long* __restrict__ overflow /* mapped host memory */)
+{
+  const uint64_t n = min(n_a ? (uint64_t)*n_a + (n_b ? (uint64_t)*n_b : 0ull) : n_fixed, cap);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t rid_bits = 64 - f.noff_bits - f.node_bits - f.roff_bits;
+  bool bad = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(hits + i);
+    const ulonglong2 a = src[0], b = src[1];
+    const uint64_t node = a.x - id_base, rid = b.x - rec_base;
+    bad = bad || (a.y >> f.noff_bits) || (node >> f.node_bits) || (b.y >> f.roff_bits) || (rid_bits < 64 && (rid >> rid_bits));
+    out[i] = ((((rid << f.roff_bits) | b.y) << f.node_bits | node) << f.noff_bits) | a.y;
+  }
+  if (__any(bad) && lane_id() == 0) *overflow = 1ull;
+}
+
 // ------------------------------------------------------------------------------------
 // The part's random-access rate, measured in place (psigpu_measure_random_loads): what the probe of the k-mer
 // table (one divergent 16-byte load per lane) and the LF / locate kernels (one 64-byte sector per quad) are
@@ -2821,6 +2897,7 @@ struct psigpu_ctx {
   DevBuf w_seedout, w_seedres, w_iv_tiles_off, w_defer, w_hit_a, w_hit_seed;
   // per-call workspace (grow-only)
   DevBuf in_bases;                 // host entry, reads in pinned memory: the chunk's reads (transfers queued ahead of the compute loop)
+  DevBuf in_mask;                  // ... packed reads: their "not ACGT" bits
   DevBuf w_bases, w_read_off, w_cnt, w_tiles, w_seed_off, w_seed_key, w_seed_info,
       w_seed_next, w_ht, w_pfx, w_pfx12, w_iv_lo, w_iv_cnt, w_iv_aux, w_hit_off, w_iv_tiles,
       w_chunks, w_chunk_fill, w_chunk_off, w_chunk_tiles, w_hits, w_spill_a, w_spill_b, w_ctr, w_total,
@@ -2844,7 +2921,7 @@ struct psigpu_ctx {
   DevBuf w_sorted[2], w_count;
   // host entry point: sub-batches of a chunk pipelined through two slots (H2D | kernels | D2H)
   struct Slot {
-    DevBuf bases, off;
+    DevBuf bases, off, mask;                     // (mask: packed reads, the sub-batch's "not ACGT" bits)
     void* h_stage = nullptr; size_t h_cap = 0;   // pinned staging: rebased read offsets, and the bases of pageable callers
     void* h_stage_dev = nullptr;                 // the same memory as the device addresses it
     hipEvent_t in_ready = nullptr, out_done = nullptr;
@@ -2863,7 +2940,21 @@ struct psigpu_ctx {
     hsa_signal_t sig_in[IN_RING]{}, sig_out[2]{};      // 1 while the transfer is in flight (two-slot path: sig_in[0..1])
   } ec;
   double hits_per_read_hint = 0.0;
+  // psigpu_set_option
+  uint64_t opt_sub_bytes = 0;
+  bool opt_no_ahead = false, opt_no_engine_copy = false;
+  uint32_t opt_wire = 0;           // 0: the narrowest wire record that fits; 8 / 16 / 32: nothing narrower
+  uint32_t opt_wire8_roff_cap = 0; // test hook: at most this many read-offset bits in an 8-byte record
+  uint32_t wire_used = 0;          // bytes per wire record the last run_pipeline call left in its wire buffer (0: none)
+  bool wire8_overflowed = false;   // a sub-batch's records did not fit 8 bytes: the context stays with 16 from then on
 };
+
+static uint32_t bits_for(uint64_t max_value)      // bits needed to hold 0..max_value (at least 1)
+{
+  uint32_t b = 1;
+  while (b < 64 && (max_value >> b)) ++b;
+  return b;
+}
 
 static thread_local std::string g_create_err;
 
@@ -3048,8 +3139,8 @@ psigpu_ctx* psigpu_create(int device)
   psigpu_ctx* ctx = new psigpu_ctx;
   ctx->device = device;
   if (getenv("PSIGPU_UNCACHED_IO")) {           // experiment: the buffers the copy engines write / read as MTYPE UC memory
-    ctx->in_bases.uncached = true;              // (tried as the default against rare wrong records under load: a test that
-    for (auto& sl : ctx->slot) { sl.bases.uncached = true; sl.d_wire.uncached = true; }      // had never failed failed 3 times in 24 -- not kept)
+    ctx->in_bases.uncached = true; ctx->in_mask.uncached = true;      // (tried as the default against rare wrong records under load: a test that
+    for (auto& sl : ctx->slot) { sl.bases.uncached = true; sl.mask.uncached = true; sl.d_wire.uncached = true; }      // had never failed failed 3 times in 24 -- not kept)
   }
   ctx->parts.emplace_back(new psigpu_ctx::FmPart);
   for (auto& ev : ctx->ev)
@@ -3077,9 +3168,9 @@ void psigpu_destroy(psigpu_ctx* ctx)
   ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release();
   for (DevBuf* b : { &ctx->w_sb_cnt, &ctx->w_sb_off, &ctx->w_sb_tiles, &ctx->w_sb_key, &ctx->w_seed_wide, &ctx->w_seed_pfx }) b->release();
   for (auto& m : ctx->parts) m->release();
-  ctx->w_hits_alt.release(); ctx->in_bases.release();
+  ctx->w_hits_alt.release(); ctx->in_bases.release(); ctx->in_mask.release();
   for (auto& sl : ctx->slot) {
-    sl.bases.release(); sl.off.release(); sl.d_wire.release();
+    sl.bases.release(); sl.off.release(); sl.mask.release(); sl.d_wire.release();
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
     if (sl.h_wire) (void)hipHostFree(sl.h_wire);
     if (sl.in_ready) (void)hipEventDestroy(sl.in_ready);
@@ -3140,6 +3231,21 @@ int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags)
   if ((flags ^ ctx->tune) & PSIGPU_TUNE_NO_ROWRECS) drop_row_records(ctx);      // made (or not) by the next FM query
   if (((flags ^ ctx->tune) & PSIGPU_TUNE_NO_PATH_TABLE) && ctx->query_mode == PSIGPU_MODE_TRAVERSE) lkt_release(ctx);
   ctx->tune = flags;
+  return PSIGPU_OK;
+}
+
+int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value)
+{
+  if (!ctx || !name) return PSIGPU_ERR_ARG;
+  const std::string n(name);
+  if (n == "sub_bytes") ctx->opt_sub_bytes = value;
+  else if (n == "no_ahead") ctx->opt_no_ahead = value != 0;
+  else if (n == "no_engine_copy") ctx->opt_no_engine_copy = value != 0;
+  else if (n == "wire") {
+    if (value != 0 && value != 8 && value != 16 && value != 32) { ctx->err = "wire: 0, 8, 16 or 32"; return PSIGPU_ERR_ARG; }
+    ctx->opt_wire = (uint32_t)value;
+  } else if (n == "wire8_roff_bits") { ctx->opt_wire8_roff_cap = (uint32_t)value; ctx->wire8_overflowed = false; }      // (test hook)
+  else { ctx->err = "unknown option '" + n + "'"; return PSIGPU_ERR_ARG; }
   return PSIGPU_OK;
 }
 
@@ -3859,8 +3965,10 @@ static GraphView graph_view(const psigpu_ctx* ctx)
 
 static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off,
                         uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t rec_offset,
-                        uint32_t flags, hipStream_t stream, uint64_t* n_hits_out, DevBuf* wire = nullptr)
+                        uint32_t flags, hipStream_t stream, uint64_t* n_hits_out, DevBuf* wire = nullptr,
+                        const PackedIn* packed = nullptr, WireFmt wfmt = WireFmt{})
 {
+  // `packed`: d_bases is an array of 2-bit words (k_seed_pack<., true>), not ASCII
   // `wire`: the host entry's 16-byte records of the call's hits (k_hits_wire16), made behind the last kernel of the
   // call so that they are ready at its one host synchronisation
   // PSIGPU_SORT_UNIQUE here: the caller will sort -- when the hits come out seed by seed, order each seed's
@@ -4001,7 +4109,15 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   }
   if (n_seeds) {
     const unsigned pgrid = (unsigned)std::min<uint64_t>((n_seeds + 256 * SP - 1) / (256 * SP), 256 * 32);
-    if (wide)
+    if (wide && packed)
+      k_seed_pack<true, true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases,
+                                                         k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
+                                                         ctx->w_seed_wide.as<u128>(), ctx->w_seed_pfx.as<uint32_t>(), pfx_len, *packed);
+    else if (packed)
+      k_seed_pack<false, true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases,
+                                                          k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
+                                                          nullptr, nullptr, 0, *packed);
+    else if (wide)
       k_seed_pack<true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases,
                                                    k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
                                                    ctx->w_seed_wide.as<u128>(), ctx->w_seed_pfx.as<uint32_t>(), pfx_len);
@@ -4359,13 +4475,31 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
       if (fs != PSIGPU_OK) return fs;
     }
     EVREC(8, stream);
-    if (wire && cap) {
+    unsigned long long* h_wflag = reinterpret_cast<unsigned long long*>((char*)ctx->h_pinned + sizeof(DevCounters) + 32);
+    ctx->wire_used = 0;
+    if (wire && cap && wfmt.bytes) {
       HIPCHK(ctx, wire->ensure((cap + 1) * 16));
-      k_hits_wire16<<<2048, 256, 0, stream>>>(d_hits, &ctr->n_hits_tab.v, &ctr->n_hits_off.v, 0, cap, ctx->id_base, rec_offset,
-                                              wire->as<uint4>());
+      if (wfmt.bytes == 8) {
+        *h_wflag = 0;
+        k_hits_wire8<<<2048, 256, 0, stream>>>(d_hits, &ctr->n_hits_tab.v, &ctr->n_hits_off.v, 0, cap, ctx->id_base, rec_offset, wfmt,
+                                               wire->as<uint64_t>(),
+                                               reinterpret_cast<unsigned long long*>((char*)ctx->h_pinned_dev + sizeof(DevCounters) + 32));
+      } else
+        k_hits_wire16<<<2048, 256, 0, stream>>>(d_hits, &ctr->n_hits_tab.v, &ctr->n_hits_off.v, 0, cap, ctx->id_base, rec_offset,
+                                                wire->as<uint4>());
+      ctx->wire_used = wfmt.bytes;
     }
     k_publish<<<1, 256, 0, stream>>>(reinterpret_cast<const uint4*>(ctr), reinterpret_cast<uint4*>(ctx->h_pinned_dev), (uint32_t)(sizeof(DevCounters) / 16));
     HIPCHK(ctx, hipStreamSynchronize(stream));
+    if (ctx->wire_used == 8 && *h_wflag) {
+      // a field did not fit (a read longer than the bits the sub-batch left it): 16-byte records of this call's hits
+      // instead -- one more kernel and synchronisation, once; the context stays with 16 bytes
+      ctx->wire8_overflowed = true;
+      k_hits_wire16<<<2048, 256, 0, stream>>>(d_hits, &ctr->n_hits_tab.v, &ctr->n_hits_off.v, 0, cap, ctx->id_base, rec_offset,
+                                              wire->as<uint4>());
+      HIPCHK(ctx, hipStreamSynchronize(stream));
+      ctx->wire_used = 16;
+    }
     ctx->grouped_state = fix_groups ? (h.not_grouped.v ? 2 : 1) : 0;
     true_seeds = h.n_seeds_true.v;
     ctx->last_max_read_len = 0;
@@ -4467,7 +4601,7 @@ static int device_sort_unique(psigpu_ctx* ctx, uint64_t n, uint64_t n_reads, uin
   return PSIGPU_OK;
 }
 
-int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off,
+static int find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const PackedIn* packed, const uint64_t* d_read_off,
                              uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step,
                              uint64_t rec_offset, uint32_t flags, void* stream,
                              const psigpu_hit** d_hits, uint64_t* n_hits)
@@ -4476,7 +4610,7 @@ int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if ((flags & PSIGPU_ALL) == 0) flags |= PSIGPU_ALL;
   uint64_t n = 0;
-  int st = run_pipeline(ctx, d_bases, d_read_off, n_reads, n_bases, k, step, rec_offset, flags, (hipStream_t)stream, &n);
+  int st = run_pipeline(ctx, d_bases, d_read_off, n_reads, n_bases, k, step, rec_offset, flags, (hipStream_t)stream, &n, nullptr, packed);
   if (st != PSIGPU_OK) return st;
   *d_hits = ctx->w_hits.as<psigpu_hit>();
   *n_hits = n;
@@ -4489,6 +4623,25 @@ int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_
     *n_hits = n;
   }
   return PSIGPU_OK;
+}
+
+int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off,
+                             uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step,
+                             uint64_t rec_offset, uint32_t flags, void* stream,
+                             const psigpu_hit** d_hits, uint64_t* n_hits)
+{
+  return find_seeds_device(ctx, d_bases, nullptr, d_read_off, n_reads, n_bases, k, step, rec_offset, flags, stream, d_hits, n_hits);
+}
+
+int psigpu_find_seeds_device_packed(psigpu_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_n_mask,
+                                    const uint64_t* d_read_off, uint64_t n_reads, uint64_t n_bases, uint32_t k,
+                                    uint32_t step, uint64_t rec_offset, uint32_t flags, void* stream,
+                                    const psigpu_hit** d_hits, uint64_t* n_hits)
+{
+  if (n_bases && !d_packed) return PSIGPU_ERR_ARG;
+  const PackedIn pk{ d_n_mask, 0, 0 };
+  return find_seeds_device(ctx, reinterpret_cast<const char*>(d_packed), &pk, d_read_off, n_reads, n_bases, k, step, rec_offset, flags,
+                           stream, d_hits, n_hits);
 }
 
 int psigpu_find_mems(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off, uint64_t n_reads, uint32_t minlen,
@@ -4686,8 +4839,18 @@ namespace {
 // Widening of the wire records (k_hits_wire16) into the caller's 32-byte records on a few host threads, sub-batch
 // after sub-batch, while the pipeline goes on.  Job j: `n` records from a slot's pinned landing buffer to `dst`;
 // thread 0 waits for the slot's transfer, then every thread widens its slice.
+// one 32-byte record into the caller's (pinned) array with two streaming stores: the array is written once, front
+// to back, 224 MB per 1 M-read chunk -- ordinary stores would first READ every line they fill
+static inline void store_hit(psigpu_hit* dst, uint64_t node, uint64_t noff, uint64_t read, uint64_t roff)
+{
+  typedef long long v2 __attribute__((vector_size(16)));
+  v2 lo = { (long long)node, (long long)noff }, hi = { (long long)read, (long long)roff };
+  __builtin_nontemporal_store(lo, reinterpret_cast<v2*>(dst));
+  __builtin_nontemporal_store(hi, reinterpret_cast<v2*>(dst) + 1);
+}
+
 struct Widener {
-  struct Job { const uint4* src; psigpu_hit* dst; uint64_t n, id_base, rec_base; int slot; };
+  struct Job { const void* src; psigpu_hit* dst; uint64_t n, id_base, rec_base; int slot; WireFmt fmt; };
   std::vector<Job> jobs;
   std::atomic<size_t> posted{ 0 }, ready{ 0 };
   // slices done, PER JOB: thread 0 may be a job ahead of a thread that was descheduled inside the job before, so a
@@ -4722,10 +4885,25 @@ struct Widener {
       if (t == 0) { if (job.n) wait_copy(job.slot); ready.store(j + 1, std::memory_order_release); }
       else while (ready.load(std::memory_order_acquire) <= j) { if (stop.load()) return; std::this_thread::yield(); }
       const uint64_t a = job.n * t / T, b = job.n * (t + 1) / T;
-      for (uint64_t i = a; i < b; ++i) {
-        const uint4 w = job.src[i];
-        job.dst[i] = psigpu_hit{ job.id_base + w.x, w.y, job.rec_base + w.z, w.w };
+      if (job.fmt.bytes == 8) {
+        const uint64_t* src = static_cast<const uint64_t*>(job.src);
+        const uint32_t nb = job.fmt.noff_bits, vb = job.fmt.node_bits, rb = job.fmt.roff_bits;
+        const uint64_t nm = (1ull << nb) - 1, vm = (1ull << vb) - 1, rm = (1ull << rb) - 1;
+        for (uint64_t i = a; i < b; ++i) {
+          uint64_t key = src[i];
+          const uint64_t noff = key & nm; key >>= nb;
+          const uint64_t node = key & vm; key >>= vb;
+          const uint64_t roff = key & rm; key >>= rb;
+          store_hit(job.dst + i, job.id_base + node, noff, job.rec_base + key, roff);
+        }
+      } else {
+        const uint4* src = static_cast<const uint4*>(job.src);
+        for (uint64_t i = a; i < b; ++i) {
+          const uint4 w = src[i];
+          store_hit(job.dst + i, job.id_base + w.x, w.y, job.rec_base + w.z, w.w);
+        }
       }
+      __builtin_ia32_sfence();                   // the streaming stores above, before the slice is declared done
       parts[j].fetch_add(1, std::memory_order_acq_rel);
     }
   }
@@ -4756,7 +4934,7 @@ static void engine_copy_init(psigpu_ctx* ctx)
 {
   psigpu_ctx::EngineCopy& ec = ctx->ec;
   ec.ok = false;
-  if (getenv("PSIGPU_NO_ENGINE_COPY")) return;
+  if (getenv("PSIGPU_NO_ENGINE_COPY") || ctx->opt_no_engine_copy) return;
   if (!g_hsa.init()) return;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return;
@@ -4810,21 +4988,29 @@ static int pipeline_init(psigpu_ctx* ctx)
 }
 
 // one transfer of the pipeline: `slot_sig` goes 1 -> 0 when it is complete
-static bool engine_copy(psigpu_ctx* ctx, bool to_device, void* dst, const void* src, size_t bytes, hsa_signal_t slot_sig)
+// (`n_transfers`: how many transfers will complete on this signal -- packed reads move two arrays per sub-batch;
+// every completed transfer takes one off, the waiter waits for 0)
+static bool engine_copy_more(psigpu_ctx* ctx, bool to_device, void* dst, const void* src, size_t bytes, hsa_signal_t slot_sig)
 {
   const psigpu_ctx::EngineCopy& ec = ctx->ec;
-  hsa_signal_store_relaxed(slot_sig, 1);
-  hsa_status_t st = hsa_amd_memory_async_copy_on_engine(dst, to_device ? ec.gpu : ec.cpu, src, to_device ? ec.cpu : ec.gpu, bytes,
-                                                         0, nullptr, slot_sig,
-                                                         (hsa_amd_sdma_engine_id_t)(to_device ? ec.eng_in : ec.eng_out), true);
-  if (st != HSA_STATUS_SUCCESS) { hsa_signal_store_relaxed(slot_sig, 0); return false; }
+  return hsa_amd_memory_async_copy_on_engine(dst, to_device ? ec.gpu : ec.cpu, src, to_device ? ec.cpu : ec.gpu, bytes,
+                                             0, nullptr, slot_sig,
+                                             (hsa_amd_sdma_engine_id_t)(to_device ? ec.eng_in : ec.eng_out), true) == HSA_STATUS_SUCCESS;
+}
+
+static bool engine_copy(psigpu_ctx* ctx, bool to_device, void* dst, const void* src, size_t bytes, hsa_signal_t slot_sig, int n_transfers = 1)
+{
+  hsa_signal_store_relaxed(slot_sig, n_transfers);
+  if (!engine_copy_more(ctx, to_device, dst, src, bytes, slot_sig)) { hsa_signal_store_relaxed(slot_sig, 0); return false; }
   return true;
 }
 
-static void engine_wait(hsa_signal_t sig)
+static void engine_wait_value(hsa_signal_t sig, int64_t below)
 {
-  while (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) { }
+  while (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, below, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= below) { }
 }
+
+static void engine_wait(hsa_signal_t sig) { engine_wait_value(sig, 1); }
 
 // One chunk through the host entry point = SURVEY 8(d)'s timed region: H2D of the reads, kernels, D2H
 // of the hits.  The chunk is cut into sub-batches of contiguous reads that flow through two slots:
@@ -4834,9 +5020,28 @@ static void engine_wait(hsa_signal_t sig)
 // staged through pinned buffers by a helper thread that runs ahead of the compute loop.  With
 // PSIGPU_SORT_UNIQUE every sub-batch is sorted on the device; sub-batches are contiguous read
 // ranges, so their concatenation is the sorted chunk.
-int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off, uint64_t n_reads,
-                      uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, psigpu_hits* out)
+//
+// The reads of a chunk as the caller hands them over: ASCII bases back to back (psigpu_find_seeds), or 2-bit codes in
+// u64 words + an optional "not ACGT" bit per base (psigpu_find_seeds_packed; layout at k_seed_pack).  read_off counts
+// BASES either way.  A sub-batch [b0, b1) of bases is then a byte range of each source array: cut at word boundaries
+// for the packed arrays, so that words stay 8-byte aligned on the device.
+struct ReadsIn {
+  const char* ascii = nullptr;
+  const uint64_t* words = nullptr;
+  const uint64_t* mask = nullptr;
+  bool packed() const { return words != nullptr; }
+  // main array (bases / 2-bit words): first byte, byte count, and the base index the first byte's first base has
+  size_t main_byte0(uint64_t b0) const { return packed() ? (size_t)(b0 >> 5) * 8 : (size_t)b0; }
+  size_t main_bytes(uint64_t b0, uint64_t b1) const { return b1 == b0 ? 0 : packed() ? (size_t)(((b1 + 31) >> 5) - (b0 >> 5)) * 8 : (size_t)(b1 - b0); }
+  const char* main_ptr() const { return packed() ? reinterpret_cast<const char*>(words) : ascii; }
+  size_t mask_byte0(uint64_t b0) const { return (size_t)(b0 >> 6) * 8; }
+  size_t mask_bytes(uint64_t b0, uint64_t b1) const { return (mask && b1 != b0) ? (size_t)(((b1 + 63) >> 6) - (b0 >> 6)) * 8 : 0; }
+};
+
+static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* read_off, uint64_t n_reads,
+                           uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, psigpu_hits* out)
 {
+  const char* bases = in.main_ptr();
   if (!ctx || !out || (n_reads && (!read_off))) return PSIGPU_ERR_ARG;
   const auto t_entry = std::chrono::steady_clock::now();
   out->n = 0; out->data = nullptr;
@@ -4857,7 +5062,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   // the one part of the call nothing overlaps with)
   // (PSIGPU_SUB_BYTES: tests force many sub-batches on small inputs)
   const char* sub_env = getenv("PSIGPU_SUB_BYTES");
-  const uint64_t SUB_BYTES = sub_env ? std::max<uint64_t>(1, strtoull(sub_env, nullptr, 10)) : (16ull << 20);
+  const uint64_t SUB_BYTES = ctx->opt_sub_bytes ? ctx->opt_sub_bytes : sub_env ? std::max<uint64_t>(1, strtoull(sub_env, nullptr, 10)) : (16ull << 20);
   { int st = pipeline_init(ctx); if (st != PSIGPU_OK) return st; }
   // Reads AND offsets in pinned memory (psi::Records of the shim, psikt): the chunk's reads go to one device buffer
   // and their transfers are queued up to IN_RING sub-batches ahead of the compute loop, so that the copy engine
@@ -4865,10 +5070,10 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   // sort and synchronisations take longer than its transfer); the offsets are rebased by a kernel that reads the
   // caller's array in place.  150 calls of either path alternated in one process (tools/e2e_ab3.py; the boxes are
   // shared and a call varies between 3.6 and 5.3 ms): median 4.37 ms against 4.56, minimum 3.64 against 3.80.
-  ptrdiff_t pin_delta = 0, off_delta = 0;
-  const bool pinned_in = n_bases == 0 || host_ptr_is_pinned(bases, &pin_delta);
+  ptrdiff_t pin_delta = 0, off_delta = 0, mask_delta = 0;
+  const bool pinned_in = n_bases == 0 || (host_ptr_is_pinned(bases, &pin_delta) && (!in.mask || host_ptr_is_pinned(in.mask, &mask_delta)));
   const bool env_no_ahead = getenv("PSIGPU_NO_AHEAD") != nullptr;      // A/B: the two-slot path (read per call: tools/e2e_ab3.py alternates)
-  const bool ahead_ok = pinned_in && n_bases && ctx->ec.ok && !env_no_ahead && host_ptr_is_pinned(read_off, &off_delta);
+  const bool ahead_ok = pinned_in && n_bases && ctx->ec.ok && !env_no_ahead && !ctx->opt_no_ahead && host_ptr_is_pinned(read_off, &off_delta);
   std::vector<uint64_t> cut{ 0 };
   {
     // piece sizes in bytes of bases: SUB/8, SUB/4, SUB/2, SUB ... SUB -- small at the start: what precedes the first
@@ -4903,12 +5108,23 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   constexpr size_t IN_RING = psigpu_ctx::EngineCopy::IN_RING;
   size_t issued = 0;
   auto issue_in = [&](size_t j) -> bool {
-    const uint64_t b0 = read_off[cut[j]], nb = read_off[cut[j + 1]] - b0;
-    if (nb == 0) { hsa_signal_store_relaxed(ctx->ec.sig_in[j % IN_RING], 0); return true; }
-    return engine_copy(ctx, true, (char*)ctx->in_bases.p + b0, bases + pin_delta + b0, nb, ctx->ec.sig_in[j % IN_RING]);
+    const uint64_t b0 = read_off[cut[j]], b1 = read_off[cut[j + 1]], nb = b1 - b0;
+    hsa_signal_t sg = ctx->ec.sig_in[j % IN_RING];
+    if (nb == 0) { hsa_signal_store_relaxed(sg, 0); return true; }
+    // (packed reads: neighbouring sub-batches share their boundary word -- both transfers write the same bytes there)
+    const size_t m0 = in.main_byte0(b0), mb = in.main_bytes(b0, b1), k0 = in.mask_byte0(b0), kb = in.mask_bytes(b0, b1);
+    const int n_copies = kb ? 2 : 1;
+    if (!engine_copy(ctx, true, (char*)ctx->in_bases.p + m0, bases + pin_delta + m0, mb, sg, n_copies)) return false;
+    if (kb && !engine_copy_more(ctx, true, (char*)ctx->in_mask.p + k0, (const char*)in.mask + mask_delta + k0, kb, sg)) {
+      engine_wait_value(sg, 2);                  // the first transfer is on its way: wait for it, then fail
+      hsa_signal_store_relaxed(sg, 0);
+      return false;
+    }
+    return true;
   };
   if (ahead) {
-    HIPCHK(ctx, ctx->in_bases.ensure(n_bases + 64));
+    HIPCHK(ctx, ctx->in_bases.ensure(in.main_bytes(0, n_bases) + 64));
+    if (in.mask) HIPCHK(ctx, ctx->in_mask.ensure(in.mask_bytes(0, n_bases) + 64));
     for (; issued < std::min(n_sub, IN_RING); ++issued)
       if (!issue_in(issued)) {
         for (size_t j = 0; j < issued; ++j) engine_wait(ctx->ec.sig_in[j]);
@@ -4922,9 +5138,11 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   auto stage_in = [&](size_t j) -> hipError_t {
     psigpu_ctx::Slot& sl = ctx->slot[j & 1];
     const uint64_t r0 = cut[j], r1 = cut[j + 1], nr = r1 - r0;
-    const uint64_t b0 = read_off[r0], nb = read_off[r1] - b0;
+    const uint64_t b0 = read_off[r0], b1 = read_off[r1], nb = b1 - b0;
+    const size_t mbytes = in.main_bytes(b0, b1), kbytes = in.mask_bytes(b0, b1);
+    const size_t mstage = (mbytes + 255) & ~(size_t)255;
     const size_t off_bytes = ((nr + 1) * 8 + 255) & ~(size_t)255;
-    const size_t need = off_bytes + (pinned_in ? 0 : nb);
+    const size_t need = off_bytes + (pinned_in ? 0 : mstage + kbytes);
     if (need > sl.h_cap) {
       if (sl.h_stage) (void)hipHostFree(sl.h_stage);
       sl.h_stage = nullptr; sl.h_cap = 0;
@@ -4933,21 +5151,35 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
       if (e != hipSuccess) return e;
       sl.h_cap = need + need / 4 + 4096;
     }
-    hipError_t e = sl.bases.ensure(nb + 64);
+    hipError_t e = sl.bases.ensure(mbytes + 64);
     if (e == hipSuccess) e = sl.off.ensure((nr + 1) * 8);
+    if (e == hipSuccess && in.mask) e = sl.mask.ensure(kbytes + 64);
     if (e != hipSuccess) return e;
     uint64_t* ho = reinterpret_cast<uint64_t*>(sl.h_stage);
     for (uint64_t r = 0; r <= nr; ++r) ho[r] = read_off[r0 + r] - b0;
-    const char* src = bases + b0;
-    if (!pinned_in && nb) { parallel_copy((char*)sl.h_stage + off_bytes, src, nb); src = (char*)sl.h_stage + off_bytes; }
-    // one transfer per sub-batch (the read offsets reach the device through k_publish from this
+    const char* src = bases + in.main_byte0(b0);
+    const char* msrc = in.mask ? (const char*)in.mask + in.mask_byte0(b0) : nullptr;
+    if (!pinned_in && nb) {
+      parallel_copy((char*)sl.h_stage + off_bytes, src, mbytes); src = (char*)sl.h_stage + off_bytes;
+      if (kbytes) { memcpy((char*)sl.h_stage + off_bytes + mstage, msrc, kbytes); msrc = (char*)sl.h_stage + off_bytes + mstage; }
+    }
+    // one transfer per sub-batch and array (the read offsets reach the device through k_publish from this
     // mapped staging buffer)
     if (trace_in) trace_in(0);
     if (ctx->ec.ok) {
-      if (nb == 0) hsa_signal_store_relaxed(ctx->ec.sig_in[j & 1], 0);
-      else if (!engine_copy(ctx, true, sl.bases.p, pinned_in ? src + pin_delta : src, nb, ctx->ec.sig_in[j & 1])) return hipErrorUnknown;
+      hsa_signal_t sg = ctx->ec.sig_in[j & 1];
+      if (nb == 0) hsa_signal_store_relaxed(sg, 0);
+      else {
+        if (!engine_copy(ctx, true, sl.bases.p, pinned_in ? src + pin_delta : src, mbytes, sg, kbytes ? 2 : 1)) return hipErrorUnknown;
+        if (kbytes && !engine_copy_more(ctx, true, sl.mask.p, pinned_in ? msrc + mask_delta : msrc, kbytes, sg)) {
+          engine_wait_value(sg, 2);
+          hsa_signal_store_relaxed(sg, 0);
+          return hipErrorUnknown;
+        }
+      }
     } else {
-      if (nb) e = hipMemcpyAsync(sl.bases.p, src, nb, hipMemcpyHostToDevice, ctx->s_in);
+      if (nb) e = hipMemcpyAsync(sl.bases.p, src, mbytes, hipMemcpyHostToDevice, ctx->s_in);
+      if (e == hipSuccess && kbytes) e = hipMemcpyAsync(sl.mask.p, msrc, kbytes, hipMemcpyHostToDevice, ctx->s_in);
       if (e == hipSuccess) e = hipEventRecord(sl.in_ready, ctx->s_in);
     }
     if (trace_in) trace_in(1);
@@ -5012,7 +5244,22 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
 
   // 16-byte records over the link, widened on the host (k_hits_wire16): when the node ids are rank + constant
   static const bool env_no_wire = getenv("PSIGPU_NO_WIRE16") != nullptr;      // A/B: 32-byte records over the link
-  const bool wire16 = ctx->id_affine && !env_no_wire;
+  static const bool env_no_wire8 = getenv("PSIGPU_NO_WIRE8") != nullptr;      // A/B: 16-byte records at the least
+  const bool wire16 = ctx->id_affine && !env_no_wire && ctx->opt_wire != 32;
+  // 8-byte records (k_hits_wire8) when the node fields leave the read fields enough bits; per sub-batch: its read count
+  // sets the read-id bits, the read offset gets the rest
+  const uint32_t w_noff_bits = bits_for(ctx->max_node_len), w_node_bits = bits_for(ctx->n_nodes ? ctx->n_nodes - 1 : 0);
+  auto wire_fmt = [&](uint64_t nr_) {
+    WireFmt f;
+    if (!wire16) return f;
+    f.bytes = 16;
+    if (env_no_wire8 || ctx->opt_wire == 16 || ctx->wire8_overflowed) return f;
+    const uint32_t used = w_noff_bits + w_node_bits + bits_for(nr_ ? nr_ - 1 : 0);
+    if (used + 8 > 64) return f;                  // fewer than 8 bits for the read offset: not worth trying
+    f.bytes = 8; f.noff_bits = w_noff_bits; f.node_bits = w_node_bits; f.roff_bits = std::min<uint32_t>(32, 64 - used);
+    if (ctx->opt_wire8_roff_cap) f.roff_bits = std::min(f.roff_bits, ctx->opt_wire8_roff_cap);      // (tests: make a long read overflow)
+    return f;
+  };
   Widener widener;                                  // (destroyed -- joined -- before hp can be handed back on an error path)
   if (wire16) {
     wd = &widener;
@@ -5037,6 +5284,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     if (!ctx->ec.ok) trace_in = [&](int) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, ctx->s_in); tin.push_back(e); };
   }
   bool host_sort = false;            // some sub-batch did not fit the device sorter's key
+  uint32_t wire_widest = 0;          // bytes per wire record, the widest any sub-batch used
   hipStream_t sc = ctx->s_comp;
   if (!use_thread && !ahead) {
     hipError_t e = stage_in(0);
@@ -5077,9 +5325,22 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
     else
       k_publish<<<64, 256, 0, sc>>>(reinterpret_cast<const uint4*>(sl.h_stage_dev), sl.off.as<uint4>(), (uint32_t)(((nr + 1) * 8 + 15) / 16));
     if (wire16 && i >= 2) widener.wait_finished(i - 1);          // the slot's landing buffer: job i - 2 has been widened
-    int st = run_pipeline(ctx, ahead ? (const char*)ctx->in_bases.p + read_off[r0] : sl.bases.as<char>(), sl.off.as<uint64_t>(), nr, nb, k, step, rec_offset + r0,
+    // where the sub-batch's bases lie on the device: behind the chunk's earlier ones (transfers queued ahead: one
+    // buffer for the chunk) or at the start of the slot's buffer -- for packed reads from the word that holds b0
+    const uint64_t b0_ = read_off[r0];
+    PackedIn pk{ nullptr, 0, 0 };
+    if (in.packed()) {
+      pk.mask = in.mask ? (ahead ? ctx->in_mask.as<uint64_t>() : sl.mask.as<uint64_t>()) : nullptr;
+      pk.bias2 = ahead ? b0_ : (b0_ & 31);
+      pk.biasm = ahead ? b0_ : (b0_ & 63);
+    }
+    const char* d_in = in.packed() ? (ahead ? ctx->in_bases.as<char>() : sl.bases.as<char>())
+                                   : (ahead ? (const char*)ctx->in_bases.p + b0_ : sl.bases.as<char>());
+    int st = run_pipeline(ctx, d_in, sl.off.as<uint64_t>(), nr, nb, k, step, rec_offset + r0,
                           flags | ((want_sort && !host_sort && getenv("PSIGPU_NO_GROUPED_SORT") == nullptr) ? PSIGPU_SORT_UNIQUE : 0u), sc, &n,
-                          wire16 ? &sl.d_wire : nullptr);
+                          wire16 ? &sl.d_wire : nullptr, in.packed() ? &pk : nullptr, wire_fmt(nr));
+    WireFmt wf = wire_fmt(nr);
+    if (wf.bytes == 8 && ctx->wire_used == 16) wf = WireFmt{ 16, 0, 0, 0 };      // (the call fell back: a field did not fit)
     if (st != PSIGPU_OK) return fail(st);
     if (trace) tr.push_back(now_ms() - t_call);
     consumed.store(i + 1, std::memory_order_release);
@@ -5104,9 +5365,20 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
       // their wire form is made now (one more synchronisation)
       hipError_t e = sl.d_wire.ensure((n + 1) * 16);
       if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
-      k_hits_wire16<<<2048, 256, 0, sc>>>(src, nullptr, nullptr, n, n, ctx->id_base, rec_offset + r0, sl.d_wire.as<uint4>());
-      if (hipStreamSynchronize(sc) != hipSuccess) { ctx->err = "hipStreamSynchronize"; return fail(PSIGPU_ERR_DEVICE); }
+      unsigned long long* h_wflag = reinterpret_cast<unsigned long long*>((char*)ctx->h_pinned + sizeof(DevCounters) + 32);
+      if (wf.bytes == 8) {
+        *h_wflag = 0;
+        k_hits_wire8<<<2048, 256, 0, sc>>>(src, nullptr, nullptr, n, n, ctx->id_base, rec_offset + r0, wf, sl.d_wire.as<uint64_t>(),
+                                           reinterpret_cast<unsigned long long*>((char*)ctx->h_pinned_dev + sizeof(DevCounters) + 32));
+        if (hipStreamSynchronize(sc) != hipSuccess) { ctx->err = "hipStreamSynchronize"; return fail(PSIGPU_ERR_DEVICE); }
+        if (*h_wflag) { ctx->wire8_overflowed = true; wf = WireFmt{ 16, 0, 0, 0 }; }
+      }
+      if (wf.bytes == 16) {
+        k_hits_wire16<<<2048, 256, 0, sc>>>(src, nullptr, nullptr, n, n, ctx->id_base, rec_offset + r0, sl.d_wire.as<uint4>());
+        if (hipStreamSynchronize(sc) != hipSuccess) { ctx->err = "hipStreamSynchronize"; return fail(PSIGPU_ERR_DEVICE); }
+      }
     }
+    if (wire_now && n) wire_widest = std::max(wire_widest, wf.bytes);
     if (n) {
       // extrapolate from the reads seen so far when the reservation turns out too small
       if (done + n > out_cap) {
@@ -5127,7 +5399,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
           e = hipHostMalloc(&sl.h_wire, want, hipHostMallocDefault);
           if (e == hipSuccess) sl.h_wire_cap = want;
         }
-        h_dst = sl.h_wire; d_src = sl.d_wire.p; bytes = n * 16;
+        h_dst = sl.h_wire; d_src = sl.d_wire.p; bytes = n * wf.bytes;
       }
       if (e != hipSuccess) { /* reported below */ }
       else if (ctx->ec.ok) {
@@ -5137,7 +5409,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
         if (e == hipSuccess) e = hipEventRecord(sl.out_done, ctx->s_out);
       }
       if (wire_now && e == hipSuccess)
-        widener.post(i, Widener::Job{ (const uint4*)sl.h_wire, hp + done, n, ctx->id_base, rec_offset + r0, (int)(i & 1) });
+        widener.post(i, Widener::Job{ sl.h_wire, hp + done, n, ctx->id_base, rec_offset + r0, (int)(i & 1), wf });
       if (trace) { tr.push_back(now_ms() - t_call); tmark(ctx->s_out); }
       if (e != hipSuccess) { ctx->err = std::string("copying the hits out: ") + hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
       done += n;
@@ -5145,7 +5417,7 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
       if (ctx->ec.ok) hsa_signal_store_relaxed(ctx->ec.sig_out[i & 1], 0);
       else if (hipEventRecord(sl.out_done, ctx->s_out) != hipSuccess) { ctx->err = "hipEventRecord"; return fail(PSIGPU_ERR_DEVICE); }
     }
-    if (wire16 && !(wire_now && n)) widener.post(i, Widener::Job{ nullptr, nullptr, 0, 0, 0, (int)(i & 1) });      // (jobs and sub-batches count alike)
+    if (wire16 && !(wire_now && n)) widener.post(i, Widener::Job{ nullptr, nullptr, 0, 0, 0, (int)(i & 1), WireFmt{} });      // (jobs and sub-batches count alike)
     if (src == ctx->w_hits.as<psigpu_hit>()) std::swap(ctx->w_hits, ctx->w_hits_alt);    // the next sub-batch writes the other buffer
     // counters of the chunk = sums over its sub-batches
     acc.n_reads += pc.n_reads; acc.n_seeds += pc.n_seeds; acc.n_seeds_valid += pc.n_seeds_valid;
@@ -5188,12 +5460,31 @@ int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_o
   if (want_sort && host_sort && done) done = sort_unique_hits(hp, done);      // records wider than the device key
   if (n_reads) ctx->hits_per_read_hint = std::max(ctx->hits_per_read_hint * 0.9, (double)done / (double)n_reads);
   acc.n_hits = done;
-  acc.wire_bytes_per_hit = (wire16 && !host_sort) ? 16u : 32u;
+  acc.wire_bytes_per_hit = (wire16 && !host_sort && wire_widest) ? wire_widest : 32u;
   ctx->last = acc;
   if (done == 0) { if (hp) g_pinned.put(hp); hp = nullptr; }
   out->data = hp;
   out->n = done;
   return PSIGPU_OK;
+}
+
+int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off, uint64_t n_reads,
+                      uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, psigpu_hits* out)
+{
+  ReadsIn in;
+  in.ascii = bases;
+  return find_seeds_host(ctx, in, read_off, n_reads, k, step, rec_offset, flags, out);
+}
+
+int psigpu_find_seeds_packed(psigpu_ctx* ctx, const uint64_t* packed, const uint64_t* n_mask, const uint64_t* read_off,
+                             uint64_t n_reads, uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, psigpu_hits* out)
+{
+  if (n_reads && read_off && read_off[n_reads] && !packed) return PSIGPU_ERR_ARG;
+  ReadsIn in;
+  static const uint64_t none = 0;
+  in.words = packed ? packed : &none;           // (a chunk without bases: still "packed")
+  in.mask = n_mask;
+  return find_seeds_host(ctx, in, read_off, n_reads, k, step, rec_offset, flags, out);
 }
 
 void psigpu_free_hits(psigpu_hits* hits)

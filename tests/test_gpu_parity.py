@@ -1119,6 +1119,138 @@ def test_host_entry_pipeline_equals_one_batch(monkeypatch, sub_bytes, pinned):
     f.close()
 
 
+def _ragged_reads(reads, k):
+    out = []
+    for i, r in enumerate(reads):
+        out += [r, r[:k + (i % 7)], '', r[:40] + 'N' + r[41:], r[:30].lower() + r[30:], 'NNNN' + r[4:50]] if i % 5 == 0 else [r]
+    return out
+
+
+@pytest.mark.parametrize('k,step', [(21, 5), (8, 1), (31, 31), (40, 9), (63, 20)])
+@pytest.mark.parametrize('pinned', [False, True])
+def test_packed_reads_equal_ascii(k, step, pinned):
+    """psigpu_find_seeds_packed (2-bit words + a "not ACGT" bit per base, read offsets in bases) returns the records of
+    psigpu_find_seeds on the same reads -- ragged reads, N, lower case, reads shorter than k, empty reads -- in one
+    piece and cut into many sub-batches (boundaries inside a word), raw and sorted; the reference keeps reads as one
+    byte per base (sequence.hpp:1130-1294) and the packed form is the link format of round 4."""
+    g, reads = _x_case()
+    ragged = _ragged_reads(reads[:300], k)
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(2, rng_seed=3)
+    f.set_option('sub_bytes', 1 << 30)
+    want_raw = f.seeds_all(ragged, step=step, rec_offset=1000)
+    want = f.seeds_all(ragged, step=step, rec_offset=1000, sort_unique=True)
+    assert len(want)
+    bases, off = psi_amd.pack_reads(ragged)
+    pr = psi_amd.PackedReads(bases, off, pinned=bool(pinned), threads=3)
+    assert pr.n_not_acgt > 0 and pr.mask is not None
+    for sub in (1 << 30, 31, 64, 1000, 30_000):
+        f.set_option('sub_bytes', sub)
+        for no_ahead in ((0, 1) if pinned else (0,)):
+            f.set_option('no_ahead', no_ahead)
+            raw = f.seeds_all_packed(pr, step=step, rec_offset=1000)
+            assert len(raw) == len(want_raw) and _eq(psi_amd.sort_unique(raw), psi_amd.sort_unique(want_raw)), (sub, no_ahead)
+            assert f.counters()['n_reads'] == len(ragged)
+            assert _eq(f.seeds_all_packed(pr, step=step, rec_offset=1000, sort_unique=True), want), (sub, no_ahead)
+    # no mask at all when every base is ACGT
+    clean = [r.upper().replace('N', 'A') for r in ragged]
+    pc = psi_amd.PackedReads(*psi_amd.pack_reads(clean), pinned=bool(pinned))
+    assert pc.mask is None
+    f.set_option('sub_bytes', 500)
+    assert _eq(f.seeds_all_packed(pc, step=step, sort_unique=True), f.seeds_all(clean, step=step, sort_unique=True))
+    # phases
+    assert _eq(psi_amd.sort_unique(f.seeds_all_packed(pr, step=step, flags=psi_amd.ON_PATHS)),
+               psi_amd.sort_unique(f.seeds_on_paths(ragged, step=step)))
+    # an empty chunk, a chunk of empty reads
+    e = psi_amd.PackedReads(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert len(f.seeds_all_packed(e, step=step)) == 0
+    e3 = psi_amd.PackedReads(np.zeros(0, np.uint8), np.zeros(4, np.uint64))
+    assert len(f.seeds_all_packed(e3, step=step)) == 0
+    f.close()
+
+
+def test_packed_device_entry_equals_ascii():
+    """psigpu_find_seeds_device_packed: the device-resident chunk as 2-bit words."""
+    import torch
+    g, reads = _x_case()
+    k, step = 21, 3
+    ragged = _ragged_reads(reads[:400], k)
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(1, rng_seed=3)
+    bases, off = psi_amd.pack_reads(ragged)
+    pr = psi_amd.PackedReads(bases, off)
+    d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    d_w, d_m = torch.from_numpy(pr.words.view(np.int64)).cuda(), torch.from_numpy(pr._mask_store.view(np.int64)).cuda()
+    for flags in (psi_amd.ALL, psi_amd.ALL | psi_amd.SORT_UNIQUE):
+        ptr, n = f.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(ragged), len(bases), step=step, rec_offset=5, flags=flags)
+        a = f.copy_hits(ptr, n)
+        ptr, n = f.seeds_all_device_packed(d_w.data_ptr(), d_m.data_ptr(), d_o.data_ptr(), len(ragged), len(bases), step=step,
+                                           rec_offset=5, flags=flags)
+        b = f.copy_hits(ptr, n)
+        assert len(a) and (_eq(a, b) if flags & psi_amd.SORT_UNIQUE else _eq(psi_amd.sort_unique(a), psi_amd.sort_unique(b)))
+    f.close()
+
+
+@pytest.mark.parametrize('pinned', [False, True])
+def test_wire_record_formats_agree(pinned):
+    """The records cross the device-to-host link as 8-byte keys (round 4), 16-byte records (round 3) or as they are
+    (32 bytes): same records, same order.  An 8-byte key whose read-offset field is too narrow for a read of the
+    sub-batch (forced here through the test hook) is detected on the device and the sub-batch goes out as 16-byte
+    records instead."""
+    g, reads = _x_case()
+    k, step = 21, 5
+    ragged = _ragged_reads(reads[:300], k)
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(2, rng_seed=3)
+    bases, off = psi_amd.pack_reads(ragged)
+    keep = [psi_amd.pinned_copy(bases), psi_amd.pinned_copy(off)] if pinned else []
+    src = (keep[0].array, keep[1].array) if pinned else (bases, off)
+    f.set_option('wire', 32)
+    want_raw = psi_amd.sort_unique(f.seeds_all(src, step=step, rec_offset=9))
+    want = f.seeds_all(src, step=step, rec_offset=9, sort_unique=True)
+    assert f.counters()['wire_bytes_per_hit'] == 32
+    for sub in (1 << 30, 700):
+        f.set_option('sub_bytes', sub)
+        for wire, expect in ((0, 8), (8, 8), (16, 16), (32, 32)):
+            f.set_option('wire', wire)
+            assert _eq(psi_amd.sort_unique(f.seeds_all(src, step=step, rec_offset=9)), want_raw), (sub, wire)
+            assert f.counters()['wire_bytes_per_hit'] == expect
+            assert _eq(f.seeds_all(src, step=step, rec_offset=9, sort_unique=True), want), (sub, wire)
+            assert f.counters()['wire_bytes_per_hit'] == expect
+        # a read-offset field of 4 bits: offsets beyond 15 do not fit -> 16-byte records, same answer
+        f.set_option('wire', 0)
+        f.set_option('wire8_roff_bits', 4)
+        assert _eq(f.seeds_all(src, step=step, rec_offset=9, sort_unique=True), want)
+        assert f.counters()['wire_bytes_per_hit'] == 16
+        assert _eq(psi_amd.sort_unique(f.seeds_all(src, step=step, rec_offset=9)), want_raw)
+        f.set_option('wire8_roff_bits', 0)
+        assert _eq(f.seeds_all(src, step=step, rec_offset=9, sort_unique=True), want)
+        assert f.counters()['wire_bytes_per_hit'] == 8
+    with pytest.raises(psi_amd.PsiGpuError):
+        f.set_option('no_such_option', 1)
+    f.close()
+
+
+def test_wire_formats_through_the_radix_sort(monkeypatch):
+    """... and when the general sort route runs (PSIGPU_NO_GROUPED_SORT), where the wire records are made after the sort."""
+    monkeypatch.setenv('PSIGPU_NO_GROUPED_SORT', '1')
+    g, reads = _x_case()
+    k, step = 21, 5
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(3, rng_seed=1)
+    f.set_option('wire', 32)
+    want = f.seeds_all(reads[:300], step=step, sort_unique=True)
+    for wire in (0, 16):
+        f.set_option('wire', wire)
+        f.set_option('sub_bytes', 2000)
+        assert _eq(f.seeds_all(reads[:300], step=step, sort_unique=True), want)
+    f.set_option('wire', 0)
+    f.set_option('wire8_roff_bits', 3)
+    assert _eq(f.seeds_all(reads[:300], step=step, sort_unique=True), want)
+    assert f.counters()['wire_bytes_per_hit'] == 16
+    f.close()
+
+
 @pytest.mark.parametrize('query_mode', ['kmer-table', 'locus-table'], indirect=True)
 def test_host_entry_with_the_host_oversubscribed(monkeypatch, query_mode):
     """The host entry's helper threads (widening of the 16-byte wire records, staging of pageable reads) next to

@@ -1,0 +1,41 @@
+"""Hit sets under GPU SHARING (round-3 review, item 1): several contexts + host threads in one process and several
+processes on the one GPU, against the brute-force definition; zero mismatches and zero abnormal exits required.
+The reference is single-threaded and deterministic (include/psi/seed_finder.hpp:1724-1732): so must every context be,
+whatever runs beside it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_contexts_threads_and_processes_share_the_gpu():
+    """4 processes x 4 threads (a context per thread at a time, finders made and destroyed all along) over 2 000 random
+    graphs: device entry and host entry (pageable / pinned / packed reads, raw / sorted, 8- / 16- / 32-byte wire
+    records, sub-batches of 16 bytes to one piece, transfers queued ahead or not) all equal to the definition."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stress.py'), '--procs', '4', '--threads', '4',
+                        '--graphs', '2000', '--lifetimes', '2', '--calls', '3', '--timeout', '1500'],
+                       capture_output=True, text=True, timeout=1700)
+    line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else '{}'
+    res = json.loads(line)
+    assert r.returncode == 0 and res.get('mismatches') == 0 and res.get('abnormal_exits') == [] and not res.get('errors'), \
+        (r.returncode, line[:4000], r.stderr[-2000:])
+    assert res['graphs'] == 2000 and res['calls'] >= 2000 * 2 * 4
+
+
+@pytest.mark.parametrize('seed', [147003, 163032])
+def test_seeds_that_once_mismatched_under_load(seed):
+    """The two fuzz seeds whose hit sets differed once under eight processes sharing the GPU in round 3 (one record
+    missing: 147003, k-mer table without a path index; two extra under a gocc threshold: 163032) -- the whole fuzz
+    configuration of each seed, four processes at once, three times."""
+    for _ in range(3):
+        ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_modes.py'), str(seed), str(seed + 1)],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(4)]
+        for p in ps:
+            out, _ = p.communicate(timeout=600)
+            assert p.returncode == 0 and 'MISMATCH' not in out, out[-2000:]
