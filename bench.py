@@ -586,30 +586,72 @@ def main():
                 L.psigpu_free_hits(C.byref(hits))
             return (time.perf_counter() - t1) / reps, n_h
 
+        def host_entry_packed(src, flags, reps):
+            """psigpu_find_seeds_packed: reads as 2-bit words (+ a "not ACGT" bit per base when the chunk has any)"""
+            calls = [(finder.ctx, psi_amd._ptr(pr.words), psi_amd._ptr(pr.mask), psi_amd._ptr(pr.off), args.reads, k, step,
+                      rec_offset, flags, C.byref(hits)) for pr in src]
+            n_h = 0
+            for i in range(2):
+                if L.psigpu_find_seeds_packed(*calls[i % nb]):
+                    raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
+                L.psigpu_free_hits(C.byref(hits))
+            ts = []
+            for i in range(reps):
+                t1 = time.perf_counter()
+                if L.psigpu_find_seeds_packed(*calls[i % nb]):
+                    raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
+                n_h = hits.n
+                L.psigpu_free_hits(C.byref(hits))
+                ts.append(time.perf_counter() - t1)
+            return float(np.median(ts)), n_h, min(ts), max(ts)
+
         pinned_src = [(p[0].array, p[1].array) for p in pin]
         pageable_src = [(np.ascontiguousarray(b), np.ascontiguousarray(o.astype(np.uint64))) for b, o in batches]
+        # what psikt's reader does while it parses (psi::Records): ASCII -> 2-bit words, measured here on 1 and 8 threads
+        t1 = time.perf_counter()
+        packed_src = [psi_amd.PackedReads(b, o, pinned=True, threads=8) for b, o in batches]
+        t_pack8 = (time.perf_counter() - t1) / nb
+        t1 = time.perf_counter()
+        psi_amd.PackedReads(batches[0][0], batches[0][1], pinned=False, threads=1)
+        t_pack1 = time.perf_counter() - t1
+        t_pk, n_pk, t_pk_min, t_pk_max = host_entry_packed(packed_src, psi_amd.ALL | psi_amd.SORT_UNIQUE, 20)
+        c_e = finder.counters()
         t_su, n_su = host_entry(pinned_src, psi_amd.ALL | psi_amd.SORT_UNIQUE, 10)
+        c_a = finder.counters()
         t_raw, n_raw = host_entry(pinned_src, psi_amd.ALL, 10)
         t_pg, _ = host_entry(pageable_src, psi_amd.ALL | psi_amd.SORT_UNIQUE, 6)
-        c_e = finder.counters()
-        bytes_in = float(len(batches[0][0]) + 8 * (args.reads + 1))
-        bytes_out = float(c_e['wire_bytes_per_hit'] or 32) * n_su       # (16-byte wire records, widened on the host)
+        pr0 = packed_src[0]
+        bytes_in = float(pr0.words.nbytes + (pr0.mask.nbytes if pr0.mask is not None else 0) + 8 * (args.reads + 1))
+        bytes_out = float(c_e['wire_bytes_per_hit'] or 32) * n_pk       # (8-byte wire records, widened on the host)
         pcie_bound_ms = max(bytes_in, bytes_out) / (PCIE_PEAK_GBS * 1e9) * 1e3
+        bytes_in_ascii = float(len(batches[0][0]) + 8 * (args.reads + 1))
+        bytes_out_ascii = float(c_a['wire_bytes_per_hit'] or 32) * n_su
         out['end_to_end'] = {
-            'what': 'psigpu_find_seeds: H2D of the reads + kernels + sort-unique on the device + D2H of the hits '
-                    '(SURVEY 8(d) timed region), reads in pinned host memory, sub-batches pipelined over three streams',
-            'value': c_e['n_seeds'] / t_su, 'unit': 'seeds/s', 'ms_per_step': t_su * 1e3,
-            'hits_per_step_sort_unique': int(n_su), 'hits_per_s': n_su / t_su,
+            'what': 'psigpu_find_seeds_packed: H2D of the reads (2-bit words, in pinned host memory) + kernels + sort-unique on '
+                    'the device + D2H of the hits (8-byte wire records, widened to the 32-byte records by host threads inside '
+                    'the call): SURVEY 8(d) timed region; sub-batches pipelined over the two named copy engines and one compute '
+                    'stream; median of 20 calls',
+            'reads_format': '2-bit packed (psigpu_find_seeds_packed); the ASCII entry (psigpu_find_seeds) is ascii_*',
+            'value': c_e['n_seeds'] / t_pk, 'unit': 'seeds/s', 'ms_per_step': t_pk * 1e3,
+            'ms_per_step_min': t_pk_min * 1e3, 'ms_per_step_max': t_pk_max * 1e3,
+            'hits_per_step_sort_unique': int(n_pk), 'hits_per_s': n_pk / t_pk,
+            'same_record_count_as_ascii_entry': bool(n_pk == n_su),
+            'ascii_ms_per_step': t_su * 1e3, 'ascii_seeds_per_s': c_a['n_seeds'] / t_su,
+            'ascii_wire_bytes_per_hit': int(c_a['wire_bytes_per_hit']),
+            'ascii_pcie_frac': (max(bytes_in_ascii, bytes_out_ascii) / (PCIE_PEAK_GBS * 1e9)) / t_su,
             'raw_hits_ms_per_step': t_raw * 1e3, 'hits_per_step_raw': int(n_raw),
             'pageable_reads_ms_per_step': t_pg * 1e3,
+            'host_pack_ms_per_chunk': {'threads_8': t_pack8 * 1e3, 'threads_1': t_pack1 * 1e3,
+                                       'note': 'ASCII -> 2-bit words on the host (psigpu_pack_reads), outside the timed '
+                                               'region: psikt packs while it parses the FASTQ'},
             'device_ms_per_step': float(c_e['ms_total']), 'device_sort_ms_per_step': float(c_e['ms_sort']),
             'sub_batches_sorted_in_place': int(c_e['sorted_in_place']),      # (of the last call: no radix sort needed)
             'wire_bytes_per_hit': int(c_e['wire_bytes_per_hit']),
-            'roofline': {'bound': 'pcie', 'achieved': max(bytes_in, bytes_out) / t_su / 1e9, 'peak': PCIE_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': pcie_bound_ms / (t_su * 1e3), 'bytes_in': bytes_in, 'bytes_out': bytes_out,
+            'roofline': {'bound': 'pcie', 'achieved': max(bytes_in, bytes_out) / t_pk / 1e9, 'peak': PCIE_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': pcie_bound_ms / (t_pk * 1e3), 'bytes_in': bytes_in, 'bytes_out': bytes_out,
                          'note': 'full duplex: the bound is max(bytes in, bytes out) / one-direction rate'},
         }
-        out['host_entry_ms_per_step'] = t_su * 1e3
+        out['host_entry_ms_per_step'] = t_pk * 1e3
 
         # ---- second series: 1 % substitution errors (SURVEY 8d) ------------------------------------
         eb, eo = synth.sim_reads_snv(sg, args.reads, args.read_len, seed=13 + rank, sub_rate=0.01)
@@ -714,9 +756,13 @@ def main():
                 su = su[su[:, 2] < sample]
                 ordered = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
                 ok_host = bool(su.shape == ordered.shape and (su == ordered).all())
-                out['parity_vs_cpu_sample'] = ok_dev and ok_host
-                out['parity_detail'] = {'device_entry': ok_dev, 'host_entry_sorted': ok_host, 'reads_checked': int(sample),
-                                        'hits_checked': int(len(want))}
+                # ... and the packed host entry (the end_to_end series)
+                sp = finder.seeds_all_packed(packed_src[0], step=step, sort_unique=True)
+                sp = sp[sp[:, 2] < sample]
+                ok_packed = bool(sp.shape == ordered.shape and (sp == ordered).all())
+                out['parity_vs_cpu_sample'] = ok_dev and ok_host and ok_packed
+                out['parity_detail'] = {'device_entry': ok_dev, 'host_entry_sorted': ok_host, 'host_entry_packed_sorted': ok_packed,
+                                        'reads_checked': int(sample), 'hits_checked': int(len(want))}
         else:
             out['cpu_baseline'] = None
     if rank == 0:

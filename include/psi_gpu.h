@@ -366,7 +366,8 @@ void psigpu_free_hits(psigpu_hits* hits);
  * A 0, C 1, G 2, T 3, first base most significant.  n_mask (may be NULL: every base of the chunk is ACGT): bit i % 64 of
  * n_mask[i / 64] set = base i is not ACGT (its two code bits are ignored; a seed that covers it yields nothing, as an N
  * does in psigpu_find_seeds).  packed holds ceil(n / 32) words, n_mask ceil(n / 64), n = read_off[n_reads]; both may be
- * pinned (DMA'd in place) or pageable (staged).  Same records, same order, same flags as psigpu_find_seeds on the
+ * pinned (DMA'd in place) or pageable (staged).  read_off[0] need not be 0 here: the reads may be a contiguous RANGE of
+ * a larger packed chunk (psikt --devices hands every GPU one), whose bases start at base read_off[0] of the arrays.  Same records, same order, same flags as psigpu_find_seeds on the
  * corresponding ASCII bases.  psigpu_pack_reads makes the two arrays from ASCII bases on the calling thread. */
 int psigpu_find_seeds_packed(psigpu_ctx* ctx, const uint64_t* packed, const uint64_t* n_mask, const uint64_t* read_off,
                              uint64_t n_reads, uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags,

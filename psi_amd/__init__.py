@@ -645,10 +645,13 @@ class SeedFinder:
         return self._find(reads, step, rec_offset, ALL | (SORT_UNIQUE if sort_unique else 0))
 
     def seeds_all_packed(self, pr: 'PackedReads', step: int = 0, rec_offset: int = 0, sort_unique: bool = False,
-                         flags: int = ALL) -> np.ndarray:
-        """psigpu_find_seeds_packed: the chunk's reads as 2-bit words (a quarter of the ASCII bytes on the host link)."""
+                         flags: int = ALL, read_range: Optional[Tuple[int, int]] = None) -> np.ndarray:
+        """psigpu_find_seeds_packed: the chunk's reads as 2-bit words (a quarter of the ASCII bytes on the host link).
+        `read_range` (begin, end): only those reads of the chunk -- the word arrays as they are, the range's own offsets
+        (read ids count from rec_offset at `begin`)."""
         out = Hits()
-        self._chk(lib().psigpu_find_seeds_packed(self.ctx, _ptr(pr.words), _ptr(pr.mask), _ptr(pr.off), len(pr.off) - 1,
+        off = pr.off if read_range is None else pr.off[read_range[0]:read_range[1] + 1]
+        self._chk(lib().psigpu_find_seeds_packed(self.ctx, _ptr(pr.words), _ptr(pr.mask), _ptr(off), len(off) - 1,
                                                  self.seed_len, step, rec_offset, flags | (SORT_UNIQUE if sort_unique else 0),
                                                  C.byref(out)))
         if out.n:

@@ -5050,7 +5050,14 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
   const bool want_sort = (flags & PSIGPU_SORT_UNIQUE) != 0;
   flags &= ~PSIGPU_SORT_UNIQUE;
   const uint64_t n_bases = n_reads ? read_off[n_reads] : 0;
-  if (n_reads && read_off[0] != 0) { ctx->err = "read_off[0] must be 0"; return PSIGPU_ERR_ARG; }
+  // ASCII reads start at bases[0]; packed reads may be a RANGE of a larger chunk (psikt --devices: every GPU takes a
+  // contiguous range of the chunk's reads and the word arrays cannot be offset by a base count): read_off[0] = the
+  // range's first base in the arrays
+  if (n_reads && read_off[0] != 0 && !in.packed()) { ctx->err = "read_off[0] must be 0"; return PSIGPU_ERR_ARG; }
+  const uint64_t base0 = n_reads ? read_off[0] : 0;
+  if (base0 > n_bases) { ctx->err = "read offsets must not decrease"; return PSIGPU_ERR_ARG; }
+  const uint64_t org2 = in.packed() ? (base0 & ~31ull) : 0, orgm = base0 & ~63ull;      // first bases of the device buffers
+  const size_t M0 = in.main_byte0(org2), K0 = in.mask_byte0(orgm);
   if (n_bases && !bases) return PSIGPU_ERR_ARG;
   if (n_reads == 0) {                 // nothing to copy either way; the counters of the call are still set
     uint64_t n = 0;
@@ -5083,7 +5090,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     // on one box: 4.58 ms grow-only, 4.78-4.86 with tapered ends.)
     const uint64_t small = std::max<uint64_t>(1, SUB_BYTES / 8);
     std::vector<uint64_t> pieces;
-    uint64_t left = n_bases;
+    uint64_t left = n_bases - base0;
     for (uint64_t p = small; p < SUB_BYTES && left > p; p *= 2) { pieces.push_back(p); left -= p; }
     const size_t n_head = pieces.size();
     while (left > 0) { const uint64_t p = std::min(left, SUB_BYTES); pieces.push_back(p); left -= p; }
@@ -5093,7 +5100,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     // (With the reads' transfers queued ahead -- below -- small pieces at the end were tried again: SUB/2, SUB/4, SUB/4
     // instead of the last full piece.  150 calls of each variant alternated in one process, tools/e2e_ab3.py: median
     // 4.53 ms against 4.37 without, minimum 3.56 against 3.64: not kept.)
-    uint64_t target = 0;
+    uint64_t target = base0;
     for (size_t pi = 0; pi < pieces.size() && cut.back() < n_reads; ++pi) {
       target += pieces[pi];
       uint64_t r = (target >= n_bases || pi + 1 == pieces.size()) ? n_reads
@@ -5114,8 +5121,8 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     // (packed reads: neighbouring sub-batches share their boundary word -- both transfers write the same bytes there)
     const size_t m0 = in.main_byte0(b0), mb = in.main_bytes(b0, b1), k0 = in.mask_byte0(b0), kb = in.mask_bytes(b0, b1);
     const int n_copies = kb ? 2 : 1;
-    if (!engine_copy(ctx, true, (char*)ctx->in_bases.p + m0, bases + pin_delta + m0, mb, sg, n_copies)) return false;
-    if (kb && !engine_copy_more(ctx, true, (char*)ctx->in_mask.p + k0, (const char*)in.mask + mask_delta + k0, kb, sg)) {
+    if (!engine_copy(ctx, true, (char*)ctx->in_bases.p + (m0 - M0), bases + pin_delta + m0, mb, sg, n_copies)) return false;
+    if (kb && !engine_copy_more(ctx, true, (char*)ctx->in_mask.p + (k0 - K0), (const char*)in.mask + mask_delta + k0, kb, sg)) {
       engine_wait_value(sg, 2);                  // the first transfer is on its way: wait for it, then fail
       hsa_signal_store_relaxed(sg, 0);
       return false;
@@ -5123,8 +5130,8 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     return true;
   };
   if (ahead) {
-    HIPCHK(ctx, ctx->in_bases.ensure(in.main_bytes(0, n_bases) + 64));
-    if (in.mask) HIPCHK(ctx, ctx->in_mask.ensure(in.mask_bytes(0, n_bases) + 64));
+    HIPCHK(ctx, ctx->in_bases.ensure(in.main_bytes(org2, n_bases) + 64));
+    if (in.mask) HIPCHK(ctx, ctx->in_mask.ensure(in.mask_bytes(orgm, n_bases) + 64));
     for (; issued < std::min(n_sub, IN_RING); ++issued)
       if (!issue_in(issued)) {
         for (size_t j = 0; j < issued; ++j) engine_wait(ctx->ec.sig_in[j]);
@@ -5331,8 +5338,8 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     PackedIn pk{ nullptr, 0, 0 };
     if (in.packed()) {
       pk.mask = in.mask ? (ahead ? ctx->in_mask.as<uint64_t>() : sl.mask.as<uint64_t>()) : nullptr;
-      pk.bias2 = ahead ? b0_ : (b0_ & 31);
-      pk.biasm = ahead ? b0_ : (b0_ & 63);
+      pk.bias2 = ahead ? b0_ - org2 : (b0_ & 31);
+      pk.biasm = ahead ? b0_ - orgm : (b0_ & 63);
     }
     const char* d_in = in.packed() ? (ahead ? ctx->in_bases.as<char>() : sl.bases.as<char>())
                                    : (ahead ? (const char*)ctx->in_bases.p + b0_ : sl.bases.as<char>());

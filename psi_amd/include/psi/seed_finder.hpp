@@ -231,9 +231,16 @@ namespace psi {
       if ( seeds.chunk == nullptr ) throw std::runtime_error( "get_seeds() has not been called" );
       Records const& c = *seeds.chunk;
       if ( begin > end || end > c.size() ) throw std::runtime_error( "read range out of bounds" );
+      psigpu_hits hits{};
+      if ( c.is_packed ) {
+        /* a range of the packed chunk: the word arrays as they are, the range's own offsets (read_off[0] != 0) */
+        check( psigpu_find_seeds_packed( ctx, c.packed.data(), c.n_not_acgt ? c.not_acgt.data() : nullptr, c.offsets.data() + begin,
+                                         end - begin, seeds.seed_len, seeds.distance, c.get_record_offset() + begin,
+                                         PSIGPU_ALL | PSIGPU_SORT_UNIQUE, &hits ) );
+        return hits;
+      }
       std::vector< std::uint64_t > off( end - begin + 1 );
       for ( std::uint64_t i = begin; i <= end; ++i ) off[ i - begin ] = c.offsets[ i ] - c.offsets[ begin ];
-      psigpu_hits hits{};
       check( psigpu_find_seeds( ctx, c.bases.data() + c.offsets[ begin ], off.data(), end - begin, seeds.seed_len,
                                 seeds.distance, c.get_record_offset() + begin, PSIGPU_ALL | PSIGPU_SORT_UNIQUE, &hits ) );
       return hits;
@@ -307,6 +314,10 @@ namespace psi {
       if ( seeds.chunk == nullptr ) throw std::runtime_error( "get_seeds() has not been called" );
       Records const& c = *seeds.chunk;
       psigpu_hits hits{};
+      if ( c.is_packed )      /* readRecords packed the chunk: a quarter of the bytes on the host link */
+        check( psigpu_find_seeds_packed( ctx, c.packed.data(), c.n_not_acgt ? c.not_acgt.data() : nullptr, c.offsets.data(), c.size(),
+                                         seeds.seed_len, seeds.distance, c.get_record_offset(), flags | PSIGPU_SORT_UNIQUE, &hits ) );
+      else
       check( psigpu_find_seeds( ctx, c.bases.data(), c.offsets.data(), c.size(), seeds.seed_len,
                                 seeds.distance, c.get_record_offset(), flags | PSIGPU_SORT_UNIQUE, &hits ) );
       return hits;

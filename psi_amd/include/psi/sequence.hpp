@@ -16,6 +16,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "psi_gpu.h"
@@ -66,29 +67,96 @@ namespace psi {
     bool pinned_ = false;
   };
 
+  /** Grow-only array of 64-bit words in pinned host memory: the 2-bit form of a chunk's reads. */
+  class PinnedWords {
+  public:
+    PinnedWords() = default;
+    PinnedWords( PinnedWords const& ) = delete;
+    PinnedWords& operator=( PinnedWords const& ) = delete;
+    ~PinnedWords() { release(); }
+    std::uint64_t const* data() const { return p_; }
+    std::uint64_t* data() { return p_; }
+    std::size_t size() const { return n_; }
+    /** n words, all zero */
+    void assign_zero( std::size_t n )
+    {
+      if ( n > cap_ ) {
+        release();
+        std::size_t cap = n + n / 8 + 64;
+        p_ = static_cast< std::uint64_t* >( psigpu_host_alloc( cap * 8 ) );
+        pinned_ = p_ != nullptr;
+        if ( p_ == nullptr ) p_ = static_cast< std::uint64_t* >( std::malloc( cap * 8 ) );
+        if ( p_ == nullptr ) throw std::bad_alloc();
+        cap_ = cap;
+      }
+      n_ = n;
+      if ( n ) std::memset( p_, 0, n * 8 );
+    }
+  private:
+    void release()
+    {
+      if ( p_ == nullptr ) return;
+      if ( pinned_ ) psigpu_host_free( p_ ); else std::free( p_ );
+      p_ = nullptr; cap_ = 0; n_ = 0;
+    }
+    std::uint64_t* p_ = nullptr;
+    std::size_t n_ = 0, cap_ = 0;
+    bool pinned_ = false;
+  };
+
   /** A set of reads stored back to back (what the device consumes) plus their names. */
   class Records {
   public:
     std::vector< std::string > name;
     PinnedChars bases;                         /**< concatenated sequences */
     std::vector< std::uint64_t > offsets{ 0 }; /**< size()+1 offsets into bases */
+    /** The same bases at 2 bits each + one "not ACGT" bit per base (layout: psigpu_find_seeds_packed): what crosses
+     *  the host link.  Made by pack() once the chunk is complete (readRecords does); the reference keeps a byte per
+     *  base (seqan2::Dna5QString, sequence.hpp:1130-1294). */
+    PinnedWords packed, not_acgt;
+    std::uint64_t n_not_acgt = 0;
+    bool is_packed = false;
+
+    void pack( unsigned threads = 0 )
+    {
+      std::uint64_t const n = bases.size();
+      packed.assign_zero( ( n + 31 ) / 32 + 2 );
+      not_acgt.assign_zero( ( n + 63 ) / 64 + 2 );
+      n_not_acgt = 0;
+      if ( threads == 0 ) threads = std::max( 1u, std::min( 8u, std::thread::hardware_concurrency() / 2 ) );
+      std::uint64_t piece = ( ( n + threads - 1 ) / threads + 63 ) / 64 * 64;     /* whole 64-base blocks per thread */
+      if ( piece < ( 1u << 20 ) ) piece = 1u << 20;
+      std::vector< std::thread > th;
+      std::vector< std::uint64_t > bad( ( n + piece - 1 ) / piece + 1, 0 );
+      std::size_t j = 0;
+      for ( std::uint64_t a = 0; a < n; a += piece, ++j ) {
+        std::uint64_t const len = std::min( piece, n - a );
+        auto job = [ this, a, len, j, &bad ] { bad[ j ] = psigpu_pack_reads( bases.data() + a, a, len, packed.data(), not_acgt.data() ); };
+        if ( a + piece < n ) th.emplace_back( job ); else job();
+      }
+      for ( auto& t : th ) t.join();
+      for ( auto b : bad ) n_not_acgt += b;
+      is_packed = true;
+    }
 
     std::size_t size() const { return offsets.size() - 1; }
     std::uint64_t length_sum() const { return bases.size(); }
     std::uint64_t get_record_offset() const { return rec_offset; }
     void set_record_offset( std::uint64_t v ) { rec_offset = v; }
-    void clear() { name.clear(); bases.clear(); offsets.assign( 1, 0 ); rec_offset = 0; }
+    void clear() { name.clear(); bases.clear(); offsets.assign( 1, 0 ); rec_offset = 0; is_packed = false; n_not_acgt = 0; }
     void push_back( std::string const& n, std::string const& s )
     {
       name.push_back( n );
       bases += s;
       offsets.push_back( bases.size() );
+      is_packed = false;
     }
     void push_back( char const* n, std::size_t nlen, char const* s, std::size_t slen )
     {
       name.emplace_back( n, nlen );
       bases.append( s, slen );
       offsets.push_back( bases.size() );
+      is_packed = false;
     }
     std::string operator[]( std::size_t i ) const
     { return bases.substr( offsets[ i ], offsets[ i + 1 ] - offsets[ i ] ); }
@@ -208,6 +276,7 @@ namespace psi {
     records.clear();
     records.set_record_offset( iss.counts() );
     while ( ( num == 0 || records.size() < num ) && iss.next_into( records ) ) { }
+    if ( records.size() != 0 ) records.pack();    /* 2 bits per base for the host link (a few threads, ~10 ms per 150 Mbp) */
     return records.size() != 0;
   }
 }  /* --- end of namespace psi --- */

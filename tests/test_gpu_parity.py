@@ -1152,6 +1152,14 @@ def test_packed_reads_equal_ascii(k, step, pinned):
             assert len(raw) == len(want_raw) and _eq(psi_amd.sort_unique(raw), psi_amd.sort_unique(want_raw)), (sub, no_ahead)
             assert f.counters()['n_reads'] == len(ragged)
             assert _eq(f.seeds_all_packed(pr, step=step, rec_offset=1000, sort_unique=True), want), (sub, no_ahead)
+    # a contiguous range of the chunk's reads (psikt --devices): the same word arrays, read_off[0] != 0
+    nr = len(ragged)
+    for (b, e), sub in (((nr // 3, 2 * nr // 3), 1 << 30), ((7, nr - 5), 97), ((nr - 1, nr), 64), ((5, 5), 64)):
+        f.set_option('sub_bytes', sub)
+        for no_ahead in ((0, 1) if pinned else (0,)):
+            f.set_option('no_ahead', no_ahead)
+            part = f.seeds_all_packed(pr, step=step, rec_offset=1000 + b, sort_unique=True, read_range=(b, e))
+            assert _eq(part, want[(want[:, 2] >= 1000 + b) & (want[:, 2] < 1000 + e)]), (b, e, sub, no_ahead)
     # no mask at all when every base is ACGT
     clean = [r.upper().replace('N', 'A') for r in ragged]
     pc = psi_amd.PackedReads(*psi_amd.pack_reads(clean), pinned=bool(pinned))
