@@ -169,6 +169,103 @@ def cpu_baseline(og, pidx, px, bases, off, k, step, n_reads_sample, budget_1t_s=
     return out, hits
 
 
+# ------------------------------------------------------------------------------------------------------
+# N > 1: BASELINE.json configs[3] -- the whole-genome graph, reads sharded over the GPUs of the node.
+# One process per GPU as the driver launches them, ONE host index: rank 0 synthesises the graph and builds
+# the index, writes the arrays behind the two C-ABI views into a memory-backed directory (psi_amd/shared.py),
+# every rank (rank 0 too) maps them and uploads from the mapping.  The directory is keyed by the workload and
+# kept, so the driver's N = 2, 4, 8 runs back to back build it once.
+# ------------------------------------------------------------------------------------------------------
+WG_FULL = {'backbone': 3_100_000_000, 'snvs': 80_000_000, 'nblock': 150_000_000, 'reads_per_gpu': 12_500_000}
+
+
+def wg_decide(args, world):
+    """rank 0: the N > 1 workload.  Whole genome when the host has room for it (the builder's peak is ~100 GB of RSS for
+    one indexed walk, the shared arrays ~60 GB, every rank's reads ~4 GB), else None = chr22 weak scaling as at N = 1."""
+    mode = os.environ.get('PSI_BENCH_WG', args.wg)
+    if mode == 'off':
+        return None, 'whole-genome workload switched off (PSI_BENCH_WG=off)'
+    plan = dict(WG_FULL)
+    for key, v in (('backbone', args.wg_backbone), ('snvs', args.wg_snvs), ('nblock', args.wg_nblock), ('reads_per_gpu', args.wg_reads)):
+        if v:
+            plan[key] = v
+    scale = plan['backbone'] / WG_FULL['backbone']
+    need_ram = (170e9 * scale + 6e9 * world * plan['reads_per_gpu'] / WG_FULL['reads_per_gpu'])
+    need_dir = 65e9 * scale + (1 << 26)
+    avail = 0
+    try:
+        for ln in open('/proc/meminfo'):
+            if ln.startswith('MemAvailable:'):
+                avail = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    tag = 'psi_bench_wg_%d_%d_%d_k%d_p%d' % (plan['backbone'], plan['snvs'], plan['nblock'], args.k, args.paths)
+    where = None
+    for base in [os.environ.get('PSI_BENCH_SHARE_DIR'), '/dev/shm', os.environ.get('TMPDIR'), '/tmp']:
+        if not base or not os.path.isdir(base):
+            continue
+        d = os.path.join(base, tag)
+        if os.path.exists(os.path.join(d, 'manifest.json')):
+            where = d                    # built by an earlier run
+            break
+        try:
+            st = os.statvfs(base)
+            if st.f_bavail * st.f_frsize >= need_dir and os.access(base, os.W_OK):
+                where = d
+                break
+        except OSError:
+            continue
+    cached = bool(where and os.path.exists(os.path.join(where, 'manifest.json')))
+    if mode != 'force':
+        if where is None:
+            return None, 'no directory with %.0f GB free for the shared index' % (need_dir / 1e9)
+        if avail and avail < (need_ram - (need_dir if cached else 0)):
+            return None, 'host has %.0f GB available, the whole-genome set-up wants %.0f' % (avail / 1e9, need_ram / 1e9)
+    elif where is None:
+        where = os.path.join('/tmp', tag)
+    plan.update(dir=where, cached=cached, host_mem_available_gb=avail / 1e9)
+    return plan, 'ok'
+
+
+def wg_build_and_export(plan, args, local_rank):
+    """rank 0: graph, index (on its GPU), the read simulator's arrays -> plan['dir']; returns the set-up times."""
+    import numpy as np
+    import psi_amd
+    from psi_amd import shared, synth
+    t = {}
+    t0 = time.time()
+    sg = synth.snv_graph(plan['backbone'], plan['snvs'], n_block=plan['nblock'], seed=11)
+    t['graph_s'] = time.time() - t0
+    t0 = time.time()
+    g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path])
+    os.makedirs(plan['dir'], exist_ok=True)
+    np.save(os.path.join(plan['dir'], 'sim_backbone.npy'), sg.backbone)
+    np.save(os.path.join(plan['dir'], 'sim_alt.npy'), sg.alt)
+    n_block = int(sg.n_block)
+    del sg
+    px = psi_amd.PathIndex.build(g, args.k, args.paths, sa_rate=args.sa_rate, rng_seed=1,
+                                 ftab_len=psi_amd.NO_FTAB if args.ftab < 0 else args.ftab,
+                                 device=None if args.host_build else local_rank)
+    t['index_build_s'] = time.time() - t0
+    t0 = time.time()
+    shared.export_views(plan['dir'], g, px, extra={'n_block': n_block, 'index_build_s': t['index_build_s'], 'graph_s': t['graph_s']})
+    t['export_s'] = time.time() - t0
+    del px, g
+    import gc
+    gc.collect()
+    return t
+
+
+class SimArrays:
+    """what synth.sim_reads_snv needs of a SnvGraph, over the mapped arrays"""
+
+    def __init__(self, d, n_block):
+        import numpy as np
+        self.backbone = np.load(os.path.join(d, 'sim_backbone.npy'), mmap_mode='r')
+        self.alt = np.load(os.path.join(d, 'sim_alt.npy'), mmap_mode='r')
+        self.n_block = n_block
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside torchrun: start N ranks as CHILD processes (before anything
     here has touched the GPU) and relay rank 0's JSON line."""
@@ -204,6 +301,12 @@ def main():
     ap.add_argument('--cpu-reads', type=int, default=-1, help='reads in the CPU-baseline sample (0 = skip baseline and check)')
     ap.add_argument('--no-check', action='store_true', help='skip the comparison of the GPU hit set with the CPU sample')
     ap.add_argument('--lean', action='store_true', help='headline only: no other modes, no end-to-end, no CPU baseline (profiling runs)')
+    ap.add_argument('--wg', choices=('auto', 'force', 'off'), default='auto',
+                    help='N > 1: the whole-genome workload of BASELINE.json configs[3] (auto: when the host has the memory)')
+    ap.add_argument('--wg-backbone', type=int, default=0, help='(tests) backbone of the N > 1 graph instead of 3.1 Gbp')
+    ap.add_argument('--wg-snvs', type=int, default=0)
+    ap.add_argument('--wg-nblock', type=int, default=0)
+    ap.add_argument('--wg-reads', type=int, default=0, help='reads per GPU of the N > 1 workload (default 12.5 M: 100 M over 8)')
     ap.add_argument('--mode', choices=('kmer-table', 'locus-table', 'traverse'), default='kmer-table',
                     help="kmer-table: path k-mers and the starting loci's k-walks tabulated once in HBM, one probe "
                          "per seed; locus-table: FM index on the paths, table for the loci; traverse: FM index + "
@@ -244,20 +347,55 @@ def main():
     step = args.step or k
     lean = args.lean
     t0 = time.time()
-    sg = synth.snv_graph(args.backbone, args.snvs, n_block=args.nblock, seed=11)
-    g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to,
-                               paths=[sg.ref_path])
-    nb = max(1, args.batches)
-    batches = [synth.sim_reads_snv(sg, args.reads, args.read_len, seed=13 + 100 * b + rank) for b in range(nb)]
-    t_ix = time.time()
-    px = psi_amd.PathIndex.build(g, k, args.paths, sa_rate=args.sa_rate, rng_seed=1,
-                                 ftab_len=psi_amd.NO_FTAB if args.ftab < 0 else args.ftab,
-                                 device=None if args.host_build else local_rank)
-    t_ix = time.time() - t_ix
+    # N > 1: the whole-genome workload (configs[3]) when the host has room for it -- rank 0 decides, everybody follows
+    wg, wg_note, wg_times = None, '', {}
+    if world > 1:
+        box = [None, '']
+        if rank == 0:
+            box = list(wg_decide(args, world))
+        dist.broadcast_object_list(box, src=0, device=torch.device('cuda', local_rank) if backend == 'nccl' else None)
+        wg, wg_note = box
+        if rank == 0:
+            log('N = %d workload: %s' % (world, ('whole genome, shared index in %s%s' % (wg['dir'], ' (cached)' if wg['cached'] else ''))
+                                         if wg else 'chr22 weak scaling (%s)' % wg_note))
+    if wg:
+        from psi_amd import shared
+        if rank == 0 and not wg['cached']:
+            wg_times = wg_build_and_export(wg, args, local_rank)
+            log('whole-genome set-up on rank 0: graph %.0f s, index %.0f s, export %.0f s' %
+                (wg_times['graph_s'], wg_times['index_build_s'], wg_times['export_s']))
+        # (the others wait for the manifest, not inside a collective: the build takes minutes)
+        t_wait = time.time()
+        while not os.path.exists(os.path.join(wg['dir'], 'manifest.json')):
+            if time.time() - t_wait > 3000:
+                log('rank %d: gave up waiting for the shared index' % rank)
+                sys.exit(4)
+            time.sleep(0.5)
+        dist.barrier()
+        g, px, extra = shared.import_views(wg['dir'])
+        sg = SimArrays(wg['dir'], int(extra.get('n_block', 0)))
+        args.reads = wg['reads_per_gpu']
+        args.batches = 1                         # (87 M seeds per step: nothing of a batch stays in any cache)
+        nb = 1
+        batches = [synth.sim_reads_snv(sg, args.reads, args.read_len, seed=13 + rank)]
+        t_ix = float(extra.get('index_build_s', 0.0))
+    else:
+        sg = synth.snv_graph(args.backbone, args.snvs, n_block=args.nblock, seed=11)
+        g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to,
+                                   paths=[sg.ref_path])
+        nb = max(1, args.batches)
+        batches = [synth.sim_reads_snv(sg, args.reads, args.read_len, seed=13 + 100 * b + rank) for b in range(nb)]
+        t_ix = time.time()
+        px = psi_amd.PathIndex.build(g, k, args.paths, sa_rate=args.sa_rate, rng_seed=1,
+                                     ftab_len=psi_amd.NO_FTAB if args.ftab < 0 else args.ftab,
+                                     device=None if args.host_build else local_rank)
+        t_ix = time.time() - t_ix
+    t_up = time.time()
     finder = psi_amd.SeedFinder(g, k, device=local_rank, mode=args.mode)
     if args.tune:
         finder.set_tuning(args.tune)
     finder.set_path_index(px)
+    t_up = time.time() - t_up
     t_prep = time.time()
     finder.prepare()                      # the tables of the query mode: index load time, not query time
     t_prep = time.time() - t_prep
@@ -316,7 +454,7 @@ def main():
                 dist.all_reduce(nbt, op=dist.ReduceOp.MAX)
                 n_blocks = int(nbt.item())
         seeds = hits = 0
-        block_s = []
+        block_s, own_s = [], []
         for _ in range(n_blocks):
             torch.cuda.synchronize()
             if sync_ranks and world > 1:
@@ -331,6 +469,7 @@ def main():
                 kern['k_table_insert'] += cs.ms_table; kern[probe_name] += cs.ms_probe; kern['k_seed_pack'] += cs.ms_pack
                 seeds += cs.n_seeds; hits += cs.n_hits
             torch.cuda.synchronize()
+            own_s.append(time.perf_counter() - t_begin)       # this rank's own steps, before it waits for the others
             if sync_ranks and world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -347,7 +486,7 @@ def main():
         c['n_kwalks_all'] = kwalks_all
         c['n_hits_table'] = c['n_hits_off_path'] if c['n_locus_kmers'] and not c['n_loci_traversed'] else 0
         return {'elapsed': elapsed, 'kern': kern, 'seeds': seeds, 'hits': hits, 'c': c, 'steps': steps,
-                'block_ms_per_step': [b / steps * 1e3 for b in block_s]}
+                'block_ms_per_step': [b / steps * 1e3 for b in block_s], 'own_ms_per_step': float(np.median(own_s)) / steps * 1e3}
 
     rand_peak = {}
 
@@ -441,7 +580,11 @@ def main():
     # every rank's sort-unique hits of one batch to rank 0, once, outside the timed region
     gather = None
     if world > 1:
-        ptr, n = finder.seeds_all_device(dev[0][0].data_ptr(), dev[0][1].data_ptr(), args.reads, dev[0][2], step=step,
+        # (whole genome: the hit list of a rank's 12.5 M reads is 2.8 GB and eight of them, twice -- torch's gather and the
+        # library's -- do not fit beside a 150-GB k-mer table on the root: the hit lists of the first 2 M reads of every rank)
+        n_g = min(args.reads, 2_000_000) if wg else args.reads
+        nb_g = int(batches[0][1][n_g])
+        ptr, n = finder.seeds_all_device(dev[0][0].data_ptr(), dev[0][1].data_ptr(), n_g, nb_g, step=step,
                                          rec_offset=rec_offset, flags=psi_amd.ALL | psi_amd.SORT_UNIQUE, stream=stream)
         mine = None
         if backend == 'nccl' and n:
@@ -463,7 +606,7 @@ def main():
         t_g = time.perf_counter() - t1
         if rank == 0:
             ids = allh[:, 2]
-            gather = {'ms': t_g * 1e3, 'records': int(allh.shape[0]), 'bytes': int(allh.shape[0]) * 32,
+            gather = {'reads_per_rank': int(n_g), 'ms': t_g * 1e3, 'records': int(allh.shape[0]), 'bytes': int(allh.shape[0]) * 32,
                       'gb_per_s': allh.shape[0] * 32 / t_g / 1e9, 'backend': backend,
                       'sorted_by_read_id': bool((ids[1:] >= ids[:-1]).all().item()) if allh.shape[0] > 1 else True}
 
@@ -512,6 +655,67 @@ def main():
                 res_cxx['same_records_as_torch_gather'] = res_cxx['records'] == gather['records']
             gather['cxx'] = res_cxx
 
+    multi = None
+    if world > 1:
+        # ---- per-GPU rates (each rank's own steps, before it waits at the barrier) --------------------------------
+        c_m = main_res['c']
+        probe_ms = main_res['kern'].get('k_kmer_probe', 0.0) / max(1, main_res['steps'])
+        mine_t = torch.tensor([main_res['own_ms_per_step'], float(c_m['n_seeds']), probe_ms,
+                               algorithmic_bytes('k_kmer_probe', c_m, k, args.sa_rate) if probe_ms else 0.0, t_up, t_prep],
+                              dtype=torch.float64, device=red_dev)
+        allt = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t)
+        per_gpu = [{'rank': r, 'ms_per_step': float(x[0]), 'seeds_per_s': float(x[1]) / (float(x[0]) * 1e-3) if float(x[0]) else 0.0,
+                    'k_kmer_probe_ms': float(x[2]),
+                    'roofline_frac': (float(x[3]) / (float(x[2]) * 1e-3) / 1e9 / HBM_PEAK_GBS) if float(x[2]) else None,
+                    'index_upload_s': float(x[4]), 'tables_s': float(x[5])} for r, x in enumerate(allt)]
+        # ---- SURVEY 8(d) through every GPU's own host link at once: psigpu_find_seeds_packed on every rank ----------
+        e2e = None
+        if not lean:
+            pr = psi_amd.PackedReads(batches[0][0], batches[0][1], pinned=True, threads=4)
+            hh = psi_amd.Hits()
+            call = (finder.ctx, psi_amd._ptr(pr.words), psi_amd._ptr(pr.mask), psi_amd._ptr(pr.off), args.reads, k, step, rec_offset,
+                    psi_amd.ALL | psi_amd.SORT_UNIQUE, C.byref(hh))
+            if L.psigpu_find_seeds_packed(*call):                 # warm: pinned pool, slot buffers
+                raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
+            n_rec = hh.n
+            L.psigpu_free_hits(C.byref(hh))
+            reps = 3
+            dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                if L.psigpu_find_seeds_packed(*call):
+                    raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
+                L.psigpu_free_hits(C.byref(hh))
+            t_own = (time.perf_counter() - t1) / reps
+            dist.barrier()
+            t_all = (time.perf_counter() - t1) / reps
+            tt = torch.tensor([t_own, t_all, float(n_rec)], dtype=torch.float64, device=red_dev)
+            alle = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(alle, tt)
+            t_wall = max(float(x[1]) for x in alle)
+            e2e = {'what': 'psigpu_find_seeds_packed on every rank at once (its own reads, its own host link): H2D + kernels + '
+                           'device sort-unique + D2H, barrier to barrier, %d calls' % reps,
+                   'ms_per_chunk': t_wall * 1e3, 'value': float(c_m['n_seeds']) * world / t_wall, 'unit': 'seeds/s',
+                   'per_gpu_ms': [float(x[0]) * 1e3 for x in alle], 'records_per_gpu': [int(x[2]) for x in alle],
+                   'wire_bytes_per_hit': int(finder.counters()['wire_bytes_per_hit'])}
+            del pr
+        # ---- properties (no oracle at this size): every seed of the first reads found where it was sampled ---------
+        n_chk = min(args.reads, 1_000_000)
+        nb_chk = int(batches[0][1][n_chk])
+        ptr_c, n_c = finder.seeds_all_device(dev[0][0].data_ptr(), dev[0][1].data_ptr(), n_chk, nb_chk, step=step,
+                                             rec_offset=rec_offset, stream=stream)
+        hc = finder.copy_hits(ptr_c, n_c)
+        per_read = (args.read_len - k) // step + 1
+        found = np.unique((hc[:, 2] - np.uint64(rec_offset)) * np.uint64(100000) + hc[:, 3])
+        seeds_found = bool(len(found) == n_chk * per_read)
+        ok_props = torch.tensor([1 if seeds_found else 0], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(ok_props, op=dist.ReduceOp.MIN)
+        multi = {'per_gpu': per_gpu, 'end_to_end_all_links': e2e,
+                 'properties': {'every_seed_of_the_first_reads_found_on_every_rank': bool(int(ok_props.item())),
+                                'reads_checked_per_rank': int(n_chk)},
+                 'n_ranks': world, 'rccl_ranks': int(dist.get_world_size()) if backend == 'nccl' else 0, 'backend': backend}
+
     if rank == 0:
         c = main_res['c']
         steps = args.steps
@@ -538,11 +742,18 @@ def main():
                                 '(H2D + kernels + device sort-unique + D2H) is end_to_end.value',
             'hits_per_s': hits_total / elapsed,
             'config': {
-                'workload': 'chr22-like synthetic stand-in (BASELINE.json configs[1]): %d bp backbone '
+                'workload': ('whole-genome-like synthetic stand-in (BASELINE.json configs[3]): %d bp backbone incl. %d bp leading N, '
+                             '%d bi-allelic SNV bubbles, nodes <= 32 bp; %d x %d bp error-free haplotype-walk reads per GPU = %d '
+                             'reads over the %d GPUs (contiguous ranges, global read ids), k=%d, seed distance %d, %d indexed '
+                             'path(s), SA sampling %d; ONE host index built by rank 0 and mapped by every rank (psi_amd/shared.py)'
+                             % (wg['backbone'], wg['nblock'], wg['snvs'], args.reads, args.read_len, args.reads * world, world, k,
+                                step, args.paths, args.sa_rate)) if wg else
+                            (('[N > 1 fell back to configs[1] weak scaling: %s] ' % wg_note if world > 1 else '') +
+                            'chr22-like synthetic stand-in (BASELINE.json configs[1]): %d bp backbone '
                             'incl. %d bp leading N, %d bi-allelic SNV bubbles, nodes <= 32 bp; %d batches of %d x %d bp '
                             'error-free haplotype-walk reads per GPU alternating, k=%d, seed distance %d, %d indexed '
                             'path(s), SA sampling %d' % (args.backbone, args.nblock, args.snvs, nb, args.reads,
-                                                         args.read_len, k, step, args.paths, args.sa_rate),
+                                                         args.read_len, k, step, args.paths, args.sa_rate)),
                 'reads_per_gpu': args.reads, 'read_len': args.read_len, 'k': k, 'seed_step': step, 'read_batches': nb,
                 'indexed_paths': args.paths, 'nodes': int(g.n_nodes), 'edges': int(g.n_edges),
                 'text_len': int(px.text_len), 'starting_loci': int(px.view.n_loci),
@@ -564,6 +775,14 @@ def main():
             out['config']['series'] = args.series
         if gather:
             out['gather_hits'] = gather
+        if multi:
+            out['multi_gpu'] = multi
+            out['config']['whole_genome'] = bool(wg)
+            if wg:
+                out['config']['shared_index_dir'] = wg['dir']
+                out['config']['shared_index_cached'] = bool(wg['cached'])
+                out['config']['setup_s'] = dict(wg_times, upload_s=t_up, tables_s=t_prep)
+                out['config']['host_mem_available_gb'] = wg.get('host_mem_available_gb')
     if world == 1 and not lean:
         # ---- the host entry point, PCIe included ------------------------------------
         hits = psi_amd.Hits()

@@ -63,7 +63,7 @@ def test_bench_two_ranks_one_gpu():
     """bench.py's N > 1 path end to end (PSI_BENCH_BACKEND=gloo: ranks share the GPU): one JSON line, weak
     scaling, hit lists gathered on rank 0 in read-id order."""
     import json
-    p = _run_two_ranks([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+    p = _run_two_ranks([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--wg', 'off',
                         '--reads', '20000', '--backbone', '3000000', '--snvs', '60000', '--nblock', '200000'],
                        {'PSI_BENCH_BACKEND': 'gloo'})
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -72,8 +72,39 @@ def test_bench_two_ranks_one_gpu():
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 3
     assert j['config']['seeds_per_step_per_gpu'] == 140000 and j['value'] > 0
+    assert 'fell back to configs[1]' in j['config']['workload'] and j['config']['whole_genome'] is False
     g = j['gather_hits']
     assert g['records'] >= 2 * 140000 and g['sorted_by_read_id'] and g['backend'] == 'gloo'
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_whole_genome_path_at_reduced_size(tmp_path):
+    """bench.py --gpus N, N > 1, as the driver runs it: BASELINE.json configs[3] -- rank 0 builds ONE host index and
+    writes the arrays behind the views to a shared directory, every rank maps them (psi_amd/shared.py), simulates its
+    own contiguous range of reads, and the line carries per-GPU rates, the end-to-end rate through every rank's host
+    entry at once, both gathers and the found-where-sampled property.  Here at 3 Mbp with two ranks on the box's one
+    GPU (PSI_BENCH_BACKEND=gloo), the same code path; a second run finds the directory and builds nothing."""
+    import json
+    env = {'PSI_BENCH_BACKEND': 'gloo', 'PSI_BENCH_SHARE_DIR': str(tmp_path)}
+    cmd = [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--wg', 'force',
+           '--wg-backbone', '3000000', '--wg-snvs', '60000', '--wg-nblock', '200000', '--wg-reads', '20000']
+    for cached in (False, True):
+        p = _run_two_ranks(cmd, env)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        lines = [l for l in p.stdout.split('\n') if l.startswith('{')]
+        assert len(lines) == 1
+        j = json.loads(lines[0])
+        assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
+        c = j['config']
+        assert c['whole_genome'] is True and 'configs[3]' in c['workload'] and c['shared_index_cached'] is cached
+        assert c['seeds_per_step_per_gpu'] == 140000 and c['reads_per_gpu'] == 20000
+        m = j['multi_gpu']
+        assert len(m['per_gpu']) == 2 and all(x['seeds_per_s'] > 0 for x in m['per_gpu'])
+        assert m['properties']['every_seed_of_the_first_reads_found_on_every_rank'] is True
+        e = m['end_to_end_all_links']
+        assert e['value'] > 0 and len(e['per_gpu_ms']) == 2 and min(e['records_per_gpu']) >= 140000
+        g = j['gather_hits']
+        assert g['records'] >= 2 * 140000 and g['sorted_by_read_id']
 
 
 @pytest.mark.gpu

@@ -1119,6 +1119,32 @@ def test_host_entry_pipeline_equals_one_batch(monkeypatch, sub_bytes, pinned):
     f.close()
 
 
+def test_finder_over_shared_views():
+    """A context loaded from MAPPED views (psi_amd.shared: the arrangement of bench.py --gpus N, one host index for
+    all ranks) answers like one loaded from the builder's own arrays -- one-part and multi-part indexes."""
+    import shutil
+    import tempfile
+    from psi_amd import shared
+    g, reads = _x_case()
+    k, step = 21, 4
+    for kw in (dict(), dict(patched=True, context=25, max_part_text=600)):
+        px = psi_amd.PathIndex.build(g, k, 3, rng_seed=2, **kw)
+        f = psi_amd.SeedFinder(g, k)
+        f.set_path_index(px)
+        want = f.seeds_all(reads[:300], step=step, sort_unique=True)
+        f.close()
+        d = tempfile.mkdtemp(dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+        try:
+            shared.export_views(d, g, px)
+            sg, sx, _ = shared.import_views(d)
+            f2 = psi_amd.SeedFinder(sg, k)
+            f2.set_path_index(sx)
+            assert _eq(f2.seeds_all(reads[:300], step=step, sort_unique=True), want) and len(want)
+            f2.close()
+        finally:
+            shutil.rmtree(d)
+
+
 def _ragged_reads(reads, k):
     out = []
     for i, r in enumerate(reads):

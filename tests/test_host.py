@@ -560,6 +560,47 @@ def test_untrusted_files_cannot_ask_for_memory(tmp_path, ref_data, golden_dir):
     assert sum(l.startswith('rejected') for l in out) == 8
 
 
+def test_views_shared_through_mapped_files(ref_data):
+    """psi_amd.shared: the arrays behind a graph view and an index view (one part and several) written to a
+    memory-backed directory by one process and mapped by another give views with the same scalars and the same bytes:
+    one host index for all the ranks of a node (bench.py --gpus N)."""
+    import ctypes as C
+    import shutil
+    import tempfile
+    from psi_amd import shared
+    b, g = _setup(ref_data, 'x')
+    for kw in (dict(), dict(patched=True, context=14, max_part_text=400), dict(ftab_len=psi_amd.NO_FTAB, sa_rate=4)):
+        px = psi_amd.PathIndex.build(g, 12, 3, rng_seed=1, **kw)
+        d = tempfile.mkdtemp(dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+        try:
+            shared.export_views(d, g, px, extra={'k': 12})
+            sg, sx, extra = shared.import_views(d)
+            assert extra == {'k': 12} and sg.n_nodes == g.n_nodes and sg.n_edges == g.n_edges
+
+            def same(v1, v2):
+                for f in shared._INDEX_SCALARS:
+                    assert getattr(v1, f) == getattr(v2, f), f
+                assert list(v1.C) == list(v2.C)
+                for name, ln, dt in shared._index_arrays(v1):
+                    p1, p2 = getattr(v1, name), getattr(v2, name)
+                    if not ln:
+                        assert not p2, name
+                        continue
+                    nb = int(ln) * np.dtype(dt).itemsize
+                    assert bytes((C.c_uint8 * nb).from_address(p1)) == bytes((C.c_uint8 * nb).from_address(p2)), name
+            same(px.view, sx.view)
+            assert int(px.view.n_more_parts) == int(sx.view.n_more_parts) == len(sx.more_parts())
+            if 'max_part_text' in kw:
+                assert int(sx.view.n_more_parts) >= 2
+            for a_, b_ in zip(px.more_parts(), sx.more_parts()):
+                same(a_, b_)
+            for f in ('node_id', 'label_off', 'labels', 'edge_off', 'edge_to'):
+                assert sg.array(f) is not None and len(sg.array(f))
+            assert bytes(sg.array('labels')) == bytes(g.labels)
+        finally:
+            shutil.rmtree(d)
+
+
 def test_reference_loci_file_format(tmp_path, ref_data):
     """`<prefix>_loci_e<E>l<K>` (reference SeedFinder::save_starts / open_starts, seed_finder.hpp:1640-1679;
     utils.hpp:521-588): u64 count + raw { node id, offset } records with external ids."""
