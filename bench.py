@@ -73,7 +73,12 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
             # SURVEY 8(d) verbatim: locate (s/2) B + 8, map 2 B, emit 32 per on-path hit (the walk itself is longer:
             # SA-order sampling, as sdsl's default, ends a walk with probability 1/s per step -- n_locate_steps)
             return (sa_rate / 2.0 * BLOCK + 8 + 2 * BLOCK + 32) * c['n_hits_on_path'] + (16 + 32.0) * c['n_hits_table']
-        return ((sa_rate - 1) * BLOCK + 4 + 2 * BLOCK + 32) * c['n_hits_on_path'] + (16 + 32.0) * c['n_hits_table']
+        # whole suffix array resident (sa_rate 1): the kernel that runs is k_fm_locate_direct over the LOCATED suffix array --
+        # 20 bytes per seed in (interval, count, flags, (read, offset)), one 8-byte (node, offset) entry per on-path hit,
+        # one 32-byte record out per hit; 16 + 32 per hit that comes from the locus table.  (Rounds 1-3 priced a hit as
+        # SURVEY 8(d) prices locate + map -- sample + two segment-table sectors, 164 B -- which this layout does not read:
+        # the fraction came out above 1.)
+        return 20.0 * c['n_seeds'] + (8 + 32.0) * c['n_hits_on_path'] + (16 + 32.0) * c['n_hits_table']
     if kernel in ('k_kmer_probe', 'k_lkt_probe'):
         # per seed its 8-byte key in and 16 bytes of results out to K2; per N-free seed one 16-byte slot in
         return (8 + 16.0) * c['n_seeds'] + 16.0 * c['n_seeds_valid']
@@ -922,6 +927,9 @@ def main():
         res = time_mode(f2, 10, 3, 'traverse', False)
         f2.close()
         rbm['traverse']['fm_route'] = {
+            'what': 'traverse mode with the FM index of the paths instead of their k-mer table (PSIGPU_TUNE_NO_PATH_TABLE): K1 here is '
+                    'k_fm_search_direct = interval-table entry + per-row records, NO LF step is executed (lf_steps_per_launch 0); the '
+                    "LF / rank kernel doing the work is the series roofline_by_mode['fm-lf']",
             'ms_per_step': res['elapsed'] / res['steps'] * 1e3, 'seeds_per_s': res['seeds'] / res['elapsed'],
             'hits_per_step': int(res['c']['n_hits']), 'tune': psi_amd.TUNE_NO_PATH_TABLE,
             'k_fm_search': roofline_of(res, 'traverse', 'k_fm_search', traffic_key='traverse/fm'),

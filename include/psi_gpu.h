@@ -300,7 +300,16 @@ int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr);
 #define PSIGPU_MODE_KMER_TABLE 0u
 #define PSIGPU_MODE_TRAVERSE 1u
 #define PSIGPU_MODE_LOCUS_TABLE 2u
+/* PSIGPU_MODE_AUTO: KMER_TABLE or TRAVERSE, whichever costs less device time over the calls the caller expects
+ * (psigpu_set_option "expected_calls": chunks the finder will be asked, 0 = unknown = many).  The tables are made by
+ * the device in time proportional to the k-walks of the starting loci + the path positions (chr22-like: 48 ms; whole
+ * genome: 6-14 s); they save the traverser's walk over ALL starting loci and the chunk's seed table on every chunk
+ * (chr22-like: 1.2 ms per 1 M-read chunk; whole genome: ~90 ms per 10 M reads) -- so a finder that answers one chunk
+ * (psikt on a small FASTQ) is better off traversing, one that answers hundreds is not.  Decided when the tables would be
+ * made (psigpu_prepare / the first query) from the index's own sizes; psigpu_query_mode tells which it was. */
+#define PSIGPU_MODE_AUTO 3u
 int psigpu_set_query_mode(psigpu_ctx* ctx, uint32_t mode, uint32_t walk_cap);
+uint32_t psigpu_query_mode(const psigpu_ctx* ctx);     /* the mode queries run in (AUTO: what it resolved to, AUTO until then) */
 
 /* Measurement switches: A/B runs behind bench.py's roofline series (which kernel answers the on-path phase
  * of the FM modes).  The hit set never depends on them.  No counterpart in the reference. */
@@ -322,7 +331,11 @@ int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags);
  *   "no_engine_copy"  1: every transfer through hipMemcpyAsync on the pipeline's streams instead of a named SDMA engine;
  *                     takes effect when set before the context's first host-entry call
  *   "wire"            bytes per record on the device-to-host link: 0 = the narrowest that fits (8, 16, 32), or 8 / 16 / 32 =
- *                     nothing narrower than that */
+ *                     nothing narrower than that
+ *   "expected_calls"  PSIGPU_MODE_AUTO: how many chunks this finder will be asked (0 = unknown: assume many)
+ *   "expected_seeds"  PSIGPU_MODE_AUTO: ... and how many seeds over all of them (0 = unknown)
+ *   "no_pfx_roots"    1: the query-time traverser starts from the starting loci themselves (TraverserBFS as written,
+ *                     traverser_bfs.hpp:72-161) instead of from their tabulated 12-base prefix walks */
 int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value);
 
 /* Builds the tables of the current query mode for seed length k now (index load time) instead of
@@ -451,6 +464,8 @@ typedef struct psigpu_counters {
                                                 * on the host; 32: as returned; the widest any sub-batch of the call used); 0 for the
                                                 * device-resident entry */
   uint64_t n_locate_steps;                     /* LF steps K2 walked from occurrences to sampled suffix-array rows (sa_rate > 1) */
+  uint64_t stale_handbacks;                    /* since the context was made: calls whose counter block came back from the device with
+                                                * another call's serial number (detected, fetched again; expected 0) */
 } psigpu_counters;
 int psigpu_get_counters(const psigpu_ctx* ctx, psigpu_counters* out);
 

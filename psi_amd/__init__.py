@@ -68,8 +68,8 @@ class IndexOpts(C.Structure):
                 ('patched', C.c_uint32), ('reserved1', C.c_uint32), ('max_part_text', C.c_uint64)]
 
 
-MODE_KMER_TABLE, MODE_TRAVERSE, MODE_LOCUS_TABLE = 0, 1, 2
-_MODES = {'kmer-table': MODE_KMER_TABLE, 'traverse': MODE_TRAVERSE, 'locus-table': MODE_LOCUS_TABLE}
+MODE_KMER_TABLE, MODE_TRAVERSE, MODE_LOCUS_TABLE, MODE_AUTO = 0, 1, 2, 3
+_MODES = {'kmer-table': MODE_KMER_TABLE, 'traverse': MODE_TRAVERSE, 'locus-table': MODE_LOCUS_TABLE, 'auto': MODE_AUTO}
 NO_FTAB = 0xFFFFFFFF
 
 
@@ -84,7 +84,7 @@ class Counters(C.Structure):
                 ('ms_total', C.c_float), ('ms_probe', C.c_float), ('ms_locus_table_build', C.c_float),
                 ('search_launches', C.c_uint32),
                 ('traverse_launches', C.c_uint32), ('sorted_in_place', C.c_uint32), ('wire_bytes_per_hit', C.c_uint32),
-                ('n_locate_steps', C.c_uint64)]
+                ('n_locate_steps', C.c_uint64), ('stale_handbacks', C.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -132,6 +132,7 @@ ABI = [
     ('psigpu_set_tuning', C.c_int, [_P, C.c_uint32]),
     ('psigpu_measure_random_loads', C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     ('psigpu_set_query_mode', C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    ('psigpu_query_mode', C.c_uint32, [_P]),
     ('psigpu_find_seeds', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                     C.c_uint32, C.POINTER(Hits)]),
     ('psigpu_free_hits', None, [C.POINTER(Hits)]),
@@ -559,6 +560,11 @@ class SeedFinder:
 
     def set_query_mode(self, mode: str, walk_cap: int = 0) -> None:
         self._chk(lib().psigpu_set_query_mode(self.ctx, _MODES[mode], walk_cap))
+
+    def query_mode(self) -> str:
+        """The mode queries run in ('auto' until an AUTO finder has decided)."""
+        m = lib().psigpu_query_mode(self.ctx)
+        return next(n for n, v in _MODES.items() if v == m)
 
     def _chk(self, st: int) -> None:
         if st:

@@ -146,6 +146,8 @@ struct DevCounters {
   PaddedCounter n_seeds_true;    // the scan's seed count (comes back to the host with the counters)
   StripedCounter max_read_len;   // longest read of the chunk, a running maximum per stripe (the hit sorter sizes its key fields with it)
   PaddedCounter not_grouped;     // sort-unique asked for: set when ordering each seed's hits in place was not enough
+  PaddedCounter serial;          // the call's serial number, stored by the kernel that zeroes the counters: what comes back to the
+                                 // host must carry the serial of THIS call (a stale hand-back is detected, not believed)
   PaddedCounter dbg0, dbg1;      // diagnostics (builds with -DTRAV_STATS)
 };
 
@@ -413,12 +415,13 @@ __device__ __forceinline__ uint32_t seeds_of_read(const uint64_t* __restrict__ r
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_seed_scan_tiles(const uint64_t* __restrict__ read_off, uint64_t n, uint32_t k, uint32_t step, uint64_t* __restrict__ tile_sum,
-                  DevCounters* __restrict__ ctr)
+                  DevCounters* __restrict__ ctr, unsigned long long serial)
 {
   __shared__ uint64_t sh[SCAN_THREADS];
   if (blockIdx.x == 0) {                       // first kernel of a call: it also zeroes the call's counters
     uint4* z = reinterpret_cast<uint4*>(ctr);
-    for (uint32_t i = threadIdx.x; i < sizeof(DevCounters) / 16; i += SCAN_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = threadIdx.x; i < sizeof(DevCounters) / 16; i += SCAN_THREADS)
+      z[i] = (i == offsetof(DevCounters, serial) / 16) ? make_uint4((uint32_t)serial, (uint32_t)(serial >> 32), 0, 0) : make_uint4(0, 0, 0, 0);
   }
   uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
   uint64_t s = 0;
@@ -1147,11 +1150,13 @@ struct EnumOut {
   uint32_t cap_chunks;
   uint32_t* walks;           // [n_loci] complete walks seen per locus
   uint32_t walk_cap;         // loci with more walks than this stay with the query-time traverser
+  uint32_t prefix;           // 1: the walks are the loci's PREFIX walks (ensure_pfx_roots): every pair also carries where the
+                             // walk stands after its last base -- (node | k-mer, offset | locus) -- so that it can be resumed
 };
 
 struct PairWriter { uint32_t id, n; };
 
-__device__ __forceinline__ void pair_emit(const EnumOut& eo, PairWriter& w, bool has, uint64_t kmer, uint32_t locus,
+__device__ __forceinline__ void pair_emit(const EnumOut& eo, PairWriter& w, bool has, uint64_t kmer, uint64_t locus,
                                           DevCounters* ctr)
 {
   uint64_t m = __ballot(has);
@@ -1236,6 +1241,31 @@ k_enum_compact(const ulonglong2* __restrict__ chunks, const uint32_t* __restrict
 }
 
 // sorted pairs -> table: the first entry of every run of equal k-mers claims a slot
+// prefix walks (ensure_pfx_roots): one workgroup per enumeration chunk -- (12-mer | node << 32, locus | offset << 32) pairs to
+// (12-mer, node, offset, locus) records, and the sort key (the locus) of every record
+__global__ void __launch_bounds__(256)
+k_pfx_compact(const ulonglong2* __restrict__ chunks, const uint32_t* __restrict__ fill, const uint64_t* __restrict__ chunk_off,
+              uint32_t cap_chunks, uint4* __restrict__ out, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+  const uint32_t c = blockIdx.x;
+  if (c >= cap_chunks) return;
+  const uint32_t n = fill[c];
+  const uint64_t dst0 = chunk_off[c];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const ulonglong2 r = chunks[(uint64_t)c * CHUNK + i];
+    out[dst0 + i] = make_uint4((uint32_t)r.x, (uint32_t)(r.x >> 32), (uint32_t)(r.y >> 32), (uint32_t)r.y);
+    keys[dst0 + i] = (uint32_t)r.y;
+    vals[dst0 + i] = (uint32_t)(dst0 + i);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_pfx_gather(const uint4* __restrict__ in, const uint32_t* __restrict__ order, uint64_t n, uint4* __restrict__ out)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = in[order[i]];
+}
+
 __global__ void k_lkt_insert(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                              const uint2* __restrict__ loci, uint64_t n, TableSlot* __restrict__ ht, uint64_t n_slots)
 {
@@ -2372,8 +2402,13 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
            const TravItemT<KEY>* __restrict__ spill_in, uint64_t n_spill_in,
            TravItemT<KEY>* __restrict__ spill_out, uint64_t spill_cap,
            uint32_t k, uint64_t rec_offset, psigpu_hit* __restrict__ chunks, uint32_t* __restrict__ chunk_fill,
-           uint32_t cap_chunks, uint64_t n_nodes, DevCounters* ctr, EnumOut eo)
+           uint32_t cap_chunks, uint64_t n_nodes, DevCounters* ctr, EnumOut eo, const uint4* __restrict__ pfx_roots = nullptr)
 {
+  // pfx_roots (round 4, query time, k > 12): the roots are not the loci but their PREFIX WALKS, enumerated once per index
+  // (ensure_pfx_roots): (12-mer, node, offset in the node's record, locus) -- where a walk from the locus stands after 12
+  // bases.  What every chunk did for every locus -- load the locus, load its node record, hop to the next node for the rest
+  // of the 12 bases -- is then a coalesced stream of 16-byte records, checked against the chunk's 12-mer map (L2-resident)
+  // while it is staged: only the third or so of the walks the map lets pass ever enters the walking loop.
   typedef TravItemT<KEY> TravItem;
   typedef DoneItemT<KEY> DoneItem;
   static_assert(!ENUM || sizeof(KEY) == 8, "the tables are made for one-word seeds");
@@ -2387,6 +2422,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   const uint32_t lane = lane_id();
   // roots: either fresh loci (spill_in == nullptr) or spilled partial walks
   const bool from_spill = spill_in != nullptr;
+  const bool from_pfx = !ENUM && !from_spill && pfx_roots != nullptr;      // (n_loci then counts prefix walks)
   const uint64_t n_roots = from_spill ? n_spill_in : n_loci;
   uint64_t cursor = (uint64_t)blockIdx.x * loci_per_wave;     // next root NOT yet requested from memory
   const uint64_t cend = min(n_roots, cursor + loci_per_wave);
@@ -2400,11 +2436,18 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   TravItem pf = { 0, 0, 0 };
   uint32_t pf_off = 0;
   uint32_t pf_cnt = 0;                    // wave-uniform: roots held in the prefetch registers
+  bool pf_keep = false;                   // prefix roots: this lane's prefetched walk passes the chunk's 12-mer map
   auto prefetch = [&]() {
     pf_cnt = (uint32_t)min((uint64_t)64, cend - cursor);
+    pf_keep = lane < pf_cnt;
     if (lane < pf_cnt) {
       uint64_t rix = cursor + lane;
       if (from_spill) { pf = spill_in[rix]; pf_off = 0; }
+      else if (from_pfx) {
+        const uint4 e = pfx_roots[rix];       // 12-mer, node, offset, locus
+        pf.kmer = (KEY)e.x | ((KEY)1 << (2 * PFX_SHORT)); pf.node = e.y; pf.locus = e.w; pf_off = e.z;
+        if (tb.pfx12) pf_keep = (tb.pfx12[e.x >> 5] >> (e.x & 31)) & 1u;
+      }
       else { uint2 lc = loci[rix]; pf.kmer = 1; pf.node = lc.x; pf.locus = (uint32_t)rix; pf_off = lc.y; }
     }
     cursor += pf_cnt;
@@ -2414,7 +2457,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   // that rank window in LDS once, coalesced; anything outside is read from memory.
   uint32_t wb = 0, win_n = 0;             // first rank / size of the window (none for spill launches)
   if (!from_spill && cursor < cend) {
-    wb = loci[cursor].x;
+    wb = from_pfx ? pfx_roots[cursor].y : loci[cursor].x;
     win_n = TRAV_WIN;
     for (uint32_t i = lane; i < TRAV_WIN; i += 64) {
       NodeLite z = { 0, NIL, LITE_SLOW };
@@ -2432,10 +2475,12 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
     if (nm) {
       uint32_t nneed = (uint32_t)__popcll(nm), myr = (uint32_t)__popcll(nm & lanemask_lt());
       uint32_t npop = min(top, nneed);
-      if (nneed > npop && rb_pos == rb_cnt && pf_cnt) {
-        // refill the staged roots from the prefetch registers and start the next prefetch
-        if (lane < pf_cnt) { rootbuf[lane] = pf; rootoff[lane] = pf_off; }
-        rb_pos = 0; rb_cnt = pf_cnt;
+      while (nneed > npop && rb_pos == rb_cnt && pf_cnt) {
+        // refill the staged roots from the prefetch registers and start the next prefetch (prefix roots: only the
+        // walks the 12-mer map lets pass are staged -- possibly none of a refill, hence the loop)
+        const uint64_t km = __ballot(pf_keep);
+        if (pf_keep) { const uint32_t at = (uint32_t)__popcll(km & lanemask_lt()); rootbuf[at] = pf; rootoff[at] = pf_off; }
+        rb_pos = 0; rb_cnt = (uint32_t)__popcll(km);
         prefetch();
         __builtin_amdgcn_wave_barrier();
       }
@@ -2454,7 +2499,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
 #endif
 
     // ---- extend through one node ---------------------------------------------------
-    uint32_t nchild = 0, e_off = 0;
+    uint32_t nchild = 0, e_off = 0, end_off = 0;
     KEY fork_kmer = 0;
     bool done = false;
     if (have) {
@@ -2494,6 +2539,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
         e_off = nr.edge_off;
         nl.edge0 = nr.edge0;
       }
+      end_off = off + take;               // where the walk stands in this node's record after the bases it took
       if (take && !dead) {
         KEY body = it.kmer ^ ((KEY)1 << (2 * depth));
         body = (body << (2 * take)) | b;
@@ -2526,7 +2572,10 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
       // a locus that went over the cap stops forking (it is left to the query-time traverser)
       bool has = false;
       if (done) { ++kpaths; has = atomicAdd(&eo.walks[it.locus], 1u) < eo.walk_cap; }
-      pair_emit(eo, pw, has, (uint64_t)(it.kmer ^ ((KEY)1 << (2 * k))), it.locus, ctr);
+      const uint64_t km_ = (uint64_t)(it.kmer ^ ((KEY)1 << (2 * k)));
+      if (eo.prefix) pair_emit(eo, pw, has, km_ | ((uint64_t)it.node << 32), (uint64_t)it.locus | ((uint64_t)end_off << 32), ctr);
+      else
+      pair_emit(eo, pw, has, km_, it.locus, ctr);
       if (nchild > 1 && eo.walks[it.locus] > eo.walk_cap) { nchild = 0; have = false; }
     } else {
       uint64_t dm = __ballot(done);
@@ -2891,6 +2940,11 @@ struct psigpu_ctx {
   uint64_t kt_ht_size = 0, kt_n_path_kmers = 0, kt_n_ext = 0;
   uint32_t lkt_k = 0;
   DevBuf lkt_ht, lkt_ent, lkt_res;
+  // traverse mode, k > 12: the loci's 12-base prefix walks (k_traverse's pfx_roots), made once per index
+  DevBuf pfx_roots;
+  uint64_t pfx_n = 0;
+  bool pfx_ready = false, pfx_failed = false;
+  float pfx_build_ms = 0.f;
   uint64_t lkt_ht_size = 0, lkt_n_ent = 0, lkt_n_res = 0, lkt_n_walks = 0;
   float lkt_build_ms = 0.f;
   std::string lkt_note;
@@ -2945,7 +2999,13 @@ struct psigpu_ctx {
   bool opt_no_ahead = false, opt_no_engine_copy = false;
   uint32_t opt_wire = 0;           // 0: the narrowest wire record that fits; 8 / 16 / 32: nothing narrower
   uint32_t opt_wire8_roff_cap = 0; // test hook: at most this many read-offset bits in an 8-byte record
+  bool opt_no_pfx_roots = false;   // traverse mode from the loci themselves (A/B, tests)
+  uint64_t opt_expected_calls = 0; // PSIGPU_MODE_AUTO: chunks the caller expects to ask (0: unknown)
+  uint64_t opt_expected_seeds = 0; // ... and seeds over all of them
+  bool auto_mode = false, auto_resolved = false;
   uint32_t wire_used = 0;          // bytes per wire record the last run_pipeline call left in its wire buffer (0: none)
+  unsigned long long serial = 0;   // run_pipeline calls so far: every call's counter block carries its number
+  uint64_t stale_handbacks = 0;    // counter blocks that came back with another call's number (psigpu_counters.stale_handbacks)
   bool wire8_overflowed = false;   // a sub-batch's records did not fit 8 bytes: the context stays with 16 from then on
 };
 
@@ -3165,7 +3225,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
                     &ctx->w_iv_tiles_off, &ctx->w_defer, &ctx->kt_ht, &ctx->kt_ext, &ctx->w_seedres };
   for (auto* b : all) b->release();
   ctx->ids_sorted.release(); ctx->w_sorted[0].release(); ctx->w_sorted[1].release(); ctx->w_count.release();
-  ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release();
+  ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release(); ctx->pfx_roots.release();
   for (DevBuf* b : { &ctx->w_sb_cnt, &ctx->w_sb_off, &ctx->w_sb_tiles, &ctx->w_sb_key, &ctx->w_seed_wide, &ctx->w_seed_pfx }) b->release();
   for (auto& m : ctx->parts) m->release();
   ctx->w_hits_alt.release(); ctx->in_bases.release(); ctx->in_mask.release();
@@ -3191,6 +3251,7 @@ const char* psigpu_last_error(const psigpu_ctx* ctx)
 }
 
 static void lkt_release(psigpu_ctx* ctx);
+static void pfx_release(psigpu_ctx* ctx);
 static void drop_row_records(psigpu_ctx* ctx);
 
 int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr)
@@ -3202,6 +3263,12 @@ int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr)
   }
   ctx->gocc_thr = thr;
   return PSIGPU_OK;
+}
+
+static void pfx_release(psigpu_ctx* ctx)
+{
+  ctx->pfx_roots.release();
+  ctx->pfx_n = 0; ctx->pfx_ready = ctx->pfx_failed = false;
 }
 
 static void lkt_release(psigpu_ctx* ctx)
@@ -3216,12 +3283,43 @@ static void lkt_release(psigpu_ctx* ctx)
 
 int psigpu_set_query_mode(psigpu_ctx* ctx, uint32_t mode, uint32_t walk_cap)
 {
-  if (!ctx || mode > PSIGPU_MODE_LOCUS_TABLE) return PSIGPU_ERR_ARG;
+  if (!ctx || mode > PSIGPU_MODE_AUTO) return PSIGPU_ERR_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return PSIGPU_ERR_DEVICE;
+  ctx->auto_mode = mode == PSIGPU_MODE_AUTO;
+  ctx->auto_resolved = false;
+  if (ctx->auto_mode) { ctx->walk_cap = walk_cap; return PSIGPU_OK; }      // (resolved, and the tables dropped if need be, by resolve_auto_mode)
   if (mode != ctx->query_mode || walk_cap != ctx->walk_cap) lkt_release(ctx);
   ctx->query_mode = mode;
   ctx->walk_cap = walk_cap;
   return PSIGPU_OK;
+}
+
+uint32_t psigpu_query_mode(const psigpu_ctx* ctx)
+{
+  if (!ctx) return PSIGPU_MODE_KMER_TABLE;
+  return (ctx->auto_mode && !ctx->auto_resolved) ? PSIGPU_MODE_AUTO : ctx->query_mode;
+}
+
+// PSIGPU_MODE_AUTO: k-mer table or traverser, by device time over the expected calls.  The constants are this part's,
+// measured on the chr22-like and the whole-genome workloads: the tables cost ~1 ns per tabulated
+// k-mer (k-walks of the loci, ~2.6 per locus on SNV graphs, + path positions); without them every call pays the traverser's
+// pass over the loci (~40 ps per locus) and the chunk's seed table with its lookups (~50 ps per seed: "expected_seeds").
+static void resolve_auto_mode(psigpu_ctx* ctx)
+{
+  if (!ctx->auto_mode || ctx->auto_resolved || !ctx->have_index) return;
+  uint64_t text = 0;
+  for (const auto& fp : ctx->parts) text += fp->text_len;
+  const double t_build_ms = (2.6 * (double)ctx->n_loci + (double)text) * 1.0e-6;
+  const double t_call_ms = (double)ctx->n_loci * 40e-9;
+  const double t_seeds_ms = (double)ctx->opt_expected_seeds * 50e-9;         // the chunk's seed table + its lookups, per seed
+  const bool table = ctx->opt_expected_calls == 0 || (double)ctx->opt_expected_calls * t_call_ms + t_seeds_ms > t_build_ms;
+  const uint32_t mode = table ? PSIGPU_MODE_KMER_TABLE : PSIGPU_MODE_TRAVERSE;
+  if (mode != ctx->query_mode) lkt_release(ctx);
+  ctx->query_mode = mode;
+  ctx->auto_resolved = true;
+  if (getenv("PSIGPU_TRACE"))
+    fprintf(stderr, "[psigpu] auto mode: %s (tables ~%.1f ms, traverser ~%.2f ms per call, %llu calls expected)\n",
+            table ? "k-mer table" : "traverse", t_build_ms, t_call_ms, (unsigned long long)ctx->opt_expected_calls);
 }
 
 int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags)
@@ -3244,7 +3342,10 @@ int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value)
   else if (n == "wire") {
     if (value != 0 && value != 8 && value != 16 && value != 32) { ctx->err = "wire: 0, 8, 16 or 32"; return PSIGPU_ERR_ARG; }
     ctx->opt_wire = (uint32_t)value;
-  } else if (n == "wire8_roff_bits") { ctx->opt_wire8_roff_cap = (uint32_t)value; ctx->wire8_overflowed = false; }      // (test hook)
+  } else if (n == "no_pfx_roots") ctx->opt_no_pfx_roots = value != 0;
+  else if (n == "expected_calls") { ctx->opt_expected_calls = value; ctx->auto_resolved = false; }
+  else if (n == "expected_seeds") { ctx->opt_expected_seeds = value; ctx->auto_resolved = false; }
+  else if (n == "wire8_roff_bits") { ctx->opt_wire8_roff_cap = (uint32_t)value; ctx->wire8_overflowed = false; }      // (test hook)
   else { ctx->err = "unknown option '" + n + "'"; return PSIGPU_ERR_ARG; }
   return PSIGPU_OK;
 }
@@ -3516,6 +3617,8 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
   ctx->n_loci = x->n_loci;
   ctx->have_index = true;
   lkt_release(ctx);
+  pfx_release(ctx);
+  ctx->auto_resolved = false;
   return PSIGPU_OK;
 }
 
@@ -3954,6 +4057,115 @@ static int ensure_lkt(psigpu_ctx* ctx, uint32_t k, const GraphView& gv)
   return PSIGPU_OK;
 }
 
+static GraphView graph_view(const psigpu_ctx* ctx);
+
+// The loci's PREFIX WALKS (k_traverse's pfx_roots): every walk of PFX_SHORT bases from every starting locus, with where it
+// stands after its last base, in locus order.  A function of the graph and the loci alone, made once per index by the
+// traverser itself in enumeration mode (seed length PFX_SHORT, no cap, prefix pairs), then ordered by locus (the node
+// window a wave stages follows its first root).  When it cannot be made (memory, a flood of walks) the traverser starts
+// from the loci as before.
+static int ensure_pfx_roots(psigpu_ctx* ctx, const GraphView& gv)
+{
+  if (ctx->pfx_ready || ctx->pfx_failed) return PSIGPU_OK;
+  const uint64_t n_loci = ctx->n_loci;
+  auto give_up = [&](const char*) { (void)hipGetLastError(); pfx_release(ctx); ctx->pfx_failed = true; return PSIGPU_OK; };
+#define PFX_TRY(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ == hipErrorOutOfMemory) return give_up("memory");                                   \
+    if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return PSIGPU_ERR_DEVICE; } \
+  } while (0)
+  if (n_loci == 0 || n_loci >= 0xFFFFFFF0ull) return give_up("no loci");
+  const auto t0 = std::chrono::steady_clock::now();
+  HIPCHK(ctx, hipDeviceSynchronize());
+  HIPCHK(ctx, ctx->w_ctr.ensure(sizeof(DevCounters)));
+  DevCounters* ctr = ctx->w_ctr.as<DevCounters>();
+  TmpBuf walks, chunks, fill, chunk_off, tiles, total, spill_a, spill_b;
+  uint64_t spill_cap = 1u << 22;
+  PFX_TRY(spill_a.alloc(spill_cap * sizeof(TravItem)));
+  PFX_TRY(spill_b.alloc(spill_cap * sizeof(TravItem)));
+  PFX_TRY(total.alloc(64));
+  PFX_TRY(walks.alloc(n_loci * 4 + 16));
+  const uint2* roots = ctx->loci.as<uint2>();
+  const uint32_t per_wave = (uint32_t)std::max<uint64_t>(256, (n_loci + 24575) / 24576);
+  const uint64_t n_waves = (n_loci + per_wave - 1) / per_wave;
+  uint64_t cap_chunks = 2 * n_loci / CHUNK + n_waves + 4096;
+  TableView tb{};
+  DevCounters h{};
+  for (int attempt = 0, regrown = 0;; ++attempt) {
+    if (cap_chunks >= 0xFFFFFFF0ull || cap_chunks * CHUNK * sizeof(ulonglong2) > (64ull << 30)) return give_up("too many prefix walks");
+    PFX_TRY(chunks.alloc(cap_chunks * CHUNK * sizeof(ulonglong2)));
+    PFX_TRY(fill.alloc((cap_chunks + 1) * 4));
+    PFX_TRY(hipMemset(fill.p, 0, (cap_chunks + 1) * 4));
+    PFX_TRY(hipMemset(walks.p, 0, n_loci * 4 + 16));
+    PFX_TRY(hipMemset(ctr, 0, sizeof(DevCounters)));
+    EnumOut eo = { chunks.as<ulonglong2>(), fill.as<uint32_t>(), (uint32_t)cap_chunks, walks.as<uint32_t>(), 0xFFFFFFFFu, 1u };
+    k_traverse<true, uint64_t><<<(unsigned)n_waves, 64>>>(gv, tb, roots, n_loci, per_wave, nullptr, 0, spill_a.as<TravItem>(), spill_cap,
+                                                PFX_SHORT, 0, nullptr, nullptr, 0, ctx->n_nodes, ctr, eo);
+    PFX_TRY(hipMemcpy(&h, ctr, sizeof h, hipMemcpyDeviceToHost));
+    TmpBuf* qin = &spill_a;
+    TmpBuf* qout = &spill_b;
+    bool spill_overflow = false;
+    while (h.n_spill.v) {
+      const unsigned long long ns = h.n_spill.v;
+      if (ns > spill_cap) {
+        if (spill_cap >= (1ull << 28) || ++regrown > 6) return give_up("spill");
+        spill_cap = std::min<uint64_t>(1ull << 28, std::max<uint64_t>(2 * spill_cap, ns + ns / 4));
+        PFX_TRY(spill_a.alloc(spill_cap * sizeof(TravItem)));
+        PFX_TRY(spill_b.alloc(spill_cap * sizeof(TravItem)));
+        spill_overflow = true;
+        break;
+      }
+      PFX_TRY(hipMemset(&ctr->n_spill.v, 0, 8));
+      k_traverse<true, uint64_t><<<(unsigned)((ns + 63) / 64), 64>>>(gv, tb, roots, n_loci, 64, qin->as<TravItem>(), ns, qout->as<TravItem>(),
+                                                          spill_cap, PFX_SHORT, 0, nullptr, nullptr, 0, ctx->n_nodes, ctr, eo);
+      std::swap(qin, qout);
+      PFX_TRY(hipMemcpy(&h, ctr, sizeof h, hipMemcpyDeviceToHost));
+    }
+    if (spill_overflow) { --attempt; continue; }
+    if (h.n_chunks.v <= cap_chunks) break;
+    if (attempt) return give_up("chunks");
+    cap_chunks = h.n_chunks.v + 1024;
+  }
+  const uint64_t used_chunks = h.n_chunks.v;
+  const uint64_t chunk_tiles = cap_chunks / SCAN_TILE + 1;
+  PFX_TRY(chunk_off.alloc((cap_chunks + 2) * 8));
+  PFX_TRY(tiles.alloc(chunk_tiles * 8));
+  k_scan_tiles<<<(unsigned)chunk_tiles, SCAN_THREADS>>>(fill.as<uint32_t>(), cap_chunks, tiles.as<uint64_t>());
+  k_scan_sums<<<1, SCAN_THREADS>>>(tiles.as<uint64_t>(), chunk_tiles, total.as<uint64_t>());
+  k_scan_final<<<(unsigned)chunk_tiles, SCAN_THREADS>>>(fill.as<uint32_t>(), cap_chunks, tiles.as<uint64_t>(), chunk_off.as<uint64_t>());
+  uint64_t n = 0;
+  PFX_TRY(hipMemcpy(&n, total.p, 8, hipMemcpyDeviceToHost));
+  spill_a.drop(); spill_b.drop(); walks.drop();
+  if (n == 0 || n >= 0xFFFFFFF0ull) return give_up("no walks");
+  TmpBuf raw, keys_a, keys_b, vals_a, vals_b;
+  PFX_TRY(raw.alloc(n * 16));
+  PFX_TRY(keys_a.alloc((n + 1) * 8)); PFX_TRY(keys_b.alloc((n + 1) * 8));
+  PFX_TRY(vals_a.alloc((n + 1) * 4)); PFX_TRY(vals_b.alloc((n + 1) * 4));
+  if (used_chunks)
+    k_pfx_compact<<<(unsigned)used_chunks, 256>>>(chunks.as<ulonglong2>(), fill.as<uint32_t>(), chunk_off.as<uint64_t>(), (uint32_t)cap_chunks,
+                                                 raw.as<uint4>(), keys_a.as<uint64_t>(), vals_a.as<uint32_t>());
+  PFX_TRY(hipDeviceSynchronize());
+  chunks.drop();
+  {
+    std::string err;
+    int st = psigpu::gpu_sort_pairs_u64(keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), n, 32, &err);
+    if (st == PSIGPU_ERR_NOMEM) return give_up("sort");
+    if (st != PSIGPU_OK) { ctx->err = err; return st; }
+  }
+  PFX_TRY(ctx->pfx_roots.ensure((n + 64) * 16));
+  k_pfx_gather<<<(unsigned)((n + 255) / 256), 256>>>(raw.as<uint4>(), vals_b.as<uint32_t>(), n, ctx->pfx_roots.as<uint4>());
+  PFX_TRY(hipDeviceSynchronize());
+  ctx->pfx_n = n;
+  ctx->pfx_ready = true;
+  ctx->pfx_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (getenv("PSIGPU_TRACE"))
+    fprintf(stderr, "[psigpu] prefix walks of the starting loci: %llu walks of %u bases from %llu loci, %.1f ms\n", (unsigned long long)n, PFX_SHORT,
+            (unsigned long long)n_loci, ctx->pfx_build_ms);
+  return PSIGPU_OK;
+#undef PFX_TRY
+}
+
 static GraphView graph_view(const psigpu_ctx* ctx)
 {
   GraphView gv;
@@ -3979,6 +4191,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   if (step == 0) step = k;                       // src/psikt.cpp:469
   if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..63)"; return PSIGPU_ERR_ARG; }
   if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
+  resolve_auto_mode(ctx);
   if ((flags & PSIGPU_OFF_PATHS) && ctx->n_loci && ctx->index_k != k) {
     ctx->err = "starting loci were computed for a different seed length";
     return PSIGPU_ERR_ARG;
@@ -4057,6 +4270,16 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   }
   const uint2* trav_loci = use_lkt ? ctx->lkt_res.as<uint2>() : ctx->loci.as<uint2>();
   const uint64_t n_trav_loci = use_lkt ? ctx->lkt_n_res : ctx->n_loci;
+  // traverse mode proper (every starting locus, every chunk), one-word seeds longer than the short prefix map: start from the
+  // loci's prefix walks instead of the loci (PSIGPU_NO_PFX_ROOTS=1: from the loci, the A/B)
+  static const bool env_no_pfx_roots = getenv("PSIGPU_NO_PFX_ROOTS") != nullptr;
+  const uint4* pfx_roots = nullptr;
+  uint64_t n_pfx_roots = 0;
+  if (want_off && !use_lkt && !wide && k > PFX_SHORT && !env_no_pfx_roots && !ctx->opt_no_pfx_roots) {
+    int st = ensure_pfx_roots(ctx, gv);
+    if (st != PSIGPU_OK) return st;
+    if (ctx->pfx_ready) { pfx_roots = ctx->pfx_roots.as<uint4>(); n_pfx_roots = ctx->pfx_n; EVREC(0, stream); }
+  }
   pc.n_loci_traversed = (flags & PSIGPU_OFF_PATHS) ? n_trav_loci : 0;
   pc.n_locus_kmers = use_lkt ? ctx->lkt_n_ent : 0;
   pc.n_path_kmers = use_kt ? ctx->kt_n_path_kmers : 0;
@@ -4089,7 +4312,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     HIPCHK(ctx, ctx->w_tiles.ensure(n_tiles * 8));
     HIPCHK(ctx, ctx->w_seed_off.ensure((n_reads + 1) * 8));
     k_seed_scan_tiles<<<(unsigned)n_tiles, SCAN_THREADS, 0, stream>>>(d_read_off, n_reads, k, step,
-                                                                    ctx->w_tiles.as<uint64_t>(), ctr);
+                                                                    ctx->w_tiles.as<uint64_t>(), ctr, ++ctx->serial);
     k_seed_scan_final<<<(unsigned)n_tiles, SCAN_THREADS, 0, stream>>>(d_read_off, n_reads, k, step,
                                                                     ctx->w_tiles.as<uint64_t>(),
                                                                     ctx->w_seed_off.as<uint64_t>(),
@@ -4246,8 +4469,9 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     };
     auto launch_traverse = [&](hipStream_t ts) -> int {
       // ~96 waves per CU over the launch keeps the tail short and the atomics few
-      const uint32_t per_wave = (uint32_t)std::max<uint64_t>(256, (n_trav_loci + 24575) / 24576);
-      uint64_t n_waves = (n_trav_loci + per_wave - 1) / per_wave;
+      const uint64_t n_roots_l = pfx_roots ? n_pfx_roots : n_trav_loci;
+      const uint32_t per_wave = (uint32_t)std::max<uint64_t>(256, (n_roots_l + 24575) / 24576);
+      uint64_t n_waves = (n_roots_l + per_wave - 1) / per_wave;
       if (wide)
         k_traverse<false, u128><<<(unsigned)n_waves, 64, 0, ts>>>(
             gv, tb, trav_loci, n_trav_loci, per_wave,
@@ -4256,10 +4480,10 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
             EnumOut{});
       else
       k_traverse<false, uint64_t><<<(unsigned)n_waves, 64, 0, ts>>>(
-          gv, tb, trav_loci, n_trav_loci, per_wave,
+          gv, tb, trav_loci, n_roots_l, per_wave,
           nullptr, 0, ctx->w_spill_a.as<TravItem>(), spill_cap, k, rec_offset,
           ctx->w_chunks.as<psigpu_hit>(), ctx->w_chunk_fill.as<uint32_t>(), (uint32_t)cap_chunks, ctx->n_nodes, ctr,
-          EnumOut{});
+          EnumOut{}, pfx_roots);
       ++pc.traverse_launches;
       EVREC(7, ts);
       return PSIGPU_OK;
@@ -4499,6 +4723,15 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
                                               wire->as<uint4>());
       HIPCHK(ctx, hipStreamSynchronize(stream));
       ctx->wire_used = 16;
+    }
+    if (n_reads && h.serial.v != ctx->serial) {
+      // what came back is not this call's counter block (never seen alone; the check is there because a stale count is
+      // exactly what one record missing / two extra under GPU sharing would look like): counted, reported, and the block
+      // is fetched again with a runtime copy
+      ++ctx->stale_handbacks;
+      if (getenv("PSIGPU_TRACE")) fprintf(stderr, "[psigpu] stale counter hand-back: serial %llu, expected %llu\n", h.serial.v, ctx->serial);
+      HIPCHK(ctx, hipMemcpy(&h, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost));
+      if (h.serial.v != ctx->serial) { ctx->err = "the counters of the call did not come back from the device"; return PSIGPU_ERR_DEVICE; }
     }
     ctx->grouped_state = fix_groups ? (h.not_grouped.v ? 2 : 1) : 0;
     true_seeds = h.n_seeds_true.v;
@@ -4742,10 +4975,14 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k)
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..63)"; return PSIGPU_ERR_ARG; }
   if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
+  resolve_auto_mode(ctx);
   if (ctx->index_k != k || k > PSIGPU_MAX_TABLE_SEED_LEN) return PSIGPU_OK;   // tables exist for the index's seed length only, and for one-word seeds
   int st = PSIGPU_OK;
   if (ctx->query_mode == PSIGPU_MODE_TRAVERSE) {                           // (only the paths' k-mers are tabulated in traverse mode)
     if (ctx->n_paths && ctx->sa_rate == 1 && !(ctx->tune & PSIGPU_TUNE_NO_PATH_TABLE)) st = ensure_lkt(ctx, k, graph_view(ctx));
+    // ... and the loci's prefix walks, where the traverser starts
+    if (st == PSIGPU_OK && ctx->n_loci && k > PFX_SHORT && !ctx->opt_no_pfx_roots && getenv("PSIGPU_NO_PFX_ROOTS") == nullptr)
+      st = ensure_pfx_roots(ctx, graph_view(ctx));
   } else if (!(ctx->n_loci == 0 && !(ctx->query_mode == PSIGPU_MODE_KMER_TABLE && ctx->n_paths)))
     st = ensure_lkt(ctx, k, graph_view(ctx));
   // the FM modes' per-row records (the k-mer table mode never reads them)
@@ -5506,6 +5743,7 @@ int psigpu_get_counters(const psigpu_ctx* ctx, psigpu_counters* out)
 {
   if (!ctx || !out) return PSIGPU_ERR_ARG;
   *out = ctx->last;
+  out->stale_handbacks = ctx->stale_handbacks;
   return PSIGPU_OK;
 }
 

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <sys/stat.h>
 #include <thread>
 #include <vector>
 
@@ -86,7 +87,8 @@ const char* USAGE =
   "      --device INT           GPU ordinal (default: 0)\n"
   "      --devices LIST         several GPUs, e.g. 0-7 or 0,2,3: the index is copied to each, every chunk's\n"
   "                             reads are split into one contiguous range per GPU (same output)\n"
-  "      --query-mode MODE      kmer-table | locus-table | traverse (default: kmer-table; same hits)\n"
+  "      --query-mode MODE      kmer-table | locus-table | traverse | auto (default: kmer-table; same hits;\n"
+  "                             auto: traverse for a small FASTQ, tables for a large one)\n"
   "  -h, --help\n";
 
 bool ends_with( std::string const& s, const char* suf )
@@ -188,6 +190,7 @@ Options parse_args( int argc, char** argv )
       if ( m == "kmer-table" ) o.query_mode = PSIGPU_MODE_KMER_TABLE;
       else if ( m == "locus-table" ) o.query_mode = PSIGPU_MODE_LOCUS_TABLE;
       else if ( m == "traverse" ) o.query_mode = PSIGPU_MODE_TRAVERSE;
+      else if ( m == "auto" ) o.query_mode = PSIGPU_MODE_AUTO;
       else throw std::runtime_error( "unknown query mode " + m );
     }
     else if ( !a.empty() && a[ 0 ] == '-' ) throw std::runtime_error( "unknown option " + a );
@@ -285,6 +288,20 @@ int run( Options const& o, Logger& log )
   warm.join();
   finder_type finder( graph, o.seed_len, o.gocc_threshold, o.max_mem, o.devices[ 0 ] );
   finder.set_query_mode( o.query_mode );
+  if ( o.query_mode == PSIGPU_MODE_AUTO ) {
+    /* how much is there to answer?  A plain FASTQ is ~2 bytes per base (bases + qualities): seeds ~ size / (2 d); the
+     * chunks follow from -c (0: the whole file is one chunk).  A gzip'd file says nothing: assume a lot. */
+    std::uint64_t calls = 0, seeds = 0;
+    struct stat sb;
+    bool const gz = o.fq_path.size() > 3 && o.fq_path.compare( o.fq_path.size() - 3, 3, ".gz" ) == 0;
+    if ( !gz && stat( o.fq_path.c_str(), &sb ) == 0 && sb.st_size > 0 ) {
+      unsigned const d = o.distance ? o.distance : o.seed_len;
+      seeds = (std::uint64_t)sb.st_size / ( 2ull * std::max( 1u, d ) ) + 1;
+      std::uint64_t const reads = (std::uint64_t)sb.st_size / 320 + 1;
+      calls = o.chunk_size ? ( reads + o.chunk_size - 1 ) / o.chunk_size : 1;
+    }
+    finder.set_expected_work( calls, seeds );
+  }
   /* the first chunk of reads is parsed (into page-locked memory) while the index is loaded or made */
   auto chunk = finder.create_readrecord();
   std::future< bool > first_chunk;

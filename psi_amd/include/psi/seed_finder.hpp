@@ -79,6 +79,13 @@ namespace psi {
     {
       check( psigpu_set_query_mode( ctx, mode, walk_cap ) );
     }
+    /** PSIGPU_MODE_AUTO: how much work the caller expects (chunks, seeds over all of them; 0 = unknown = a lot). */
+    void set_expected_work( std::uint64_t calls, std::uint64_t seeds )
+    {
+      check( psigpu_set_option( ctx, "expected_calls", calls ) );
+      check( psigpu_set_option( ctx, "expected_seeds", seeds ) );
+    }
+    unsigned int query_mode() const { return psigpu_query_mode( ctx ); }
     SeedFinder( SeedFinder const& ) = delete;
     SeedFinder& operator=( SeedFinder const& ) = delete;
     ~SeedFinder() { psigpu_destroy( ctx ); }

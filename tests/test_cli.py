@@ -58,7 +58,8 @@ def test_output_bytes_match_golden(tmp_path):
     for graph in ('x.gfa', 'x.vg'):
         for extra in (['-n', '0'], ['-n', '1', '-P', '-I', prefix], ['-n', '1', '-P', '-I', prefix, '-c', '3'],
                       ['-n', '2', '-P', '-d', '10'], ['-n', '1', '-P', '--query-mode', 'traverse'],
-                      ['-n', '1', '-P', '--query-mode', 'locus-table'], ['-n', '0', '--query-mode', 'traverse']):
+                      ['-n', '1', '-P', '--query-mode', 'locus-table'], ['-n', '0', '--query-mode', 'traverse'],
+                      ['-n', '1', '-P', '--query-mode', 'auto'], ['-n', '1', '-P', '--query-mode', 'auto', '-c', '2']):
             out = str(tmp_path / 'out.gam')
             p = run(os.path.join(REF, graph), '-f', fq, '-l', '10', '-o', out, '-L', str(tmp_path / 'psi.log'),
                     *extra)

@@ -1119,6 +1119,72 @@ def test_host_entry_pipeline_equals_one_batch(monkeypatch, sub_bytes, pinned):
     f.close()
 
 
+@pytest.mark.parametrize('k,step', [(13, 4), (21, 21), (31, 7)])
+def test_traverser_from_prefix_walks_equals_traverser_from_loci(k, step):
+    """Traverse mode (TraverserBFS over every starting locus for every chunk, traverser_bfs.hpp:72-161) starts from the loci's
+    tabulated 12-base prefix walks since round 4; started from the loci themselves (option no_pfx_roots) it must give the
+    same records -- SNV graph with N blocks, a dense layered graph whose walks spill out of LDS, graph x without a path
+    index (every locus a starting locus) -- and the same number of complete k-walks."""
+    from oracle import brute
+    cases = []
+    sg = synth.snv_graph(200_000, 8_000, n_block=5_000, seed=k)
+    cases.append((psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path]),
+                  synth.sim_reads_snv(sg, 2000, 100, seed=3), 1))
+    nid, lo, lab, eo, et, ref = synth.layered_graph(150, max_width=4, max_len=5, seed=k, p_n=0.01)
+    lg = psi_amd.Graph.from_csr(nid, lo, lab, eo, et, paths=[ref])
+    rng = np.random.default_rng(k)
+    lreads = []
+    for _ in range(300):
+        v = int(rng.integers(0, len(nid)))
+        seq = bytes(lab[int(lo[v]):int(lo[v + 1])]).decode()
+        while len(seq) < 60 and eo[v + 1] > eo[v]:
+            v = int(et[int(rng.integers(int(eo[v]), int(eo[v + 1])))])
+            seq += bytes(lab[int(lo[v]):int(lo[v + 1])]).decode()
+        lreads.append(seq[:60])
+    cases.append((lg, lreads, 0))
+    gx, xr = _x_case()
+    cases.append((gx, xr[:200], 0))
+    for g, reads, npaths in cases:
+        res = []
+        for no_roots in (0, 1):
+            f = psi_amd.SeedFinder(g, k, mode='traverse')
+            f.set_option('no_pfx_roots', no_roots)
+            f.create_path_index(npaths, rng_seed=1)
+            if no_roots == 0:
+                f.prepare()
+            hits = psi_amd.sort_unique(f.seeds_all(reads, step=step))
+            res.append((hits, f.counters()['n_kpaths']))
+            f.close()
+        assert len(res[0][0]) and _eq(res[0][0], res[1][0])
+        assert res[0][1] == res[1][1]
+
+
+def test_auto_query_mode_decides_by_expected_work():
+    """PSIGPU_MODE_AUTO: a finder that expects one small chunk traverses (no tables made), one that expects many -- or
+    does not know -- tabulates; same records either way (north_star: the traverser kernel and the tabulated default are
+    the same function of the index)."""
+    sg = synth.snv_graph(300_000, 9_000, n_block=20_000, seed=5)
+    g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path])
+    bases, off = synth.sim_reads_snv(sg, 2000, 150, seed=6)
+    k = 21
+    px = psi_amd.PathIndex.build(g, k, 1, rng_seed=2)
+    res = {}
+    for label, calls, seeds, want_mode in (('one', 1, 14_000, 'traverse'), ('many', 100_000, 10 ** 9, 'kmer-table'),
+                                           ('unknown', 0, 0, 'kmer-table')):
+        f = psi_amd.SeedFinder(g, k, mode='auto')
+        assert f.query_mode() == 'auto'
+        f.set_option('expected_calls', calls)
+        f.set_option('expected_seeds', seeds)
+        f.set_path_index(px)
+        f.prepare()
+        assert f.query_mode() == want_mode, label
+        res[label] = psi_amd.sort_unique(f.seeds_all((bases, off), step=k))
+        c = f.counters()
+        assert (c['n_loci_traversed'] > 0) == (want_mode == 'traverse')
+        f.close()
+    assert len(res['one']) > 2000 and _eq(res['one'], res['many']) and _eq(res['one'], res['unknown'])
+
+
 def test_finder_over_shared_views():
     """A context loaded from MAPPED views (psi_amd.shared: the arrangement of bench.py --gpus N, one host index for
     all ranks) answers like one loaded from the builder's own arrays -- one-part and multi-part indexes."""

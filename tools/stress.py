@@ -56,7 +56,7 @@ def worker(args, proc, tid, seeds, stats, lock):
                 stats['first_mismatches'].append({'kind': kind, 'seed': seed, 'proc': proc, 'thread': tid, **detail})
         print('MISMATCH', kind, seed, detail, file=sys.stderr, flush=True)
 
-    n_calls = n_life = 0
+    n_calls = n_life = n_stale = 0
     for seed in seeds:
         g, reads = T._random_graph(seed)
         rng = random.Random(seed * 7919 + 13)
@@ -116,12 +116,14 @@ def worker(args, proc, tid, seeds, stats, lock):
                     bad('host_entry', seed, {'k': k, 'step': step, 'npaths': npaths, 'mode': mode, 'life': life, 'shape': shape,
                                              'sorted': su, 'got': int(len(r)), 'want': int(len(want)),
                                              'extra': sorted(a - b)[:4], 'missing': sorted(b - a)[:4], 'counters': f.counters()})
+            n_stale += int(f.counters()['stale_handbacks'])
             f.close()
         del pin, pk, px, pg
     with lock:
         stats['calls'] = stats.get('calls', 0) + n_calls
         stats['lifetimes'] = stats.get('lifetimes', 0) + n_life
         stats['graphs'] = stats.get('graphs', 0) + len(seeds)
+        stats['stale_handbacks'] = stats.get('stale_handbacks', 0) + n_stale
 
 
 def run_process(args):
