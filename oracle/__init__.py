@@ -31,8 +31,10 @@ def build(force: bool = False) -> str:
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        alt = os.environ.get('PSI_ORACLE_LIB')         # (a sanitized build of the checker: tools/asan_full.sh)
+        if not alt:
+            build()
+        L = C.CDLL(alt or _LIB_PATH)
         L.orc_graph_new.restype = C.c_void_p
         L.orc_graph_new.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p,
                                     C.c_void_p, C.c_void_p]

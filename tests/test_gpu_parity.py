@@ -1159,6 +1159,100 @@ def test_traverser_from_prefix_walks_equals_traverser_from_loci(k, step):
         assert res[0][1] == res[1][1]
 
 
+def _load_make_ref_paths():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_ref_paths', os.path.join(GOLDEN, 'make_ref_paths.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_reference_paths_file_decides_the_on_path_hits(tmp_path):
+    """SURVEY 8(f) row 3, content-sensitive: an index made from a reference-written `<prefix>_paths`
+    (PathIndex::save_paths_set pathindex.hpp:315-332 -> PathSet::serialize pathset.hpp:260-274 -> Path::serialize
+    path_base.hpp:551-560) must answer seeds_on_paths -- the phase whose hit set DEPENDS on which paths and which trims
+    were parsed -- like the oracle over the same three trimmed paths (the sequences the reference asserts,
+    test_pathindex.cpp:166-168, 248-255), and leave the starting loci the brute-force definition leaves over them.
+    (i) the committed fixture (graph x, context 10, Reversed); (ii) a file with long paths (> 300 nodes: several
+    enc_vector samples), Forward direction; (iii) a graph whose ids DECREASE along the path (deltas wrap mod 2^64).
+    What stays unpinnable here: that a given sdsl release writes exactly this layout (no sdsl-written file exists in
+    the reference tree or this image)."""
+    import oracle
+    from oracle import brute
+    m = _load_make_ref_paths()
+    bg = brute.parse_gfa(os.path.join(REF, 'x.gfa'))
+    g = _graph('x.gfa')
+    reads = brute.read_seqs(os.path.join(REF, 'reads_n1000l100e0i0.seq'))[:400]
+    bases, off = psi_amd.pack_reads(reads)
+    k, step = 10, 3
+    rank = {v: i for i, v in enumerate(bg.ids)}
+    label_off = np.asarray(g.label_off, dtype=np.int64)
+    og = oracle.OracleGraph.from_brute(bg)
+
+    def on_path_oracle(px):
+        paths = [p.tolist() for p in px.paths()]
+        left = [int(label_off[p[0] + 1] - label_off[p[0]]) - h if h else 0 for p, (h, _) in zip(paths, px.trims())]
+        right = [t for _, t in px.trims()]
+        pidx = oracle.OraclePathIndex(og, paths, left=left, right=right)
+        e = np.zeros(0, np.uint64)
+        return oracle.sort_unique(oracle.seeds_all(og, pidx, bytes(bases), off, k, step, e, e, phases=1))
+
+    def check(px, mode):
+        f = psi_amd.SeedFinder(g, k, mode=mode)
+        f.set_path_index(px)
+        got = psi_amd.sort_unique(f.seeds_on_paths((bases, off), step=step))
+        f.close()
+        want = on_path_oracle(px)
+        assert _eq(got, want)
+        return got
+
+    # (i) the reference test's three trimmed paths
+    px = psi_amd.PathIndex.from_reference_paths(g, k, os.path.join(GOLDEN, 'ref_paths_x_trimmed.bin'))
+    ids = [[bg.ids[v] for v in p.tolist()] for p in px.paths()]
+    assert ids == [[205, 207, 209, 210], [187, 189, 191, 193, 194, 195, 197], [167, 168, 171, 172, 174]]
+    hits_i = check(px, os.environ.get('PSI_AMD_MODE', 'kmer-table'))
+    assert len(hits_i) > 0
+    ln, lo = px.loci
+    assert [(bg.ids[v], int(o)) for v, o in zip(ln.tolist(), lo.tolist())] == brute.uncovered_loci(bg, ids, k, px.trims())
+    # the same three paths UNTRIMMED are another index: more on-path hits -- the trims of the file matter
+    full = psi_amd.PathIndex.build_paths(g, k, [p.tolist() for p in px.paths()])
+    hits_full = check(full, os.environ.get('PSI_AMD_MODE', 'kmer-table'))
+    assert len(hits_full) > len(hits_i) and set(map(tuple, hits_i.tolist())) < set(map(tuple, hits_full.tolist()))
+    # (ii) long walks, Forward: written by the independent statement of the format, read back, queried
+    nl = m.x_node_lengths()
+    walks = psi_amd.PathIndex.build(g, k, 3, rng_seed=5, patched=True, context=13)
+    recs = []
+    for p, (h, t) in zip(walks.paths(), walks.trims()):
+        pid = [bg.ids[v] for v in p.tolist()]
+        recs.append((pid, nl[pid[0]] - h if h else 0, t))
+    assert max(len(r[0]) for r in recs) > 128
+    fn = str(tmp_path / 'long_paths')
+    open(fn, 'wb').write(m.paths_file(13, True, recs, nl))
+    py = psi_amd.PathIndex.from_reference_paths(g, k, fn)
+    assert py.ref_forward is True and py.trims() == walks.trims()
+    a, b = check(py, os.environ.get('PSI_AMD_MODE', 'kmer-table')), check(walks, os.environ.get('PSI_AMD_MODE', 'kmer-table'))
+    assert _eq(a, b) and len(a) > len(hits_i)
+    pl, po = py.loci
+    assert [(bg.ids[v], int(o)) for v, o in zip(pl.tolist(), po.tolist())] == \
+        brute.uncovered_loci(bg, [r[0] for r in recs], k, py.trims())
+    # (iii) ids that decrease along every path: graph x renumbered id -> 1000 - id
+    rev = {v: 1000 - v for v in bg.ids}
+    g2 = psi_amd.Graph.from_csr(np.array([rev[v] for v in bg.ids], dtype=np.uint64), g.label_off, g.labels, g.edge_off, g.edge_to,
+                                paths=[p for p in g.paths()])
+    recs2 = [([rev[v] for v in r[0]], r[1], r[2]) for r in recs]
+    fn2 = str(tmp_path / 'rev_paths')
+    open(fn2, 'wb').write(m.paths_file(13, False, recs2, {rev[v]: nl[v] for v in nl}))
+    pz = psi_amd.PathIndex.from_reference_paths(g2, k, fn2)
+    assert [p.tolist() for p in pz.paths()] == [p.tolist() for p in walks.paths()] and pz.trims() == walks.trims()
+    f = psi_amd.SeedFinder(g2, k)
+    f.set_path_index(pz)
+    c = psi_amd.sort_unique(f.seeds_on_paths((bases, off), step=step))
+    f.close()
+    back = b.copy()
+    back[:, 0] = np.uint64(1000) - back[:, 0]
+    assert _eq(c, psi_amd.sort_unique(back))
+
+
 def test_auto_query_mode_decides_by_expected_work():
     """PSIGPU_MODE_AUTO: a finder that expects one small chunk traverses (no tables made), one that expects many -- or
     does not know -- tabulates; same records either way (north_star: the traverser kernel and the tabulated default are

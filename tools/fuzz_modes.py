@@ -137,6 +137,14 @@ def main():
                         f.set_gocc_threshold(0)
                         if not (gg.shape == wg.shape and (gg == wg).all()):
                             print('GOCC MISMATCH', seed, k, step, npaths, patched, mode, cap, thr, gg.shape, wg.shape, flush=True)
+                            # who is it: the product or the checker?  both again -- the oracle on one thread too
+                            f.set_gocc_threshold(thr)
+                            g2 = psi_amd.sort_unique(f.seeds_all(reads, step=step))
+                            w2 = T._oracle_hits(arrays, f, rb, ro, k, step, gocc=thr)
+                            w1 = T._oracle_hits(arrays, f, rb, ro, k, step, gocc=thr, threads=1)
+                            print(' again: product', g2.shape, 'oracle', w2.shape, 'oracle on one thread', w1.shape,
+                                  '| first product run == second:', bool(gg.shape == g2.shape and (gg == g2).all()),
+                                  '| first oracle run == one-thread run:', bool(wg.shape == w1.shape and (wg == w1).all()), flush=True)
                             sys.exit(1)
                         n_cases += 1
                     if cap == 0:
