@@ -1274,7 +1274,10 @@ def test_auto_query_mode_decides_by_expected_work():
         assert f.query_mode() == want_mode, label
         res[label] = psi_amd.sort_unique(f.seeds_all((bases, off), step=k))
         c = f.counters()
-        assert (c['n_loci_traversed'] > 0) == (want_mode == 'traverse')
+        if want_mode == 'traverse':
+            assert c['n_loci_traversed'] == c['n_loci'] and c['n_locus_kmers'] == 0       # nothing about the loci tabulated
+        else:
+            assert c['n_locus_kmers'] > 0 and c['n_loci_traversed'] < c['n_loci']        # (a walk cap leaves some loci over)
         f.close()
     assert len(res['one']) > 2000 and _eq(res['one'], res['many']) and _eq(res['one'], res['unknown'])
 

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""The packed host entry (psigpu_find_seeds_packed: H2D of 2-bit reads + kernels + device sort-unique + D2H of 8-byte wire
+records, widened on the host) on the bench workload: median / min ms per 1 M-read chunk for several sub-batch sizes and
+wire formats, and one traced call (E2E_TRACE=1: per-sub-batch host timeline on stderr).  Needs a GPU."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import psi_amd
+from psi_amd import synth
+
+sg = synth.snv_graph(51_000_000, 1_100_000, n_block=11_000_000, seed=11)
+g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path])
+px = psi_amd.PathIndex.build(g, 21, 1, rng_seed=1, device=0)
+f = psi_amd.SeedFinder(g, 21, device=0)
+f.set_path_index(px)
+f.prepare()
+batches = [synth.sim_reads_snv(sg, 1_000_000, 150, seed=13 + 100 * b) for b in range(2)]
+packed = [psi_amd.PackedReads(b, o, pinned=True, threads=8) for b, o in batches]
+L = psi_amd.lib()
+hits = psi_amd.Hits()
+flags = psi_amd.ALL | psi_amd.SORT_UNIQUE
+calls = [(f.ctx, psi_amd._ptr(p.words), psi_amd._ptr(p.mask), psi_amd._ptr(p.off), 1_000_000, 21, 21, 0, flags, C.byref(hits)) for p in packed]
+out = []
+
+
+def run(label, reps=15):
+    for i in range(3):
+        assert L.psigpu_find_seeds_packed(*calls[i % 2]) == 0
+        L.psigpu_free_hits(C.byref(hits))
+    ts = []
+    for i in range(reps):
+        t = time.perf_counter()
+        assert L.psigpu_find_seeds_packed(*calls[i % 2]) == 0
+        n = hits.n
+        L.psigpu_free_hits(C.byref(hits))
+        ts.append((time.perf_counter() - t) * 1e3)
+    c = f.counters()
+    r = {'label': label, 'median_ms': float(np.median(ts)), 'min_ms': min(ts), 'max_ms': max(ts), 'hits': int(n),
+         'device_ms': float(c['ms_total']), 'wire': int(c['wire_bytes_per_hit'])}
+    out.append(r)
+    print(json.dumps(r), flush=True)
+
+
+for mb in (4, 8, 16, 32, 64, 160):
+    f.set_option('sub_bytes', mb << 20)
+    run('sub %d Mi bases' % mb)
+f.set_option('sub_bytes', 0)
+for w in (16, 32):
+    f.set_option('wire', w)
+    run('wire %d' % w)
+f.set_option('wire', 0)
+f.set_option('no_ahead', 1)
+run('two slots (no transfers queued ahead)')
+f.set_option('no_ahead', 0)
+if os.environ.get('E2E_TRACE'):
+    os.environ['PSIGPU_TRACE'] = '1'
+    L.psigpu_find_seeds_packed(*calls[0]); L.psigpu_free_hits(C.byref(hits))
+    del os.environ['PSIGPU_TRACE']
