@@ -306,6 +306,7 @@ def main():
     ap.add_argument('--cpu-reads', type=int, default=-1, help='reads in the CPU-baseline sample (0 = skip baseline and check)')
     ap.add_argument('--no-check', action='store_true', help='skip the comparison of the GPU hit set with the CPU sample')
     ap.add_argument('--lean', action='store_true', help='headline only: no other modes, no end-to-end, no CPU baseline (profiling runs)')
+    ap.add_argument('--general-reads', action='store_true', help='do not tell the library that all reads have one length')
     ap.add_argument('--wg', choices=('auto', 'force', 'off'), default='auto',
                     help='N > 1: the whole-genome workload of BASELINE.json configs[3] (auto: when the host has the memory)')
     ap.add_argument('--wg-backbone', type=int, default=0, help='(tests) backbone of the N > 1 graph instead of 3.1 Gbp')
@@ -410,12 +411,17 @@ def main():
             (time.time() - t0, t_ix, 'host' if args.host_build else 'device', t_prep, g.n_nodes, g.n_edges,
              px.text_len, px.view.n_loci))
 
+    # the synthetic reads all have --read-len bases: the caller says so (PSIGPU_UNIFORM_READS, checked on the device) as
+    # psikt does for a chunk of equal-length reads; --general-reads times the path that assumes nothing
+    uni = 0 if args.general_reads else psi_amd.UNIFORM_READS
     stream = torch.cuda.current_stream().cuda_stream
     rec_offset = rank * args.reads
     L = psi_amd.lib()
     dev = [(torch.from_numpy(b).cuda(), torch.from_numpy(o.astype(np.int64)).cuda(), len(b)) for b, o in batches]
 
-    def time_mode(f, steps, warmup, mode, sync_ranks, blocks=False):
+    def time_mode(f, steps, warmup, mode, sync_ranks, blocks=False, call_flags=None):
+        if call_flags is None:
+            call_flags = uni
         """K timed steps of the device-resident entry over the alternating batches; per-kernel times from
         the library's HIP events (recorded on the streams the kernels run on)."""
         # untimed: every k-walk from the starting loci (the unit SURVEY 8(d) prices the traverser by).
@@ -432,7 +438,7 @@ def main():
         d_hits, n_out = C.c_void_p(), C.c_uint64()
         # the timed loop goes through the C ABI with prebuilt arguments: the binding's conveniences
         # (argument objects, a dict of counters) cost tens of microseconds per call
-        calls = [(f.ctx, d[0].data_ptr(), d[1].data_ptr(), args.reads, d[2], k, step, rec_offset, psi_amd.ALL, stream,
+        calls = [(f.ctx, d[0].data_ptr(), d[1].data_ptr(), args.reads, d[2], k, step, rec_offset, psi_amd.ALL | call_flags, stream,
                   C.byref(d_hits), C.byref(n_out)) for d in dev]
         for i in range(warmup):
             if L.psigpu_find_seeds_device(*calls[i % nb]):
@@ -680,7 +686,7 @@ def main():
             pr = psi_amd.PackedReads(batches[0][0], batches[0][1], pinned=True, threads=4)
             hh = psi_amd.Hits()
             call = (finder.ctx, psi_amd._ptr(pr.words), psi_amd._ptr(pr.mask), psi_amd._ptr(pr.off), args.reads, k, step, rec_offset,
-                    psi_amd.ALL | psi_amd.SORT_UNIQUE, C.byref(hh))
+                    psi_amd.ALL | psi_amd.SORT_UNIQUE | uni, C.byref(hh))
             if L.psigpu_find_seeds_packed(*call):                 # warm: pinned pool, slot buffers
                 raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
             n_rec = hh.n
@@ -766,6 +772,7 @@ def main():
                 'index_build_s': t_ix, 'index_built_on': 'host' if args.host_build else 'device',
                 'seeds_per_step_per_gpu': int(c['n_seeds']), 'hits_per_step_per_gpu': int(c['n_hits']),
                 'hits_on_path': int(c['n_hits_on_path']), 'hits_off_path': int(c['n_hits_off_path']),
+                'uniform_reads_flag': not args.general_reads,
                 'query_mode': args.mode, 'locus_kmers': int(c['n_locus_kmers']), 'path_kmers': int(c['n_path_kmers']),
                 'table_build_ms': float(c['ms_locus_table_build']), 'prepare_wall_s': t_prep,
                 'loci_traversed_per_step': int(c['n_loci_traversed']),
@@ -838,12 +845,12 @@ def main():
         t1 = time.perf_counter()
         psi_amd.PackedReads(batches[0][0], batches[0][1], pinned=False, threads=1)
         t_pack1 = time.perf_counter() - t1
-        t_pk, n_pk, t_pk_min, t_pk_max = host_entry_packed(packed_src, psi_amd.ALL | psi_amd.SORT_UNIQUE, 20)
+        t_pk, n_pk, t_pk_min, t_pk_max = host_entry_packed(packed_src, psi_amd.ALL | psi_amd.SORT_UNIQUE | uni, 20)
         c_e = finder.counters()
-        t_su, n_su = host_entry(pinned_src, psi_amd.ALL | psi_amd.SORT_UNIQUE, 10)
+        t_su, n_su = host_entry(pinned_src, psi_amd.ALL | psi_amd.SORT_UNIQUE | uni, 10)
         c_a = finder.counters()
-        t_raw, n_raw = host_entry(pinned_src, psi_amd.ALL, 10)
-        t_pg, _ = host_entry(pageable_src, psi_amd.ALL | psi_amd.SORT_UNIQUE, 6)
+        t_raw, n_raw = host_entry(pinned_src, psi_amd.ALL | uni, 10)
+        t_pg, _ = host_entry(pageable_src, psi_amd.ALL | psi_amd.SORT_UNIQUE | uni, 6)
         pr0 = packed_src[0]
         bytes_in = float(pr0.words.nbytes + (pr0.mask.nbytes if pr0.mask is not None else 0) + 8 * (args.reads + 1))
         bytes_out = float(c_e['wire_bytes_per_hit'] or 32) * n_pk       # (8-byte wire records, widened on the host)
@@ -877,6 +884,11 @@ def main():
         }
         out['host_entry_ms_per_step'] = t_pk * 1e3
 
+        # ---- the same steps without the equal-length claim (reads of any lengths: scan + search for a seed's read) --------
+        if uni:
+            res_g = time_mode(finder, 10, 3, args.mode, False, call_flags=0)
+            out['general_reads_path'] = {'ms_per_step': res_g['elapsed'] / res_g['steps'] * 1e3, 'seeds_per_s': res_g['seeds'] / res_g['elapsed'],
+                                         'what': 'the same steps without PSIGPU_UNIFORM_READS'}
         # ---- second series: 1 % substitution errors ------------------------------------
         eb, eo = synth.sim_reads_snv(sg, args.reads, args.read_len, seed=13 + rank, sub_rate=0.01)
         d_eb, d_eo = torch.from_numpy(eb).cuda(), torch.from_numpy(eo.astype(np.int64)).cuda()

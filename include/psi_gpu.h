@@ -357,6 +357,12 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k);
                                    done on the device: the hits of each seed ordered in place when
                                    they come out seed by seed, else 64-bit packed keys + radix sort */
 
+#define PSIGPU_UNIFORM_READS 8u /* the caller knows that every read of the chunk has the same length (read_off[i] = i * L):
+                                   a seed's read and offset then follow from its number -- no scan over the reads' seed
+                                   counts, no search for a seed's read.  The claim is CHECKED on the device while the seeds
+                                   are packed; a chunk for which it does not hold is answered again the general way (same
+                                   records, a little later).  psi::Records sets it for chunks of equal-length reads. */
+
 /* One chunk of psikt's loop: get_seeds + index_reads + seeds_all (src/psikt.cpp:195-204).
  * `bases`/`read_off` are HOST buffers (read i = bases[read_off[i] .. read_off[i+1])),
  * `step` is psikt's -d (0 = k), `rec_offset` the number of reads consumed before this

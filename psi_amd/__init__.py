@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PSI_AMD_LIB') or os.path.join(_HERE, 'libpsi_gpu.so')   # env: experiment builds
 
-ALL, ON_PATHS, OFF_PATHS, SORT_UNIQUE = 3, 1, 2, 4
+ALL, ON_PATHS, OFF_PATHS, SORT_UNIQUE, UNIFORM_READS = 3, 1, 2, 4, 8
 MAX_SEED_LEN = 63
 TUNE_NO_DIRECT, TUNE_NO_VERIFY, TUNE_NO_ROWRECS, TUNE_NO_PATH_TABLE = 1, 2, 4, 8
 
@@ -647,8 +647,9 @@ class SeedFinder:
         lib().psigpu_free_hits(C.byref(out))
         return arr
 
-    def seeds_all(self, reads, step: int = 0, rec_offset: int = 0, sort_unique: bool = False):
-        return self._find(reads, step, rec_offset, ALL | (SORT_UNIQUE if sort_unique else 0))
+    def seeds_all(self, reads, step: int = 0, rec_offset: int = 0, sort_unique: bool = False, uniform: bool = False):
+        """`uniform`: PSIGPU_UNIFORM_READS -- the caller says all reads have one length (checked on the device)."""
+        return self._find(reads, step, rec_offset, ALL | (SORT_UNIQUE if sort_unique else 0) | (UNIFORM_READS if uniform else 0))
 
     def seeds_all_packed(self, pr: 'PackedReads', step: int = 0, rec_offset: int = 0, sort_unique: bool = False,
                          flags: int = ALL, read_range: Optional[Tuple[int, int]] = None) -> np.ndarray:

@@ -146,6 +146,7 @@ struct DevCounters {
   PaddedCounter n_seeds_true;    // the scan's seed count (comes back to the host with the counters)
   StripedCounter max_read_len;   // longest read of the chunk, a running maximum per stripe (the hit sorter sizes its key fields with it)
   PaddedCounter not_grouped;     // sort-unique asked for: set when ordering each seed's hits in place was not enough
+  PaddedCounter not_uniform;     // PSIGPU_UNIFORM_READS was claimed and a read of the chunk has another length
   PaddedCounter serial;          // the call's serial number, stored by the kernel that zeroes the counters: what comes back to the
                                  // host must carry the serial of THIS call (a stale hand-back is detected, not believed)
   PaddedCounter dbg0, dbg1;      // diagnostics (builds with -DTRAV_STATS)
@@ -488,6 +489,24 @@ k_seed_scan_final(const uint64_t* __restrict__ read_off, uint64_t n, uint32_t k,
   }
 }
 
+// PSIGPU_UNIFORM_READS: every read has the same length, so a seed's read and offset follow from its number -- no scan of
+// the reads' seed counts, no per-seed search for the owning read.  The first kernel of such a call: the counters zeroed,
+// the call's serial number, the seed count and the longest read where the scan kernels would have left them.
+__global__ void __launch_bounds__(256)
+k_seed_init_uniform(DevCounters* __restrict__ ctr, unsigned long long serial, uint64_t* __restrict__ params, uint64_t n_seeds,
+                    uint64_t read_len)
+{
+  uint4* z = reinterpret_cast<uint4*>(ctr);
+  for (uint32_t i = threadIdx.x; i < sizeof(DevCounters) / 16; i += 256) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i == offsetof(DevCounters, serial) / 16) v = make_uint4((uint32_t)serial, (uint32_t)(serial >> 32), 0, 0);
+    if (i == offsetof(DevCounters, n_seeds_true) / 16) v = make_uint4((uint32_t)n_seeds, (uint32_t)(n_seeds >> 32), 0, 0);
+    if (i == offsetof(DevCounters, max_read_len) / 16) v = make_uint4((uint32_t)read_len, (uint32_t)(read_len >> 32), 0, 0);
+    z[i] = v;
+  }
+  if (threadIdx.x == 0) { params[0] = n_seeds; params[1] = 0; }
+}
+
 // ASCII base -> 2-bit code (A 0, C 1, G 2, T 3, either case), -1 for anything else; branch-free
 __device__ __forceinline__ int base2(char ch)
 {
@@ -535,23 +554,37 @@ constexpr int SP = 1;        // seeds a thread works on at a time (more were mea
 // the word array, `pk.bias2` / `pk.biasm` what to add to a base index of the call (read_off[r] + offset) to get its index
 // in the word / mask buffers as they lie on the device (a sub-batch is transferred from a word boundary).
 struct PackedIn { const uint64_t* mask; uint64_t bias2, biasm; };
+// UNIFORM (PSIGPU_UNIFORM_READS): uni_len = the length every read is said to have, uni_spr = seeds per read; the owning
+// read of seed s is s / uni_spr, and the claim is CHECKED for that read (a flag in the counters: the host then answers the
+// chunk again the general way).
+struct UniformIn { uint32_t len, spr; };
 
-template <bool WIDE, bool PACKED = false>
+template <bool WIDE, bool PACKED = false, bool UNIFORM = false>
 __global__ void __launch_bounds__(256)
 k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_off,
             const uint64_t* __restrict__ seed_off, uint64_t n_reads, const uint64_t* __restrict__ params,
             uint64_t seeds_cap, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t* __restrict__ seed_key, uint2* __restrict__ seed_info,
-            DevCounters* ctr, u128* __restrict__ seed_wide, uint32_t* __restrict__ seed_pfx, uint32_t pfx_len, PackedIn pk = PackedIn{ nullptr, 0, 0 })
+            DevCounters* ctr, u128* __restrict__ seed_wide, uint32_t* __restrict__ seed_pfx, uint32_t pfx_len, PackedIn pk = PackedIn{ nullptr, 0, 0 },
+            UniformIn un = UniformIn{ 0, 0 })
 {
   typedef typename std::conditional<WIDE, u128, uint64_t>::type KEY;
   constexpr uint32_t NW = WIDE ? 8 : 4;
   uint32_t nok = 0;
+  // (UNIFORM: the seed count is the launch's own -- params[0] is written by a kernel in front of this one all the same)
   const uint64_t n_seeds = min(params[0], seeds_cap), ratio = params[1];
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint32_t nw = (k + 7) >> 3;               // 64-bit loads per seed (at most 4; 8 for two-word seeds)
   for (uint64_t s0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s0 < n_seeds; s0 += stride * SP) {
     uint64_t lo[SP], so0[SP], so1[SP], ro[SP];
     bool in[SP];
+    if constexpr (UNIFORM) {
+      static_assert(SP == 1, "one seed per thread");
+      const uint32_t r = (uint32_t)s0 / un.spr;              // (n_seeds < 2^32)
+      in[0] = true; lo[0] = r; so0[0] = (uint64_t)r * un.spr; so1[0] = so0[0] + un.spr;
+      ro[0] = (uint64_t)r * un.len;
+      // the claim, checked where it is used: this read starts and ends where equal lengths put it
+      if (read_off[r] != ro[0] || read_off[r + 1] != ro[0] + un.len) ctr->not_uniform.v = 1ull;
+    } else {
 #pragma unroll
     for (int j = 0; j < SP; ++j) {
       const uint64_t s = s0 + (uint64_t)j * stride;
@@ -583,6 +616,7 @@ k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
         }
         lo[j] = l; so0[j] = seed_off[l]; ro[j] = read_off[l];
       }
+    }
     }
     uint64_t x[SP][NW];
     uint64_t st[SP];
@@ -3005,6 +3039,7 @@ struct psigpu_ctx {
   bool auto_mode = false, auto_resolved = false;
   uint32_t wire_used = 0;          // bytes per wire record the last run_pipeline call left in its wire buffer (0: none)
   unsigned long long serial = 0;   // run_pipeline calls so far: every call's counter block carries its number
+  uint64_t uniform_refuted = 0;    // calls that claimed PSIGPU_UNIFORM_READS for reads that were not (answered again the general way)
   uint64_t stale_handbacks = 0;    // counter blocks that came back with another call's number (psigpu_counters.stale_handbacks)
   bool wire8_overflowed = false;   // a sub-batch's records did not fit 8 bytes: the context stays with 16 from then on
 };
@@ -4186,7 +4221,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   // PSIGPU_SORT_UNIQUE here: the caller will sort -- when the hits come out seed by seed, order each seed's
   // hits in place before the counters go back, so that the answer to "was that enough?" comes with them
   const bool want_sorted = (flags & PSIGPU_SORT_UNIQUE) != 0;
-  flags &= ~PSIGPU_SORT_UNIQUE;
+  const uint32_t flags_in = flags;
+  flags &= ~(PSIGPU_SORT_UNIQUE | PSIGPU_UNIFORM_READS);
   ctx->grouped_state = 0;
   if (step == 0) step = k;                       // src/psikt.cpp:469
   if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..63)"; return PSIGPU_ERR_ARG; }
@@ -4307,6 +4343,17 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   }
 
   // ---- K0: seeds ---------------------------------------------------------------------
+  // PSIGPU_UNIFORM_READS: equal read lengths, claimed by the caller and checked by the packer
+  UniformIn un{ 0, 0 };
+  if ((flags_in & PSIGPU_UNIFORM_READS) && n_reads && !wide && n_bases % n_reads == 0 && n_bases / n_reads >= k &&
+      n_bases / n_reads < (1ull << 31)) {
+    un.len = (uint32_t)(n_bases / n_reads);
+    un.spr = (un.len - k) / step + 1;
+  }
+  const bool uniform = un.spr != 0;
+  if (uniform) {
+    k_seed_init_uniform<<<1, 256, 0, stream>>>(ctr, ++ctx->serial, ctx->w_total.as<uint64_t>(), n_reads * (uint64_t)un.spr, un.len);
+  } else
   if (n_reads) {
     uint64_t n_tiles = n_reads / SCAN_TILE + 1;     // covers index n_reads too
     HIPCHK(ctx, ctx->w_tiles.ensure(n_tiles * 8));
@@ -4332,7 +4379,15 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   }
   if (n_seeds) {
     const unsigned pgrid = (unsigned)std::min<uint64_t>((n_seeds + 256 * SP - 1) / (256 * SP), 256 * 32);
-    if (wide && packed)
+    if (uniform && packed)
+      k_seed_pack<false, true, true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, nullptr, n_reads, d_params, n_seeds, n_bases,
+                                                                k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
+                                                                nullptr, nullptr, 0, *packed, un);
+    else if (uniform)
+      k_seed_pack<false, false, true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, nullptr, n_reads, d_params, n_seeds, n_bases,
+                                                                 k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
+                                                                 nullptr, nullptr, 0, PackedIn{ nullptr, 0, 0 }, un);
+    else if (wide && packed)
       k_seed_pack<true, true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases,
                                                          k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
                                                          ctx->w_seed_wide.as<u128>(), ctx->w_seed_pfx.as<uint32_t>(), pfx_len, *packed);
@@ -4732,6 +4787,12 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
       if (getenv("PSIGPU_TRACE")) fprintf(stderr, "[psigpu] stale counter hand-back: serial %llu, expected %llu\n", h.serial.v, ctx->serial);
       HIPCHK(ctx, hipMemcpy(&h, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost));
       if (h.serial.v != ctx->serial) { ctx->err = "the counters of the call did not come back from the device"; return PSIGPU_ERR_DEVICE; }
+    }
+    if (uniform && h.not_uniform.v) {
+      // the reads are not all of one length after all: the whole call again, the general way
+      ++ctx->uniform_refuted;
+      return run_pipeline(ctx, d_bases, d_read_off, n_reads, n_bases, k, step, rec_offset, flags_in & ~PSIGPU_UNIFORM_READS, stream,
+                          n_hits_out, wire, packed, wfmt);
     }
     ctx->grouped_state = fix_groups ? (h.not_grouped.v ? 2 : 1) : 0;
     true_seeds = h.n_seeds_true.v;

@@ -243,7 +243,7 @@ namespace psi {
         /* a range of the packed chunk: the word arrays as they are, the range's own offsets (read_off[0] != 0) */
         check( psigpu_find_seeds_packed( ctx, c.packed.data(), c.n_not_acgt ? c.not_acgt.data() : nullptr, c.offsets.data() + begin,
                                          end - begin, seeds.seed_len, seeds.distance, c.get_record_offset() + begin,
-                                         PSIGPU_ALL | PSIGPU_SORT_UNIQUE, &hits ) );
+                                         PSIGPU_ALL | PSIGPU_SORT_UNIQUE | ( c.uniform() ? PSIGPU_UNIFORM_READS : 0u ), &hits ) );
         return hits;
       }
       std::vector< std::uint64_t > off( end - begin + 1 );
@@ -323,10 +323,12 @@ namespace psi {
       psigpu_hits hits{};
       if ( c.is_packed )      /* readRecords packed the chunk: a quarter of the bytes on the host link */
         check( psigpu_find_seeds_packed( ctx, c.packed.data(), c.n_not_acgt ? c.not_acgt.data() : nullptr, c.offsets.data(), c.size(),
-                                         seeds.seed_len, seeds.distance, c.get_record_offset(), flags | PSIGPU_SORT_UNIQUE, &hits ) );
+                                         seeds.seed_len, seeds.distance, c.get_record_offset(),
+                                         flags | PSIGPU_SORT_UNIQUE | ( c.uniform() ? PSIGPU_UNIFORM_READS : 0u ), &hits ) );
       else
       check( psigpu_find_seeds( ctx, c.bases.data(), c.offsets.data(), c.size(), seeds.seed_len,
-                                seeds.distance, c.get_record_offset(), flags | PSIGPU_SORT_UNIQUE, &hits ) );
+                                seeds.distance, c.get_record_offset(),
+                                flags | PSIGPU_SORT_UNIQUE | ( c.uniform() ? PSIGPU_UNIFORM_READS : 0u ), &hits ) );
       return hits;
     }
 

@@ -146,22 +146,25 @@ namespace psi {
     void clear() { name.clear(); bases.clear(); offsets.assign( 1, 0 ); rec_offset = 0; is_packed = false; n_not_acgt = 0; }
     void push_back( std::string const& n, std::string const& s )
     {
-      name.push_back( n );
-      bases += s;
-      offsets.push_back( bases.size() );
-      is_packed = false;
+      push_back( n.data(), n.size(), s.data(), s.size() );
     }
     void push_back( char const* n, std::size_t nlen, char const* s, std::size_t slen )
     {
+      if ( offsets.size() == 1 ) { first_len = slen; same_len = true; }
+      else if ( slen != first_len ) same_len = false;
       name.emplace_back( n, nlen );
       bases.append( s, slen );
       offsets.push_back( bases.size() );
       is_packed = false;
     }
+    /** every read of the chunk has the same length (PSIGPU_UNIFORM_READS: the device then skips the scan over the reads) */
+    bool uniform() const { return size() != 0 && same_len; }
     std::string operator[]( std::size_t i ) const
     { return bases.substr( offsets[ i ], offsets[ i + 1 ] - offsets[ i ] ); }
   private:
     std::uint64_t rec_offset = 0;
+    std::size_t first_len = 0;
+    bool same_len = false;
   };
 
   /** Sequence input stream: counts the records handed out so far (kseq++'s `counts()`).

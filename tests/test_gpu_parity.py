@@ -1366,6 +1366,46 @@ def test_packed_reads_equal_ascii(k, step, pinned):
     f.close()
 
 
+@pytest.mark.parametrize('k,step', [(21, 21), (12, 5), (31, 1)])
+def test_uniform_reads_flag(k, step):
+    """PSIGPU_UNIFORM_READS: with reads of one length a seed's read and offset follow from its number (no scan of the reads'
+    seed counts); the claim is checked on the device, and a chunk for which it is false -- one read a base shorter, a
+    ragged chunk, an empty read -- is answered again the general way: same records either way, through the device entry,
+    the host entry (ASCII and packed, one piece and many sub-batches)."""
+    import torch
+    g, reads = _x_case()
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(2, rng_seed=3)
+    equal = [r[:90] for r in reads[:500] if len(r) >= 90]
+    equal[7] = equal[7][:40] + 'N' + equal[7][41:]
+    almost = list(equal); almost[250] = almost[250][:-1]
+    ragged = _ragged_reads(reads[:200], k)
+    for name, rs, holds in (('equal', equal, True), ('almost', almost, False), ('ragged', ragged, False)):
+        bases, off = psi_amd.pack_reads(rs)
+        want = f.seeds_all((bases, off), step=step, rec_offset=3, sort_unique=True)
+        c0 = f.counters()
+        assert len(want)
+        for sub in (1 << 30, 700):
+            f.set_option('sub_bytes', sub)
+            assert _eq(f.seeds_all((bases, off), step=step, rec_offset=3, sort_unique=True, uniform=True), want), (name, sub)
+            c = f.counters()
+            assert c['n_seeds'] == c0['n_seeds'] and c['n_seeds_valid'] == c0['n_seeds_valid']
+            pr = psi_amd.PackedReads(bases, off, pinned=True)
+            assert _eq(f.seeds_all_packed(pr, step=step, rec_offset=3, sort_unique=True, flags=psi_amd.ALL | psi_amd.UNIFORM_READS), want), (name, sub)
+        d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        ptr, n = f.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, rec_offset=3,
+                                    flags=psi_amd.ALL | psi_amd.SORT_UNIQUE | psi_amd.UNIFORM_READS)
+        assert _eq(f.copy_hits(ptr, n), want), name
+        f.set_option('sub_bytes', 0)
+    # traverse mode as well (the chunk's seed table is built from the same seeds)
+    f2 = psi_amd.SeedFinder(g, k, mode='traverse')
+    f2.set_path_index(f.pindex)
+    bases, off = psi_amd.pack_reads(equal)
+    assert _eq(f2.seeds_all((bases, off), step=step, sort_unique=True, uniform=True), f.seeds_all((bases, off), step=step, sort_unique=True))
+    f2.close()
+    f.close()
+
+
 def test_packed_device_entry_equals_ascii():
     """psigpu_find_seeds_device_packed: the device-resident chunk as 2-bit words."""
     import torch
