@@ -334,6 +334,7 @@ int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags);
  *                     nothing narrower than that
  *   "expected_calls"  PSIGPU_MODE_AUTO: how many chunks this finder will be asked (0 = unknown: assume many)
  *   "expected_seeds"  PSIGPU_MODE_AUTO: ... and how many seeds over all of them (0 = unknown)
+ *   "res16"           1: the k-mer table probe leaves 16 bytes of results per seed for the emit kernel (rounds 1-3) instead of 8
  *   "no_pfx_roots"    1: the query-time traverser starts from the starting loci themselves (TraverserBFS as written,
  *                     traverser_bfs.hpp:72-161) instead of from their tabulated 12-base prefix walks */
 int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value);

@@ -1684,6 +1684,27 @@ __global__ void k_kt_direct_off(const uint64_t* __restrict__ okeys, const uint32
 // The whole of K1 in this mode: one probe per seed -- one 16-byte load -- over the wave ranges of
 // K2.  Leaves 16 bytes per seed for K2: (a, b) of the slot, the number of on-path occurrences and
 // of loci that are wanted (phase flags, gocc threshold), and whether they are the inline position.
+//
+// R8 (round 4): 8 bytes of results per seed instead of 16 -- [ext flag | locus flag | on-path flag | offset (28 bits) | node rank
+// or record number (32 bits)]: the probe shares the load path with its own result stream, and nearly every seed is answered
+// from its slot (one position, inline).  A seed answered by a 32-byte record hands on the record's number only; the emit
+// kernel reads the record anyway and applies the phase flags and the threshold again.  Graphs with a node of 2^28 bases or
+// more keep the 16-byte form (option "res16": always).
+constexpr uint64_t R8_ON = 1ull << 60, R8_OFF = 1ull << 61, R8_EXT = 1ull << 62;
+constexpr uint32_t R8_NOFF_BITS = 28;
+
+// counts of a k-mer's 32-byte record under the call's phase flags and threshold: (on-path occurrences emitted, loci emitted)
+__device__ __forceinline__ uint2 ext_counts(const uint4 e /* off_a, off_b, on_cnt, off_cnt */, bool want_on, bool want_off, uint32_t gocc_thr)
+{
+  const uint32_t c_on = e.z & ~KT_INLINE;
+  const bool on_emitted = want_on && c_on <= gocc_thr;
+  uint2 r = make_uint2(on_emitted ? min(c_on, RES_CNT) : 0u, 0u);
+  // loci at an on-path position are left out when the on-path occurrences are emitted
+  if (want_off) r.y = (e.w & KT_INLINE) ? ((on_emitted && (e.w & KT_OFFDUP)) ? 0u : 1u) : (on_emitted ? e.y : e.w);
+  return r;
+}
+
+template <bool R8>
 __global__ void __launch_bounds__(256)
 k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
              uint64_t seeds_cap, uint32_t per_wave, bool want_on, bool want_off, uint32_t gocc_thr,
@@ -1713,11 +1734,9 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
           res.x = v.z; res.y = v.w;
           if (type == K16_EXT) {
             const uint4 e = reinterpret_cast<const uint4*>(kt.ext + v.z)[1];      // off_a, off_b, on_cnt, off_cnt
-            const uint32_t c_on = e.z & ~KT_INLINE;
-            const bool on_emitted = want_on && c_on <= gocc_thr;
-            res.z = RES_EXT | (on_emitted ? min(c_on, RES_CNT) : 0u);
-            // loci at an on-path position are left out when the on-path occurrences are emitted
-            if (want_off) res.w = (e.w & KT_INLINE) ? ((on_emitted && (e.w & KT_OFFDUP)) ? 0u : 1u) : (on_emitted ? e.y : e.w);
+            const uint2 cc = ext_counts(e, want_on, want_off, gocc_thr);
+            res.z = RES_EXT | cc.x;
+            res.w = cc.y;
           } else {
             if (want_on && type != K16_OFF1) res.z = 1u | RES_INLINE;
             // (one occurrence and one locus at the same position, both phases asked for: one hit)
@@ -1729,6 +1748,12 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
         h = kt_next(h, t, kt.n_slots);
       }
     }
+    if constexpr (R8) {
+      uint64_t r8 = (uint64_t)res.x;
+      if (res.z & RES_EXT) r8 |= R8_EXT;
+      else r8 |= ((uint64_t)res.y << 32) | ((res.z & RES_CNT) ? R8_ON : 0ull) | ((res.w & ~RES_INLINE) ? R8_OFF : 0ull);
+      reinterpret_cast<uint64_t*>(seed_res)[seed] = r8;
+    } else
     seed_res[seed] = res;
     const uint32_t con = res.z & RES_CNT, coff = res.w & ~RES_INLINE;
     wsum += con; osum += coff;
@@ -2236,12 +2261,13 @@ k_fm_locate_direct(MapView mv, SeedOut so, bool have_off, const LocusEnt* __rest
 // out to the lanes otherwise.
 constexpr int EMIT_G = 2;
 
+template <bool R8>
 __global__ void __launch_bounds__(256)
 k_kmer_emit(MapView mv, const uint4* __restrict__ seed_res, const KmerSlot* __restrict__ ext,
             const LocusEnt* __restrict__ ent, const uint64_t* __restrict__ wave_total,
             const uint64_t* __restrict__ wave_total_off, const uint64_t* __restrict__ params,
             uint64_t seeds_cap, uint32_t per_wave, const uint2* __restrict__ seed_info, uint64_t rec_offset,
-            psigpu_hit* __restrict__ hits, uint64_t cap, DevCounters* ctr)
+            psigpu_hit* __restrict__ hits, uint64_t cap, DevCounters* ctr, bool want_on, bool want_off, uint32_t gocc_thr)
 {
   const uint32_t lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -2284,7 +2310,16 @@ k_kmer_emit(MapView mv, const uint4* __restrict__ seed_res, const KmerSlot* __re
     for (int g = 0; g < EMIT_G; ++g) {
       const uint64_t item = base + (uint64_t)g * 64 + lane;
       rr[g] = make_uint4(0, 0, 0, 0); ss[g] = make_uint2(0, 0);
-      if (item < s1) { rr[g] = seed_res[item]; ss[g] = seed_info[item]; }
+      if (item < s1) {
+        if constexpr (R8) {
+          const uint64_t r8 = reinterpret_cast<const uint64_t*>(seed_res)[item];
+          // (the 16-byte form of the same answer; a record's counts are taken from the record below)
+          rr[g] = (r8 & R8_EXT) ? make_uint4((uint32_t)r8, 0u, RES_EXT, 0u)
+                                : make_uint4((uint32_t)r8, (uint32_t)(r8 >> 32) & ((1u << R8_NOFF_BITS) - 1u),
+                                             (r8 & R8_ON) ? (1u | RES_INLINE) : 0u, (r8 & R8_OFF) ? (1u | RES_INLINE) : 0u);
+        } else rr[g] = seed_res[item];
+        ss[g] = seed_info[item];
+      }
     }
 #pragma unroll
     for (int g = 0; g < EMIT_G; ++g) {
@@ -2292,11 +2327,12 @@ k_kmer_emit(MapView mv, const uint4* __restrict__ seed_res, const KmerSlot* __re
       const uint2 si = ss[g];
       SeedHits sh = { 0, 0, 0, 0, 0, 0, 0, 0 };
       sh.con = r.z & RES_CNT;
-      const uint32_t coff = r.w & ~RES_INLINE;
+      uint32_t coff = r.w & ~RES_INLINE;
       if (r.z & RES_EXT) {
-        if (sh.con | coff) {
+        if (R8 || (sh.con | coff)) {
           const uint4* e = reinterpret_cast<const uint4*>(ext + r.x);
           const uint4 e0 = e[0], e1 = e[1];               // key, on_a, on_b | off_a, off_b, on_cnt, off_cnt
+          if constexpr (R8) { const uint2 cc = ext_counts(e1, want_on, want_off, gocc_thr); sh.con = cc.x; coff = cc.y; }
           if (sh.con) {
             if (e1.z & KT_INLINE) { sh.on_node = e0.z; sh.on_noff = e0.w; sh.aux = AUX_RESOLVED; }
             else { sh.lo = e0.z; sh.aux = AUX_ONPOS; }
@@ -3034,6 +3070,7 @@ struct psigpu_ctx {
   uint32_t opt_wire = 0;           // 0: the narrowest wire record that fits; 8 / 16 / 32: nothing narrower
   uint32_t opt_wire8_roff_cap = 0; // test hook: at most this many read-offset bits in an 8-byte record
   bool opt_no_pfx_roots = false;   // traverse mode from the loci themselves (A/B, tests)
+  bool opt_res16 = false;          // 16 bytes of probe results per seed (A/B, tests)
   uint64_t opt_expected_calls = 0; // PSIGPU_MODE_AUTO: chunks the caller expects to ask (0: unknown)
   uint64_t opt_expected_seeds = 0; // ... and seeds over all of them
   bool auto_mode = false, auto_resolved = false;
@@ -3378,6 +3415,7 @@ int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value)
     if (value != 0 && value != 8 && value != 16 && value != 32) { ctx->err = "wire: 0, 8, 16 or 32"; return PSIGPU_ERR_ARG; }
     ctx->opt_wire = (uint32_t)value;
   } else if (n == "no_pfx_roots") ctx->opt_no_pfx_roots = value != 0;
+  else if (n == "res16") ctx->opt_res16 = value != 0;
   else if (n == "expected_calls") { ctx->opt_expected_calls = value; ctx->auto_resolved = false; }
   else if (n == "expected_seeds") { ctx->opt_expected_seeds = value; ctx->auto_resolved = false; }
   else if (n == "wire8_roff_bits") { ctx->opt_wire8_roff_cap = (uint32_t)value; ctx->wire8_overflowed = false; }      // (test hook)
@@ -4445,6 +4483,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   tb.pfx12 = (use_pfx12 && !no_pfx) ? ctx->w_pfx12.as<uint32_t>() : nullptr;
   tb.pfx_bits = (need_table && !no_pfx) ? ctx->w_pfx.as<uint32_t>() : nullptr; tb.pfx_len = pfx_len;
   const bool kprobe = use_kt && n_seeds;               // k-mer table: the seed's interval and its loci in one probe
+  static const bool env_res16 = getenv("PSIGPU_RES16") != nullptr;
+  const bool res8 = kprobe && !env_res16 && !ctx->opt_res16 && ctx->max_node_len < (1ull << R8_NOFF_BITS);      // 8 bytes of probe results per seed
   const bool on_paths = (flags & PSIGPU_ON_PATHS) && ctx->n_paths && n_seeds && !kprobe;   // FM index (K1)
   const bool off_paths = need_table && n_seeds;        // query-time traverser
   const bool probe = use_lkt && n_seeds && !kprobe;    // locus k-mer table (16-byte slots) beside the FM index
@@ -4589,7 +4629,12 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         const uint32_t thr_k1 = combine ? 0xFFFFFFFFu : thr;
         if (kprobe) {
           KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
-          k_kmer_probe<<<grid, 256, 0, stream>>>(kt, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave,
+          if (res8)
+            k_kmer_probe<true><<<grid, 256, 0, stream>>>(kt, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave,
+                                                         (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr, ctx->w_seedres.as<uint4>(),
+                                                         ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), ctr);
+          else
+          k_kmer_probe<false><<<grid, 256, 0, stream>>>(kt, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave,
                                                  (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr, ctx->w_seedres.as<uint4>(),
                                                  ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), ctr);
           probed = true;
@@ -4648,9 +4693,17 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
       const LocusEnt* oe = (probe || kprobe) ? ctx->lkt_ent.as<LocusEnt>() : nullptr;
       if (kprobe) {
         const FMView fm0 = fm_view(ctx->p0());
-        k_kmer_emit<<<grid, 256, 0, stream>>>(map_view(ctx->p0(), fm0), ctx->w_seedres.as<uint4>(), ctx->kt_ext.as<KmerSlot>(), oe,
+        const uint32_t thr_e = ctx->gocc_thr ? ctx->gocc_thr : 0xFFFFFFFFu;
+        if (res8)
+          k_kmer_emit<true><<<grid, 256, 0, stream>>>(map_view(ctx->p0(), fm0), ctx->w_seedres.as<uint4>(), ctx->kt_ext.as<KmerSlot>(), oe,
+                                                      ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), d_params,
+                                                      n_seeds, per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap, ctr,
+                                                      (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr_e);
+        else
+        k_kmer_emit<false><<<grid, 256, 0, stream>>>(map_view(ctx->p0(), fm0), ctx->w_seedres.as<uint4>(), ctx->kt_ext.as<KmerSlot>(), oe,
                                               ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), d_params,
-                                              n_seeds, per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap, ctr);
+                                              n_seeds, per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap, ctr,
+                                              (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr_e);
       } else {
         if (ctx->sa_rate != 1) {
           HIPCHK(ctx, ctx->w_hit_a.ensure((cap + 1) * 8));

@@ -1406,6 +1406,29 @@ def test_uniform_reads_flag(k, step):
     f.close()
 
 
+@pytest.mark.parametrize('query_mode', ['kmer-table', 'kmer-table-cap1'], indirect=True)
+def test_probe_result_formats_agree(query_mode):
+    """The k-mer table probe hands 8 bytes per seed to the emit kernel since round 4 (16 before: option res16): same raw
+    stream -- order and multiplicities included -- for k-mers answered from their slot and for k-mers with a 32-byte
+    record (several occurrences: four full copies of the paths; several loci), under gocc thresholds and for each phase."""
+    g, reads = _x_case()
+    for k, npaths in ((10, 4), (21, 1), (8, 0)):
+        f = psi_amd.SeedFinder(g, k)
+        f.create_path_index(npaths, rng_seed=2)
+        for thr in (0, 1, 3):
+            f.set_gocc_threshold(thr)
+            out = {}
+            for r16 in (0, 1):
+                f.set_option('res16', r16)
+                out[r16] = (f.seeds_all(reads[:300], step=3), f.seeds_on_paths(reads[:300], step=3), f.seeds_off_paths(reads[:300], step=3),
+                            f.counters()['n_hits'])
+            for a, b in zip(out[0][:3], out[1][:3]):
+                # the same multiset of records (the table's hits come out seed by seed; a walk cap adds the traverser's in any order)
+                assert _eq(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+            assert len(out[0][0]) > 0
+        f.close()
+
+
 def test_packed_device_entry_equals_ascii():
     """psigpu_find_seeds_device_packed: the device-resident chunk as 2-bit words."""
     import torch
