@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -3064,6 +3065,7 @@ struct psigpu_ctx {
     hsa_signal_t sig_in[IN_RING]{}, sig_out[2]{};      // 1 while the transfer is in flight (two-slot path: sig_in[0..1])
   } ec;
   double hits_per_read_hint = 0.0;
+  void* widener = nullptr;         // the host entry's widening threads (struct Widener, made by its first call)
   // psigpu_set_option
   uint64_t opt_sub_bytes = 0;
   bool opt_no_ahead = false, opt_no_engine_copy = false;
@@ -3285,10 +3287,13 @@ psigpu_ctx* psigpu_create(int device)
   return ctx;
 }
 
+static void widener_destroy(psigpu_ctx* ctx);
+
 void psigpu_destroy(psigpu_ctx* ctx)
 {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  widener_destroy(ctx);
   DevBuf* all[] = { &ctx->nodes, &ctx->lite, &ctx->node_id, &ctx->lab2, &ctx->labn, &ctx->edge_to, &ctx->loci, &ctx->w_bases,
                     &ctx->w_read_off, &ctx->w_cnt, &ctx->w_tiles, &ctx->w_seed_off, &ctx->w_seed_key,
                     &ctx->w_seed_info, &ctx->w_seed_next, &ctx->w_ht, &ctx->w_pfx, &ctx->w_pfx12, &ctx->w_iv_lo, &ctx->w_iv_cnt, &ctx->w_iv_aux, &ctx->w_hit_off,
@@ -4442,7 +4447,11 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
                                                     k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
                                                     nullptr, nullptr, 0);
   }
-  EVREC(1, stream);
+  // the host entry answers a chunk in ~10 sub-batches whose kernels take 0.1 ms each: two of the five event records of a
+  // default-mode call (each ~5 us of idle GPU) are left out there -- the per-kernel times of such a call are then 0, its
+  // total and its sort time stay (PSIGPU_TRACE keeps all)
+  const bool lean_ev = wire != nullptr && getenv("PSIGPU_TRACE") == nullptr;
+  if (!lean_ev) EVREC(1, stream);
   static const bool env_no_verify = getenv("PSIGPU_NO_VERIFY") != nullptr;   // A/B: LF steps only
   const bool no_verify = env_no_verify || (ctx->tune & PSIGPU_TUNE_NO_VERIFY);
   auto fm_view = [&](const psigpu_ctx::FmPart& fp) {
@@ -4689,7 +4698,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
             k_wave_offsets<<<1, 1024, 0, stream>>>(tiles_of(p), (probe && p == 0) ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, n_waves,
                                                    (uint64_t*)&ctr->n_hits_on.v, (uint64_t*)&ctr->n_hits_tab.v, p != 0);
       }
-      EVREC(4, stream);
+      if (!(lean_ev && kprobe && !off_paths)) EVREC(4, stream);
       const LocusEnt* oe = (probe || kprobe) ? ctx->lkt_ent.as<LocusEnt>() : nullptr;
       if (kprobe) {
         const FMView fm0 = fm_view(ctx->p0());
@@ -4879,11 +4888,12 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   pc.n_locate_steps = h.n_locate_steps.total();
   if (getenv("PSIGPU_DEBUG")) fprintf(stderr, "[psigpu] dbg0 %llu dbg1 %llu chunks %llu spilled %llu\n", h.dbg0.v, h.dbg1.v, h.n_chunks.v, (unsigned long long)pc.n_spilled);
   auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ctx->ev[a], ctx->ev[b]); return t; };
-  pc.ms_pack = ms(0, 1); pc.ms_table = off_paths ? ms(2, 6) : 0.f;
+  const bool lean_k = lean_ev && kprobe && !off_paths;          // (events 1 and 4 were not recorded)
+  pc.ms_pack = lean_ev ? 0.f : ms(0, 1); pc.ms_table = off_paths ? ms(2, 6) : 0.f;
   pc.ms_search = on_paths ? ms(3, 10) : 0.f;          // K1
   // table probe + the scan of the per-wave totals
-  pc.ms_probe = kprobe ? ms(1, 4) : (probe ? ms(10, 4) : 0.f);
-  pc.ms_locate = (on_paths || probe || kprobe) ? ((kprobe && !off_paths) ? ms(4, ctx->grouped_state ? 11 : 8) : ms(4, 5)) : 0.f;
+  pc.ms_probe = lean_k ? 0.f : kprobe ? (lean_ev ? 0.f : ms(1, 4)) : (probe ? ms(10, 4) : 0.f);
+  pc.ms_locate = lean_k ? 0.f : (on_paths || probe || kprobe) ? ((kprobe && !off_paths) ? ms(4, ctx->grouped_state ? 11 : 8) : ms(4, 5)) : 0.f;
   pc.ms_traverse = off_paths ? ms(6, 7) : 0.f;        // runs beside K1/K2 on the second stream
   pc.ms_total = ms(0, 8);
   if (ctx->grouped_state) { pc.ms_sort = ms(11, 8); pc.ms_total -= pc.ms_sort; }     // (added back by the caller with the sort's time)
@@ -5202,24 +5212,53 @@ static inline void store_hit(psigpu_hit* dst, uint64_t node, uint64_t noff, uint
 
 struct Widener {
   struct Job { const void* src; psigpu_hit* dst; uint64_t n, id_base, rec_base; int slot; WireFmt fmt; };
+  // The threads live as long as the context (round 4: a call used to start and join up to eight threads of its own,
+  // 0.15-0.2 ms of a 2-ms call); a call is a SESSION: begin() resets the job list and wakes them, end() waits until
+  // every one of them has left the session.
   std::vector<Job> jobs;
+  size_t n_jobs = 0;
   std::atomic<size_t> posted{ 0 }, ready{ 0 };
   // slices done, PER JOB: thread 0 may be a job ahead of a thread that was descheduled inside the job before, so a
   // count over all jobs reaches "T x (j + 1)" while a slice of job j is still being read (seen under three fuzz
   // processes on one box: a record of the sub-batch that reused the landing buffer)
   std::unique_ptr<std::atomic<uint32_t>[]> parts;
+  size_t parts_cap = 0;
   size_t checked = 0;                           // caller's thread only: jobs [0, checked) are known to be finished
-  std::atomic<bool> stop{ false };
+  std::atomic<bool> stop{ false };              // the session is abandoned (error path): leave it
   std::vector<std::thread> th;
   std::function<void(int)> wait_copy;           // blocks until the slot's device-to-host transfer is complete
   unsigned T = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t session = 0;                         // (mu)
+  bool quit = false;                            // (mu)
+  std::atomic<unsigned> left{ 0 };              // threads that have left the current session
+  bool open = false;                            // caller's thread only: a session is running
 
-  void start(unsigned n_threads, size_t n_jobs, std::function<void(int)> wc)
+  void begin(unsigned n_threads, size_t n_jobs_, std::function<void(int)> wc)
   {
-    T = n_threads; jobs.resize(n_jobs); wait_copy = std::move(wc);
-    parts.reset(new std::atomic<uint32_t>[n_jobs ? n_jobs : 1]);
+    if (T == 0) {
+      T = n_threads;
+      for (unsigned t = 0; t < T; ++t) th.emplace_back([this, t] { loop(t); });
+    }
+    n_jobs = n_jobs_;
+    if (jobs.size() < n_jobs) jobs.resize(n_jobs);
+    if (parts_cap < n_jobs) { parts_cap = n_jobs + n_jobs / 2 + 16; parts.reset(new std::atomic<uint32_t>[parts_cap]); }
     for (size_t j = 0; j < n_jobs; ++j) parts[j].store(0, std::memory_order_relaxed);
-    for (unsigned t = 0; t < T; ++t) th.emplace_back([this, t] { run(t); });
+    posted.store(0); ready.store(0); stop.store(false); left.store(0);
+    checked = 0;
+    wait_copy = std::move(wc);
+    { std::lock_guard<std::mutex> lk(mu); ++session; }
+    cv.notify_all();
+    open = true;
+  }
+  // every thread out of the session (all jobs done, or `stop` after an error): nothing of the call's buffers is touched after this
+  void end()
+  {
+    if (!open) return;
+    stop.store(true);
+    while (left.load(std::memory_order_acquire) < T) std::this_thread::yield();
+    open = false;
   }
   void post(size_t j, const Job& job) { jobs[j] = job; posted.store(j + 1, std::memory_order_release); }
   // every slice of jobs [0, upto) has been widened (called by the thread that posts)
@@ -5228,9 +5267,23 @@ struct Widener {
     for (; checked < upto; ++checked)
       while (parts[checked].load(std::memory_order_acquire) < T) std::this_thread::yield();
   }
+  void loop(unsigned t)
+  {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return quit || session != seen; });
+        if (quit) return;
+        seen = session;
+      }
+      run(t);
+      left.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
   void run(unsigned t)
   {
-    for (size_t j = 0; j < jobs.size(); ++j) {
+    for (size_t j = 0; j < n_jobs; ++j) {
       while (posted.load(std::memory_order_acquire) <= j) { if (stop.load()) return; std::this_thread::yield(); }
       const Job job = jobs[j];
       if (t == 0) { if (job.n) wait_copy(job.slot); ready.store(j + 1, std::memory_order_release); }
@@ -5258,12 +5311,24 @@ struct Widener {
       parts[j].fetch_add(1, std::memory_order_acq_rel);
     }
   }
-  ~Widener() { stop = true; for (auto& x : th) if (x.joinable()) x.join(); }
+  ~Widener()
+  {
+    end();
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    for (auto& x : th) if (x.joinable()) x.join();
+  }
 };
 
 }  // namespace
 
 extern "C" {
+
+static void widener_destroy(psigpu_ctx* ctx)
+{
+  delete static_cast<Widener*>(ctx->widener);
+  ctx->widener = nullptr;
+}
 
 // Streams and events of the host entry's pipeline, made on its first call.
 //
@@ -5420,7 +5485,11 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
   // the one part of the call nothing overlaps with)
   // (PSIGPU_SUB_BYTES: tests force many sub-batches on small inputs)
   const char* sub_env = getenv("PSIGPU_SUB_BYTES");
-  const uint64_t SUB_BYTES = ctx->opt_sub_bytes ? ctx->opt_sub_bytes : sub_env ? std::max<uint64_t>(1, strtoull(sub_env, nullptr, 10)) : (16ull << 20);
+  // (bases per sub-batch.  ASCII reads: 16 Mi, the link is the bound and more, smaller pieces hide its latency; packed reads:
+  // 32 Mi -- the link moves a quarter of the bytes, the compute loop is the critical path and every sub-batch costs ~75 us
+  // of launches, event records and its synchronisation: 2.30 ms per 1 M-read chunk at 16 Mi, 2.12 at 32, tools/e2e_packed.py)
+  const uint64_t SUB_BYTES = ctx->opt_sub_bytes ? ctx->opt_sub_bytes : sub_env ? std::max<uint64_t>(1, strtoull(sub_env, nullptr, 10))
+                                                                               : ((in.packed() ? 32ull : 16ull) << 20);
   { int st = pipeline_init(ctx); if (st != PSIGPU_OK) return st; }
   // Reads AND offsets in pinned memory (psi::Records of the shim, psikt): the chunk's reads go to one device buffer
   // and their transfers are queued up to IN_RING sub-batches ahead of the compute loop, so that the copy engine
@@ -5618,11 +5687,13 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     if (ctx->opt_wire8_roff_cap) f.roff_bits = std::min(f.roff_bits, ctx->opt_wire8_roff_cap);      // (tests: make a long read overflow)
     return f;
   };
-  Widener widener;                                  // (destroyed -- joined -- before hp can be handed back on an error path)
+  if (!ctx->widener) ctx->widener = new Widener;
+  Widener& widener = *static_cast<Widener*>(ctx->widener);
+  struct Session { Widener& w; ~Session() { w.end(); } } session{ widener };      // (every way out: its threads have left the call's buffers)
   if (wire16) {
     wd = &widener;
     const unsigned hw = std::thread::hardware_concurrency();
-    widener.start(std::max(1u, std::min(8u, hw / 4)), n_sub, [ctx](int slot_) {
+    widener.begin(std::max(1u, std::min(8u, hw / 4)), n_sub, [ctx](int slot_) {
       if (ctx->ec.ok) engine_wait(ctx->ec.sig_out[slot_]);
       else { (void)hipSetDevice(ctx->device); (void)hipEventSynchronize(ctx->slot[slot_].out_done); }
     });
