@@ -974,6 +974,18 @@ def main():
             del ix
         rbm['fm-lf'] = lf
         out['roofline_by_mode'] = rbm
+        # ---- what the tables of the default mode cost against what they save (review item: the headline's kernel looks up what
+        # `prepare` computed): chunks of this size after which the k-mer table mode has paid for its tables, against traverse mode
+        # (nothing about the loci tabulated) -- PSIGPU_MODE_AUTO / psikt --query-mode auto decide by the same arithmetic
+        if 'traverse' in rbm and args.mode == 'kmer-table':
+            t_tab = float(c['ms_locus_table_build'])
+            saved = rbm['traverse']['ms_per_step'] - out['ms_per_step']
+            out['break_even'] = {'table_build_ms': t_tab, 'prepare_wall_s': t_prep, 'ms_per_step_default': out['ms_per_step'],
+                                 'ms_per_step_traverse': rbm['traverse']['ms_per_step'],
+                                 'chunks': (t_tab / saved) if saved > 0 else None,
+                                 'reads': (t_tab / saved * args.reads) if saved > 0 else None,
+                                 'note': 'steady state is the metric (index load excluded, SURVEY 8d); a finder that answers fewer '
+                                         'chunks than this is better off in traverse mode: psigpu_set_query_mode( PSIGPU_MODE_AUTO )'}
 
         # ---- CPU baseline + parity gate -------------------------------------------------------------
         if args.cpu_reads != 0:

@@ -330,6 +330,7 @@ def test_spill_path_is_exercised(query_mode):
     k = 14
     want = np.array(brute.hit_set(bg, reads, k, 6), dtype=np.uint64).reshape(-1, 4)
     f = psi_amd.SeedFinder(g, k)
+    f.set_option('no_pfx_roots', 1)           # from the loci themselves: every walk enters the loop and the stack floods
     f.create_path_index(0)
     got = psi_amd.sort_unique(f.seeds_all(reads, step=6))
     c = f.counters()
@@ -337,6 +338,9 @@ def test_spill_path_is_exercised(query_mode):
     if query_mode == 'traverse':
         assert c['n_spilled'] > 0 and c['traverse_launches'] > 1
         assert c['n_locus_kmers'] == 0 and c['n_loci_traversed'] == c['n_loci']
+    # ... and from the loci's prefix walks (the default since round 4: the chunk's 12-mer map prunes them while they are staged)
+    f.set_option('no_pfx_roots', 0)
+    assert _eq(psi_amd.sort_unique(f.seeds_all(reads, step=6)), want)
     f.close()
     # k = 31: hundreds of millions of k-walks per locus, far over every cap and every budget of the
     # table construction -- in every mode these loci are traversed per chunk, pruned by the seeds
