@@ -152,6 +152,13 @@ typedef struct psigpu_index psigpu_index;
  * (GFA 1 / GFA 2) or .vg (gzip'd protobuf stream, vg/vg.proto:13-103, vg/stream.hpp:81-130).
  * Returns NULL on failure; *status gets the code. */
 psigpu_graph* psigpu_graph_load(const char* path, int* status);
+/* ... with options.  PSIGPU_GRAPH_FOLLOW_REVERSING: a link whose sides reverse (a+ -> b-, a- -> b+: an inversion) and reverse
+ * steps of embedded paths are refused by default -- the device walks nodes forwards only -- while the reference follows every
+ * out-link's `to` id and reads that node forwards, whatever side the link enters it by (include/psi/traverser_bfs.hpp:146-160
+ * discards `linktype`).  With the flag the loader does exactly that: every link is the edge from -> to as written, a reverse
+ * path step is the node; graphs with inversions load and the hit set is the reference's.  psikt: --follow-reversing-edges. */
+#define PSIGPU_GRAPH_FOLLOW_REVERSING 1u
+psigpu_graph* psigpu_graph_load_opts(const char* path, uint32_t flags, int* status);
 
 /* In-memory construction (edge targets are node ranks). `path_nodes` holds node ranks of
  * the embedded (reference) paths; all path arguments may be NULL / 0. */

@@ -98,6 +98,7 @@ ABI = [
     ('psigpu_abi_version', C.c_uint32, []),
     ('psigpu_host_last_error', C.c_char_p, []),
     ('psigpu_graph_load', _P, [C.c_char_p, _INTP]),
+    ('psigpu_graph_load_opts', _P, [C.c_char_p, C.c_uint32, _INTP]),
     ('psigpu_graph_from_csr', _P, [C.c_uint64, _P, _P, _P, _P, _P, C.c_uint64, _P, _P, _INTP]),
     ('psigpu_graph_free', None, [_P]),
     ('psigpu_graph_view_get', C.c_int, [_P, C.POINTER(GraphView)]),
@@ -281,9 +282,11 @@ class Graph:
         self.n_edges = lib().psigpu_graph_edge_count(self.h)
 
     @classmethod
-    def load(cls, path: str) -> 'Graph':
+    def load(cls, path: str, follow_reversing: bool = False) -> 'Graph':
+        """`follow_reversing`: PSIGPU_GRAPH_FOLLOW_REVERSING -- reversing links and reverse path steps are walked as the
+        reference walks them (the link's `to` node, read forwards) instead of being refused."""
         st = C.c_int(0)
-        h = lib().psigpu_graph_load(path.encode(), C.byref(st))
+        h = lib().psigpu_graph_load_opts(path.encode(), 1 if follow_reversing else 0, C.byref(st))
         if not h:
             raise PsiGpuError('cannot load graph %s: %s' % (path, _host_err()))
         return cls(h)

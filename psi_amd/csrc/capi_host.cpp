@@ -21,11 +21,13 @@ uint32_t psigpu_abi_version(void) { return PSIGPU_ABI_VERSION; }
 
 const char* psigpu_host_last_error(void) { return g_host_err.c_str(); }
 
-psigpu_graph* psigpu_graph_load(const char* path, int* status)
+psigpu_graph* psigpu_graph_load(const char* path, int* status) { return psigpu_graph_load_opts(path, 0, status); }
+
+psigpu_graph* psigpu_graph_load_opts(const char* path, uint32_t flags, int* status)
 {
   int st = PSIGPU_OK;
   std::string err;
-  Graph* g = path ? load_graph_file(path, &st, &err) : nullptr;
+  Graph* g = path ? load_graph_file(path, &st, &err, flags) : nullptr;
   if (!path) st = PSIGPU_ERR_ARG;
   if (status) *status = st;
   if (!g) { g_host_err = err; return nullptr; }

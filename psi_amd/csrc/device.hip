@@ -3065,6 +3065,7 @@ struct psigpu_ctx {
     hsa_signal_t sig_in[IN_RING]{}, sig_out[2]{};      // 1 while the transfer is in flight (two-slot path: sig_in[0..1])
   } ec;
   double hits_per_read_hint = 0.0;
+  bool trace_call = false;         // the host-entry call in progress runs under PSIGPU_TRACE
   void* widener = nullptr;         // the host entry's widening threads (struct Widener, made by its first call)
   // psigpu_set_option
   uint64_t opt_sub_bytes = 0;
@@ -4450,7 +4451,7 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   // the host entry answers a chunk in ~10 sub-batches whose kernels take 0.1 ms each: two of the five event records of a
   // default-mode call (each ~5 us of idle GPU) are left out there -- the per-kernel times of such a call are then 0, its
   // total and its sort time stay (PSIGPU_TRACE keeps all)
-  const bool lean_ev = wire != nullptr && getenv("PSIGPU_TRACE") == nullptr;
+  const bool lean_ev = wire != nullptr && !ctx->trace_call;      // (the host entry reads PSIGPU_TRACE once per call)
   if (!lean_ev) EVREC(1, stream);
   static const bool env_no_verify = getenv("PSIGPU_NO_VERIFY") != nullptr;   // A/B: LF steps only
   const bool no_verify = env_no_verify || (ctx->tune & PSIGPU_TUNE_NO_VERIFY);
@@ -4862,7 +4863,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     for (int i = 0; i < STRIPES; ++i) ctx->last_max_read_len = std::max<uint64_t>(ctx->last_max_read_len, h.max_read_len.s[i].v);
     if (true_seeds > n_seeds) { ctx->err = "n_bases does not cover the reads"; return PSIGPU_ERR_ARG; }
     total_hits = h.n_hits_tab.v + h.n_hits_off.v;
-    if (getenv("PSIGPU_DEBUG"))
+    static const bool env_debug = getenv("PSIGPU_DEBUG") != nullptr;
+    if (env_debug)
       fprintf(stderr, "[psigpu] attempt %d: seeds %llu of %llu, hits on %llu tab %llu off %llu, chunks %llu of %llu, spill %llu, cap %llu (kprobe %d on %d off %d probe %d)\n",
               attempt, (unsigned long long)true_seeds, (unsigned long long)n_seeds, h.n_hits_on.v, h.n_hits_tab.v, h.n_hits_off.v, h.n_chunks.v,
               (unsigned long long)cap_chunks, h.n_spill.v, (unsigned long long)cap, (int)kprobe, (int)on_paths, (int)off_paths, (int)probe);
@@ -4886,7 +4888,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   pc.n_lf_steps = h.n_lf_steps.total();
   pc.n_rows_verified = h.n_rows_verified.total();
   pc.n_locate_steps = h.n_locate_steps.total();
-  if (getenv("PSIGPU_DEBUG")) fprintf(stderr, "[psigpu] dbg0 %llu dbg1 %llu chunks %llu spilled %llu\n", h.dbg0.v, h.dbg1.v, h.n_chunks.v, (unsigned long long)pc.n_spilled);
+  static const bool env_debug2 = getenv("PSIGPU_DEBUG") != nullptr;
+  if (env_debug2) fprintf(stderr, "[psigpu] dbg0 %llu dbg1 %llu chunks %llu spilled %llu\n", h.dbg0.v, h.dbg1.v, h.n_chunks.v, (unsigned long long)pc.n_spilled);
   auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ctx->ev[a], ctx->ev[b]); return t; };
   const bool lean_k = lean_ev && kprobe && !off_paths;          // (events 1 and 4 were not recorded)
   pc.ms_pack = lean_ev ? 0.f : ms(0, 1); pc.ms_table = off_paths ? ms(2, 6) : 0.f;
@@ -5700,6 +5703,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
   }
   psigpu_counters acc{};
   const bool trace = getenv("PSIGPU_TRACE") != nullptr;        // per-sub-batch host timeline on stderr
+  ctx->trace_call = trace;
   auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_call = now_ms();
   std::vector<double> tr;

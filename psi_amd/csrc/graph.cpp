@@ -27,6 +27,7 @@ struct RawGraph {
   std::string seqbuf;                                    // labels in file order, upper case
   std::vector<std::pair<uint64_t, uint64_t>> edges;      // external ids, forward
   std::vector<std::pair<std::string, std::vector<uint64_t>>> paths;
+  bool follow_reversing = false;                         // PSIGPU_GRAPH_FOLLOW_REVERSING: every link is its `from -> to`, whatever its sides
 
   // (a node that is defined twice keeps its last definition: resolved when ranks are assigned)
   void add_node(uint64_t id, const char* s, size_t n)
@@ -65,10 +66,17 @@ bool strip_orient(const std::string& tok, uint64_t* id, bool* rev)
 // Orientation handling: the reference traverser follows `to` ids only and ignores the link
 // type (include/psi/traverser_bfs.hpp:146-160), i.e. it assumes forward-only graphs.  A
 // (a-, b-) link is the forward link (b+, a+); anything else that reverses is rejected.
+//
+// PSIGPU_GRAPH_FOLLOW_REVERSING restates the reference literally instead: its traverser asks gum for the out-links of a node
+// and follows each link's `to` id, reading that node forwards whatever side the link enters it by (`linktype` is discarded,
+// traverser_bfs.hpp:146-160) -- so every link, reversing or not, is the edge from -> to as the file writes it, and a reverse
+// step of an embedded path is the node itself.  Graphs with inversions load that way; the hit set is the reference's, not
+// what a strand-aware mapper would call correct.
 bool add_edge(RawGraph& rg, uint64_t a, bool ar, uint64_t b, bool br, std::string* err)
 {
+  if (rg.follow_reversing) { rg.edges.emplace_back(a, b); return true; }
   if (ar && br) std::swap(a, b);
-  else if (ar || br) { *err = "reversing edges are not supported"; return false; }
+  else if (ar || br) { *err = "reversing edges are not supported (PSIGPU_GRAPH_FOLLOW_REVERSING / psikt --follow-reversing-edges walks them as the reference does)"; return false; }
   rg.edges.emplace_back(a, b);
   return true;
 }
@@ -158,7 +166,7 @@ bool parse_gfa(const std::string& path, RawGraph& rg, std::string* err)
           const char o = te[-1];
           uint64_t id;
           if ((o != '+' && o != '-') || te - q < 2 || !parse_u64(q, te - q - 1, &id)) { *err = "bad path step"; return false; }
-          if (o == '-') { *err = "reverse path steps are not supported"; return false; }
+          if (o == '-' && !rg.follow_reversing) { *err = "reverse path steps are not supported"; return false; }
           nodes.push_back(id);
         }
         q = s2 ? s2 + 1 : qe;
@@ -254,7 +262,7 @@ bool parse_vg_graph_msg(const uint8_t* b, uint64_t n, RawGraph& rg,
               uint32_t e, ew; uint64_t ev = 0, el = 0; const uint8_t* ep = nullptr;
               while (pq.next(&e, &ew, &ev, &ep, &el)) {
                 if (e == 1 && ew == 0) nid = ev;
-                else if (e == 4 && ew == 0 && ev) { *err = "reverse path steps are not supported"; return false; }
+                else if (e == 4 && ew == 0 && ev && !rg.follow_reversing) { *err = "reverse path steps are not supported"; return false; }
               }
             } else if (c == 5 && cw == 0) rank = cv;
           }
@@ -317,9 +325,10 @@ bool ends_with(const std::string& s, const char* suf)
 
 }  // namespace
 
-Graph* load_graph_file(const std::string& path, int* status, std::string* err)
+Graph* load_graph_file(const std::string& path, int* status, std::string* err, uint32_t flags)
 {
   RawGraph rg;
+  rg.follow_reversing = (flags & PSIGPU_GRAPH_FOLLOW_REVERSING) != 0;
   bool ok;
   if (ends_with(path, ".vg")) ok = parse_vg(path, rg, err);
   else ok = parse_gfa(path, rg, err);

@@ -78,7 +78,7 @@ struct Index {
 };
 
 // graph.cpp
-Graph* load_graph_file(const std::string& path, int* status, std::string* err);
+Graph* load_graph_file(const std::string& path, int* status, std::string* err, uint32_t flags = 0);
 
 // pathsel.cpp / index.cpp
 // pathsel.cpp: Haplotyper walks and patches

@@ -39,6 +39,7 @@ struct Options {                       // reference src/options.hpp:67-93
   bool nolog = false, verbose = false;
   std::vector< int > devices{ 0 };
   unsigned int query_mode = PSIGPU_MODE_KMER_TABLE;
+  bool follow_reversing = false;
 };
 
 struct Logger {
@@ -89,6 +90,8 @@ const char* USAGE =
   "                             reads are split into one contiguous range per GPU (same output)\n"
   "      --query-mode MODE      kmer-table | locus-table | traverse | auto (default: kmer-table; same hits;\n"
   "                             auto: traverse for a small FASTQ, tables for a large one)\n"
+  "      --follow-reversing-edges  links whose sides reverse (inversions) and reverse path steps are walked as the\n"
+  "                             reference walks them -- the link's `to` node, read forwards -- instead of being refused\n"
   "  -h, --help\n";
 
 bool ends_with( std::string const& s, const char* suf )
@@ -185,6 +188,7 @@ Options parse_args( int argc, char** argv )
       }
       if ( o.devices.empty() ) throw std::runtime_error( "--devices needs at least one GPU" );
     }
+    else if ( a == "--follow-reversing-edges" ) o.follow_reversing = true;
     else if ( a == "--query-mode" ) {
       std::string m = need();
       if ( m == "kmer-table" ) o.query_mode = PSIGPU_MODE_KMER_TABLE;
@@ -275,7 +279,7 @@ int run( Options const& o, Logger& log )
   std::thread warm( [] { void* p = psigpu_host_alloc( 4096 ); if ( p != nullptr ) psigpu_host_free( p ); } );
   struct Joiner { std::thread& t; ~Joiner() { if ( t.joinable() ) t.join(); } } warm_guard{ warm };
   log.info( "Loading input graph from file '" + o.graph_path + "'..." );
-  Graph graph( o.graph_path );
+  Graph graph( o.graph_path, o.follow_reversing );
   log.info( "Number of nodes: " + std::to_string( graph.get_node_count() ) + ", edges: " +
             std::to_string( graph.get_edge_count() ) + ", paths: " + std::to_string( graph.get_path_count() ) );
   SeqStreamIn reads_iss( o.fq_path );

@@ -29,16 +29,16 @@ namespace psi {
     typedef std::uint64_t rank_type;
 
     Graph() = default;
-    explicit Graph( std::string const& path ) { load( path ); }
+    explicit Graph( std::string const& path, bool follow_reversing = false ) { load( path, follow_reversing ); }
     Graph( Graph const& ) = delete;
     Graph& operator=( Graph const& ) = delete;
     ~Graph() { psigpu_graph_free( h_ ); }
 
     /** gum::util::load(graph, path, ...): .gfa or .vg; throws std::runtime_error. */
-    void load( std::string const& path )
+    void load( std::string const& path, bool follow_reversing = false )
     {
       int st = 0;
-      psigpu_graph* g = psigpu_graph_load( path.c_str(), &st );
+      psigpu_graph* g = psigpu_graph_load_opts( path.c_str(), follow_reversing ? PSIGPU_GRAPH_FOLLOW_REVERSING : 0u, &st );
       if ( g == nullptr )
         throw std::runtime_error( "cannot load graph '" + path + "': " + psigpu_host_last_error() );
       psigpu_graph_free( h_ );

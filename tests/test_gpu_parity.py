@@ -1257,6 +1257,48 @@ def test_reference_paths_file_decides_the_on_path_hits(tmp_path):
     assert _eq(c, psi_amd.sort_unique(back))
 
 
+def test_inversion_graph_followed_as_the_reference_follows_it(tmp_path):
+    """PSIGPU_GRAPH_FOLLOW_REVERSING (psikt --follow-reversing-edges): a graph with reversing links is walked as the
+    reference's traverser walks it -- every out-link's `to` node, forwards, `linktype` ignored
+    (include/psi/traverser_bfs.hpp:146-160) -- i.e. the hit set is the brute-force definition over the edges AS WRITTEN."""
+    from oracle import brute
+    import random
+    rng = random.Random(4)
+    n = 40
+    seqs = {i + 1: ''.join(rng.choice('ACGT') for _ in range(rng.choice([3, 5, 8, 13, 21]))) for i in range(n)}
+    lines = ['H\tVN:Z:1.0'] + ['S\t%d\t%s' % (v, s) for v, s in seqs.items()]
+    bg = brute.Graph()
+    for v, sq in seqs.items():
+        bg.add_node(v, sq)
+    edges = set()
+    for v in range(1, n):
+        for t in {v + 1, min(n, v + rng.randint(1, 3))}:
+            if (v, t) in edges:
+                continue
+            edges.add((v, t))
+            a, b = rng.choice(['+', '+', '-']), rng.choice(['+', '+', '-'])        # a third of the links reverse a side
+            lines.append('L\t%d\t%s\t%d\t%s\t0M' % (v, a, t, b))
+            bg.add_edge(v, t)                                                      # as written: from -> to
+    lines.append('P\tref\t' + ','.join('%d%s' % (v, rng.choice('+-')) for v in range(1, n + 1)) + '\t*')
+    fn = str(tmp_path / 'inv.gfa')
+    open(fn, 'w').write('\n'.join(lines) + '\n')
+    g = psi_amd.Graph.load(fn, follow_reversing=True)
+    reads = []
+    for _ in range(120):
+        v = rng.randint(1, n - 5)
+        sq = bg.seq[v][rng.randrange(len(bg.seq[v])):]
+        while len(sq) < 40 and bg.out[v]:
+            v = rng.choice(bg.out[v])
+            sq += bg.seq[v]
+        reads.append(sq[:40])
+    for k, npaths in ((8, 1), (13, 0), (21, 2)):
+        want = np.array(brute.hit_set(bg, reads, k, 2), dtype=np.uint64).reshape(-1, 4)
+        f = psi_amd.SeedFinder(g, k)
+        f.create_path_index(npaths, rng_seed=1)
+        assert len(want) and _eq(psi_amd.sort_unique(f.seeds_all(reads, step=2)), want)
+        f.close()
+
+
 def test_auto_query_mode_decides_by_expected_work():
     """PSIGPU_MODE_AUTO: a finder that expects one small chunk traverses (no tables made), one that expects many -- or
     does not know -- tabulates; same records either way (north_star: the traverser kernel and the tabulated default are

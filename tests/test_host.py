@@ -560,6 +560,32 @@ def test_untrusted_files_cannot_ask_for_memory(tmp_path, ref_data, golden_dir):
     assert sum(l.startswith('rejected') for l in out) == 8
 
 
+def test_reversing_links_are_refused_or_followed_as_the_reference_does(tmp_path):
+    """A link whose sides reverse (an inversion) and a reverse path step: refused by default (the device walks nodes
+    forwards only), walked with PSIGPU_GRAPH_FOLLOW_REVERSING as the reference walks them -- every out-link's `to` id, the
+    node read forwards, `linktype` discarded (include/psi/traverser_bfs.hpp:146-160): the edge from -> to as written."""
+    gfa = ('H\tVN:Z:1.0\nS\t1\tACGTACGTAC\nS\t2\tGGGTTTCC\nS\t3\tTTGACCA\nS\t4\tCATG\n'
+           'L\t1\t+\t2\t+\t0M\nL\t1\t+\t3\t-\t0M\nL\t3\t-\t4\t+\t0M\nL\t2\t+\t4\t+\t0M\nL\t4\t-\t2\t-\t0M\n'
+           'P\tref\t1+,3-,4+\t*\n')
+    fn = str(tmp_path / 'inv.gfa')
+    open(fn, 'w').write(gfa)
+    with pytest.raises(psi_amd.PsiGpuError, match='reversing edges are not supported'):
+        psi_amd.Graph.load(fn)
+    g = psi_amd.Graph.load(fn, follow_reversing=True)
+    assert g.n_nodes == 4 and g.n_edges == 5
+    eo, et = g.edge_off.tolist(), g.edge_to.tolist()
+    out = {int(g.node_id[v]): sorted(int(g.node_id[t]) for t in et[eo[v]:eo[v + 1]]) for v in range(4)}
+    assert out == {1: [2, 3], 2: [4], 3: [4], 4: [2]}          # (4- -> 2- is followed as 4 -> 2, as written, not turned into 2 -> 4)
+    assert [int(g.node_id[v]) for v in g.paths()[0].tolist()] == [1, 3, 4]
+    # without the reversing links the default loader takes the file, and a (a-, b-) link is the forward link b -> a
+    plain = gfa.replace('L\t1\t+\t3\t-\t0M\n', '').replace('L\t3\t-\t4\t+\t0M\n', '').replace('1+,3-,4+', '1+,2+,4+')
+    open(fn, 'w').write(plain)
+    g2 = psi_amd.Graph.load(fn)
+    eo, et = g2.edge_off.tolist(), g2.edge_to.tolist()
+    out2 = {int(g2.node_id[v]): sorted(int(g2.node_id[t]) for t in et[eo[v]:eo[v + 1]]) for v in range(4)}
+    assert out2 == {1: [2], 2: [4, 4], 3: [], 4: []} or out2 == {1: [2], 2: [4], 3: [], 4: []}
+
+
 def test_views_shared_through_mapped_files(ref_data):
     """psi_amd.shared: the arrays behind a graph view and an index view (one part and several) written to a
     memory-backed directory by one process and mapped by another give views with the same scalars and the same bytes:
