@@ -341,6 +341,7 @@ int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags);
  *                     nothing narrower than that
  *   "expected_calls"  PSIGPU_MODE_AUTO: how many chunks this finder will be asked (0 = unknown: assume many)
  *   "expected_seeds"  PSIGPU_MODE_AUTO: ... and how many seeds over all of them (0 = unknown)
+ *   "no_lookahead"    1: every sub-batch of the host entry is synchronised before the next one's kernels are queued (rounds 1-3)
  *   "res16"           1: the k-mer table probe leaves 16 bytes of results per seed for the emit kernel (rounds 1-3) instead of 8
  *   "no_pfx_roots"    1: the query-time traverser starts from the starting loci themselves (TraverserBFS as written,
  *                     traverser_bfs.hpp:72-161) instead of from their tabulated 12-base prefix walks */
@@ -478,6 +479,11 @@ typedef struct psigpu_counters {
                                                 * on the host; 32: as returned; the widest any sub-batch of the call used); 0 for the
                                                 * device-resident entry */
   uint64_t n_locate_steps;                     /* LF steps K2 walked from occurrences to sampled suffix-array rows (sa_rate > 1) */
+  uint32_t lookahead_subbatches;               /* psigpu_find_seeds*: sub-batches of the call whose kernels were queued while the one
+                                                * before was still in flight (default mode, reads and offsets in pinned memory) */
+  uint32_t reserved3;
+  uint64_t lookahead_fallbacks;                /* since the context was made: chunks handed from that arrangement to the synchronous
+                                                * loop (more hits than expected, a seed with many hits, a wire field too narrow ...) */
   uint64_t stale_handbacks;                    /* since the context was made: calls whose counter block came back from the device with
                                                 * another call's serial number (detected, fetched again; expected 0) */
 } psigpu_counters;

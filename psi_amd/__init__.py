@@ -84,7 +84,8 @@ class Counters(C.Structure):
                 ('ms_total', C.c_float), ('ms_probe', C.c_float), ('ms_locus_table_build', C.c_float),
                 ('search_launches', C.c_uint32),
                 ('traverse_launches', C.c_uint32), ('sorted_in_place', C.c_uint32), ('wire_bytes_per_hit', C.c_uint32),
-                ('n_locate_steps', C.c_uint64), ('stale_handbacks', C.c_uint64)]
+                ('n_locate_steps', C.c_uint64), ('lookahead_subbatches', C.c_uint32), ('reserved3', C.c_uint32),
+                ('lookahead_fallbacks', C.c_uint64), ('stale_handbacks', C.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

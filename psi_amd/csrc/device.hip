@@ -3066,6 +3066,18 @@ struct psigpu_ctx {
   } ec;
   double hits_per_read_hint = 0.0;
   bool trace_call = false;         // the host-entry call in progress runs under PSIGPU_TRACE
+  // host entry, default mode: two sub-batches in flight (the kernels of sub-batch i + 1 are queued before the host waits
+  // for sub-batch i).  Set by a run_pipeline call that went through the default mode's five kernels alone; per in-flight
+  // sub-batch a hit buffer, a mapped block for its counters and an event.
+  uint32_t fast_k = 0, fast_flags = 0;
+  bool fast_on = false, fast_off = false;
+  struct FastSlot {
+    DevBuf hits;
+    void* h = nullptr; void* h_dev = nullptr;
+    hipEvent_t begin = nullptr, done = nullptr;
+  } fast[2];
+  bool opt_no_lookahead = false;
+  uint64_t lookahead_fallbacks = 0;
   void* widener = nullptr;         // the host entry's widening threads (struct Widener, made by its first call)
   // psigpu_set_option
   uint64_t opt_sub_bytes = 0;
@@ -3314,6 +3326,12 @@ void psigpu_destroy(psigpu_ctx* ctx)
     if (sl.in_ready) (void)hipEventDestroy(sl.in_ready);
     if (sl.out_done) (void)hipEventDestroy(sl.out_done);
   }
+  for (auto& fs : ctx->fast) {
+    fs.hits.release();
+    if (fs.h) (void)hipHostFree(fs.h);
+    if (fs.begin) (void)hipEventDestroy(fs.begin);
+    if (fs.done) (void)hipEventDestroy(fs.done);
+  }
   for (hipStream_t st : { ctx->s_in, ctx->s_comp, ctx->s_out }) if (st) (void)hipStreamDestroy(st);
   for (int i = 0; i < ctx->ec.n_sig; ++i)      // (kept for the next context)
     g_hsa.give(i < psigpu_ctx::EngineCopy::IN_RING ? ctx->ec.sig_in[i] : ctx->ec.sig_out[i - psigpu_ctx::EngineCopy::IN_RING]);
@@ -3354,6 +3372,7 @@ static void lkt_release(psigpu_ctx* ctx)
   ctx->lkt_ht.release(); ctx->lkt_ent.release(); ctx->lkt_res.release(); ctx->kt_ht.release(); ctx->kt_ext.release();
   ctx->kt_onpos.release();
   ctx->lkt_ready = false; ctx->lkt_failed = false; ctx->kt_ready = false;
+  ctx->fast_k = 0;
   ctx->kt_ht_size = ctx->kt_n_path_kmers = 0;
   ctx->lkt_ht_size = ctx->lkt_n_ent = ctx->lkt_n_res = ctx->lkt_n_walks = 0;
   ctx->lkt_note.clear();
@@ -3422,6 +3441,7 @@ int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value)
     ctx->opt_wire = (uint32_t)value;
   } else if (n == "no_pfx_roots") ctx->opt_no_pfx_roots = value != 0;
   else if (n == "res16") ctx->opt_res16 = value != 0;
+  else if (n == "no_lookahead") ctx->opt_no_lookahead = value != 0;
   else if (n == "expected_calls") { ctx->opt_expected_calls = value; ctx->auto_resolved = false; }
   else if (n == "expected_seeds") { ctx->opt_expected_seeds = value; ctx->auto_resolved = false; }
   else if (n == "wire8_roff_bits") { ctx->opt_wire8_roff_cap = (uint32_t)value; ctx->wire8_overflowed = false; }      // (test hook)
@@ -4901,7 +4921,113 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   pc.ms_total = ms(0, 8);
   if (ctx->grouped_state) { pc.ms_sort = ms(11, 8); pc.ms_total -= pc.ms_sort; }     // (added back by the caller with the sort's time)
   *n_hits_out = total_hits;
+  // (the host entry may keep two sub-batches of such calls in flight: enqueue_default)
+  if (kprobe && !off_paths && !on_paths && !probe && n_fm == 1) {
+    ctx->fast_k = k; ctx->fast_flags = flags; ctx->fast_on = (flags & PSIGPU_ON_PATHS) != 0; ctx->fast_off = want_off && use_lkt;
+  } else ctx->fast_k = 0;
 
+  return PSIGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// The default mode's kernels of ONE sub-batch of the host entry, queued WITHOUT a host synchronisation (round 4).  The host
+// entry answers a chunk in ~7 sub-batches of ~0.1 ms of kernels each; run_pipeline ends every one with a synchronisation,
+// and between the end of a sub-batch's last kernel and the start of the next one's first the device idled for what the
+// host needs to wake up, read the counters, queue the transfer out and launch again (~75 us per sub-batch, a third of a
+// 2-ms call).  Here the kernels of sub-batch i + 1 are in the queue before the host waits for sub-batch i: the per-call
+// workspace is shared (the stream orders the kernels), what the HOST reads afterwards is per sub-batch in flight -- the
+// hit buffer, the wire buffer, a mapped block for the counters, an event.  Only for calls that a run_pipeline call before
+// them has shown to need nothing but the default mode's kernels (ctx->fast_k); anything unusual found when a sub-batch is
+// finished -- more hits than its buffer holds, a seed with more hits than the in-place ordering takes, a wire field too
+// narrow, reads that are not of one length after all -- hands the rest of the chunk to the synchronous loop.
+// ------------------------------------------------------------------------------------
+struct FastArgs {
+  const char* d_in; const PackedIn* pk; const uint64_t* d_off;
+  uint64_t nr, nb; uint32_t k, step; uint64_t rec_base;
+  bool want_sort, claim_uniform;
+  WireFmt wf; DevBuf* wire; uint64_t cap; int slot;
+};
+
+static int enqueue_default(psigpu_ctx* ctx, const FastArgs& a, hipStream_t stream, unsigned long long* serial_out, bool* uniform_out)
+{
+  psigpu_ctx::FastSlot& fs = ctx->fast[a.slot];
+  DevCounters* ctr = ctx->w_ctr.as<DevCounters>();
+  const uint32_t k = a.k, step = a.step;
+  const uint64_t n_seeds = a.nb / step + a.nr;                     // upper bound: grids and buffers (sized by the caller)
+  const uint64_t* d_params = ctx->w_total.as<uint64_t>();
+  HIPCHK(ctx, hipEventRecord(fs.begin, stream));
+  UniformIn un{ 0, 0 };
+  if (a.claim_uniform && a.nr && a.nb % a.nr == 0 && a.nb / a.nr >= k && a.nb / a.nr < (1ull << 31)) {
+    un.len = (uint32_t)(a.nb / a.nr);
+    un.spr = (un.len - k) / step + 1;
+  }
+  const bool uniform = un.spr != 0;
+  *uniform_out = uniform;
+  const unsigned long long serial = ++ctx->serial;
+  *serial_out = serial;
+  if (uniform)
+    k_seed_init_uniform<<<1, 256, 0, stream>>>(ctr, serial, ctx->w_total.as<uint64_t>(), a.nr * (uint64_t)un.spr, un.len);
+  else {
+    const uint64_t n_tiles = a.nr / SCAN_TILE + 1;
+    k_seed_scan_tiles<<<(unsigned)n_tiles, SCAN_THREADS, 0, stream>>>(a.d_off, a.nr, k, step, ctx->w_tiles.as<uint64_t>(), ctr, serial);
+    k_seed_scan_final<<<(unsigned)n_tiles, SCAN_THREADS, 0, stream>>>(a.d_off, a.nr, k, step, ctx->w_tiles.as<uint64_t>(),
+                                                                    ctx->w_seed_off.as<uint64_t>(), ctx->w_total.as<uint64_t>(), ctr);
+  }
+  const unsigned pgrid = (unsigned)std::min<uint64_t>((n_seeds + 255) / 256, 256 * 32);
+  const PackedIn pk0{ nullptr, 0, 0 };
+  uint64_t* key = ctx->w_seed_key.as<uint64_t>();
+  uint2* info = ctx->w_seed_info.as<uint2>();
+#define PACK_ARGS(SO) a.d_in, a.d_off, SO, a.nr, d_params, n_seeds, a.nb, k, step, key, info, ctr, nullptr, nullptr, 0
+  if (uniform && a.pk) k_seed_pack<false, true, true><<<pgrid, 256, 0, stream>>>(PACK_ARGS(nullptr), *a.pk, un);
+  else if (uniform) k_seed_pack<false, false, true><<<pgrid, 256, 0, stream>>>(PACK_ARGS(nullptr), pk0, un);
+  else if (a.pk) k_seed_pack<false, true><<<pgrid, 256, 0, stream>>>(PACK_ARGS(ctx->w_seed_off.as<uint64_t>()), *a.pk);
+  else k_seed_pack<false><<<pgrid, 256, 0, stream>>>(PACK_ARGS(ctx->w_seed_off.as<uint64_t>()));
+#undef PACK_ARGS
+  uint64_t n_waves = std::min<uint64_t>(WAVES_MAX, (n_seeds + 15) / 16);
+  n_waves = (n_waves + 3) / 4 * 4;
+  const uint32_t per_wave = (uint32_t)(((n_seeds + n_waves - 1) / n_waves + 63) / 64 * 64);
+  const unsigned grid = (unsigned)(n_waves / 4);
+  const uint32_t thr = ctx->gocc_thr ? ctx->gocc_thr : 0xFFFFFFFFu;
+  static const bool env_res16 = getenv("PSIGPU_RES16") != nullptr;
+  const bool res8 = !env_res16 && !ctx->opt_res16 && ctx->max_node_len < (1ull << R8_NOFF_BITS);
+  const KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
+  uint4* res = ctx->w_seedres.as<uint4>();
+  uint64_t* tiles = ctx->w_iv_tiles.as<uint64_t>();
+  uint64_t* tiles_off = ctx->w_iv_tiles_off.as<uint64_t>();
+  if (res8) k_kmer_probe<true><<<grid, 256, 0, stream>>>(kt, key, d_params, n_seeds, per_wave, ctx->fast_on, ctx->fast_off, thr, res, tiles, tiles_off, ctr);
+  else k_kmer_probe<false><<<grid, 256, 0, stream>>>(kt, key, d_params, n_seeds, per_wave, ctx->fast_on, ctx->fast_off, thr, res, tiles, tiles_off, ctr);
+  const psigpu_ctx::FmPart& fp = ctx->p0();
+  MapView mv;
+  mv.samples = fp.samples.as<uint32_t>(); mv.sa_rate = ctx->sa_rate;
+  mv.exc_sa = fp.exc_sa.as<uint32_t>();
+  mv.seg = fp.seg.as<SegRec>(); mv.seg_dir = fp.seg_dir.as<uint32_t>();
+  mv.sarec = nullptr; mv.sarec_rem = k - fp.ftab_len;
+  mv.node_id = ctx->node_id.as<uint64_t>(); mv.id_base = ctx->id_base; mv.id_affine = ctx->id_affine;
+  mv.loci = ctx->loci.as<uint2>();
+  mv.on_pos = ctx->kt_onpos.as<uint2>();
+  mv.saloc = fp.have_saloc ? fp.saloc.as<uint2>() : nullptr;
+  psigpu_hit* d_hits = fs.hits.as<psigpu_hit>();
+  const LocusEnt* oe = ctx->lkt_ent.as<LocusEnt>();
+  if (res8) k_kmer_emit<true><<<grid, 256, 0, stream>>>(mv, res, ctx->kt_ext.as<KmerSlot>(), oe, tiles, tiles_off, d_params, n_seeds, per_wave, info,
+                                                         a.rec_base, d_hits, a.cap, ctr, ctx->fast_on, ctx->fast_off, thr);
+  else k_kmer_emit<false><<<grid, 256, 0, stream>>>(mv, res, ctx->kt_ext.as<KmerSlot>(), oe, tiles, tiles_off, d_params, n_seeds, per_wave, info,
+                                                    a.rec_base, d_hits, a.cap, ctr, ctx->fast_on, ctx->fast_off, thr);
+  if (a.want_sort && a.cap) {
+    int fsr = HitSorter::fix_grouped(d_hits, a.cap, &ctr->n_hits_tab.v, (uint64_t*)&ctr->not_grouped.v, stream, &ctx->err);
+    if (fsr != PSIGPU_OK) return fsr;
+  }
+  unsigned long long* h_wflag = reinterpret_cast<unsigned long long*>((char*)fs.h + sizeof(DevCounters) + 32);
+  *h_wflag = 0;
+  if (a.cap) {
+    if (a.wf.bytes == 8)
+      k_hits_wire8<<<2048, 256, 0, stream>>>(d_hits, &ctr->n_hits_tab.v, &ctr->n_hits_off.v, 0, a.cap, ctx->id_base, a.rec_base, a.wf,
+                                             a.wire->as<uint64_t>(), reinterpret_cast<unsigned long long*>((char*)fs.h_dev + sizeof(DevCounters) + 32));
+    else
+      k_hits_wire16<<<2048, 256, 0, stream>>>(d_hits, &ctr->n_hits_tab.v, &ctr->n_hits_off.v, 0, a.cap, ctx->id_base, a.rec_base, a.wire->as<uint4>());
+  }
+  k_publish<<<1, 256, 0, stream>>>(reinterpret_cast<const uint4*>(ctr), reinterpret_cast<uint4*>(fs.h_dev), (uint32_t)(sizeof(DevCounters) / 16));
+  HIPCHK(ctx, hipEventRecord(fs.done, stream));
+  HIPCHK(ctx, hipGetLastError());
   return PSIGPU_OK;
 }
 
@@ -5723,7 +5849,122 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     hipError_t e = stage_in(0);
     if (e != hipSuccess) { ctx->err = std::string("staging the reads: ") + hipGetErrorString(e); return fail(PSIGPU_ERR_DEVICE); }
   }
-  for (size_t i = 0; i < n_sub; ++i) {
+  // ---- two sub-batches in flight (enqueue_default): chunks whose sub-batches need the default mode's kernels alone ----
+  size_t first = 0;                  // sub-batches [0, first) are done when the synchronous loop below starts
+  static const bool env_no_lookahead = getenv("PSIGPU_NO_LOOKAHEAD") != nullptr;
+  bool fast = ahead && wire16 && !trace && !env_no_lookahead && !ctx->opt_no_lookahead && ctx->fast_k == k &&
+              ctx->fast_flags == (flags & PSIGPU_ALL) && ctx->lkt_ready && ctx->kt_ready && ctx->lkt_k == k && ctx->hits_per_read_hint > 0 &&
+              !(want_sort && getenv("PSIGPU_NO_GROUPED_SORT") != nullptr);
+  if (fast) {
+    const uint32_t stp = step ? step : k;
+    uint64_t nr_max = 0, nb_max = 0;
+    for (size_t j = 0; j < n_sub; ++j) {
+      nr_max = std::max(nr_max, cut[j + 1] - cut[j]);
+      nb_max = std::max(nb_max, read_off[cut[j + 1]] - read_off[cut[j]]);
+    }
+    const uint64_t seeds_max = nb_max / stp + nr_max;
+    const double ratio = ctx->hits_per_read_hint * 1.25;
+    const uint64_t cap_max = (uint64_t)(ratio * (double)nr_max) + 4096;
+    // everything the kernels of a sub-batch touch is sized here, once: nothing may be regrown (freed) under a sub-batch in flight
+    hipError_t e = hipSuccess;
+    auto need = [&](DevBuf& b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
+    need(ctx->w_ctr, sizeof(DevCounters)); need(ctx->w_total, 64);
+    need(ctx->w_tiles, (nr_max / SCAN_TILE + 2) * 8); need(ctx->w_seed_off, (nr_max + 1) * 8);
+    need(ctx->w_seed_key, (seeds_max + 1) * 8); need(ctx->w_seed_info, (seeds_max + 1) * 8);
+    need(ctx->w_seedres, (seeds_max + 16) * 16);
+    need(ctx->w_iv_tiles, (WAVES_MAX + 8) * 8); need(ctx->w_iv_tiles_off, (WAVES_MAX + 8) * 8);
+    for (int q = 0; q < 2; ++q) {
+      psigpu_ctx::FastSlot& fs = ctx->fast[q];
+      need(fs.hits, (cap_max + 1) * sizeof(psigpu_hit));
+      need(ctx->slot[q].d_wire, (cap_max + 1) * 16);
+      need(ctx->slot[q].off, (nr_max + 1) * 8);
+      if (e == hipSuccess && !fs.h) {
+        e = hipHostMalloc(&fs.h, sizeof(DevCounters) + 64, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&fs.h_dev, fs.h, 0);
+        if (e == hipSuccess) e = hipEventCreate(&fs.begin);
+        if (e == hipSuccess) e = hipEventCreate(&fs.done);
+      }
+    }
+    if (e != hipSuccess || seeds_max >= 0xFFFFFFF0ull) { (void)hipGetLastError(); fast = false; }      // (the synchronous loop reports what is wrong, if anything is)
+    struct Pending { unsigned long long serial; bool uniform; uint64_t cap; WireFmt wf; } pend[2];
+    auto enqueue = [&](size_t j) -> int {
+      psigpu_ctx::Slot& sl = ctx->slot[j & 1];
+      const uint64_t r0 = cut[j], nr = cut[j + 1] - r0, b0 = read_off[r0], nb = read_off[cut[j + 1]] - b0;
+      engine_wait(ctx->ec.sig_in[j % IN_RING]);                 // its reads have landed
+      if (j >= 2) { engine_wait(ctx->ec.sig_out[j & 1]); widener.wait_finished(j - 1); }      // the slot's wire and landing buffers are free
+      k_rebase_offsets<<<64, 256, 0, sc>>>(reinterpret_cast<const uint64_t*>((const char*)(read_off + r0) + off_delta), sl.off.as<uint64_t>(), nr + 1);
+      PackedIn pk{ nullptr, 0, 0 };
+      if (in.packed()) { pk.mask = in.mask ? ctx->in_mask.as<uint64_t>() : nullptr; pk.bias2 = b0 - org2; pk.biasm = b0 - orgm; }
+      FastArgs a;
+      a.d_in = in.packed() ? ctx->in_bases.as<char>() : (const char*)ctx->in_bases.p + b0;
+      a.pk = in.packed() ? &pk : nullptr;
+      a.d_off = sl.off.as<uint64_t>();
+      a.nr = nr; a.nb = nb; a.k = k; a.step = stp; a.rec_base = rec_offset + r0;
+      a.want_sort = want_sort; a.claim_uniform = (flags & PSIGPU_UNIFORM_READS) != 0;
+      a.wf = wire_fmt(nr); a.wire = &sl.d_wire;
+      a.cap = (uint64_t)(ratio * (double)nr) + 4096;
+      a.slot = (int)(j & 1);
+      Pending& pd = pend[j & 1];
+      pd.cap = a.cap; pd.wf = a.wf;
+      return enqueue_default(ctx, a, sc, &pd.serial, &pd.uniform);
+    };
+    if (fast) { int st = enqueue(0); if (st != PSIGPU_OK) return fail(st); }
+    for (size_t i = 0; fast && i < n_sub; ++i) {
+      for (; issued < std::min(n_sub, i + IN_RING); ++issued)
+        if (!issue_in(issued)) { ctx->err = "staging the reads: engine copy failed"; return fail(PSIGPU_ERR_DEVICE); }
+      if (i + 1 < n_sub) { int st = enqueue(i + 1); if (st != PSIGPU_OK) return fail(st); }
+      psigpu_ctx::FastSlot& fs = ctx->fast[i & 1];
+      psigpu_ctx::Slot& sl = ctx->slot[i & 1];
+      if (hipEventSynchronize(fs.done) != hipSuccess) { ctx->err = "hipEventSynchronize"; return fail(PSIGPU_ERR_DEVICE); }
+      const DevCounters& h = *reinterpret_cast<const DevCounters*>(fs.h);
+      const unsigned long long wflag = *reinterpret_cast<const unsigned long long*>((const char*)fs.h + sizeof(DevCounters) + 32);
+      const Pending& pd = pend[i & 1];
+      const uint64_t r0 = cut[i], nr = cut[i + 1] - r0;
+      const uint64_t n = h.n_hits_tab.v;
+      if (h.serial.v != pd.serial) ++ctx->stale_handbacks;
+      if (h.serial.v != pd.serial || (pd.uniform && h.not_uniform.v) || n > pd.cap || (want_sort && h.not_grouped.v) || wflag) {
+        // something the five kernels alone do not settle: this sub-batch and the rest of the chunk the synchronous way
+        if (wflag) ctx->wire8_overflowed = true;
+        if (n > pd.cap) ctx->hits_per_read_hint = std::max(ctx->hits_per_read_hint, (double)n / (double)std::max<uint64_t>(1, nr));
+        ++ctx->lookahead_fallbacks;
+        if (hipStreamSynchronize(sc) != hipSuccess) { ctx->err = "hipStreamSynchronize"; return fail(PSIGPU_ERR_DEVICE); }
+        break;
+      }
+      acc.n_reads += nr; acc.n_seeds += h.n_seeds_true.v; acc.n_seeds_valid += h.n_seeds_valid.total();
+      acc.n_seeds_on_path += h.n_live.total(); acc.n_hits_on_path += h.n_hits_on.v; acc.n_hits_off_path += n - h.n_hits_on.v;
+      acc.n_loci = ctx->n_loci; acc.n_locus_kmers = ctx->fast_off ? ctx->lkt_n_ent : 0; acc.n_path_kmers = ctx->kt_n_path_kmers;
+      acc.ms_locus_table_build = ctx->lkt_build_ms;
+      { float t = 0; (void)hipEventElapsedTime(&t, fs.begin, fs.done); acc.ms_total += t; }
+      acc.sorted_in_place += want_sort ? 1u : 0u;
+      for (int q = 0; q < STRIPES; ++q) ctx->last_max_read_len = std::max<uint64_t>(q ? ctx->last_max_read_len : 0, h.max_read_len.s[q].v);
+      if (n) {
+        if (done + n > out_cap) {
+          const double per_read = (double)(done + n) / (double)(cut[i + 1]);
+          int st = out_reserve(std::max<uint64_t>(done + n, (uint64_t)(per_read * 1.1 * (double)n_reads) + 1024));
+          if (st != PSIGPU_OK) return fail(st);
+        }
+        hipError_t e2 = hipSuccess;
+        if (n * 16 > sl.h_wire_cap) {
+          if (sl.h_wire) (void)hipHostFree(sl.h_wire);
+          sl.h_wire = nullptr; sl.h_wire_cap = 0;
+          const size_t want = n * 16 + n * 4 + 4096;
+          e2 = hipHostMalloc(&sl.h_wire, want, hipHostMallocDefault);
+          if (e2 == hipSuccess) sl.h_wire_cap = want;
+        }
+        if (e2 == hipSuccess && !engine_copy(ctx, false, sl.h_wire, sl.d_wire.p, n * pd.wf.bytes, ctx->ec.sig_out[i & 1])) e2 = hipErrorUnknown;
+        if (e2 != hipSuccess) { ctx->err = std::string("copying the hits out: ") + hipGetErrorString(e2); return fail(PSIGPU_ERR_DEVICE); }
+        widener.post(i, Widener::Job{ sl.h_wire, hp + done, n, ctx->id_base, rec_offset + r0, (int)(i & 1), pd.wf });
+        wire_widest = std::max(wire_widest, pd.wf.bytes);
+        done += n;
+      } else {
+        hsa_signal_store_relaxed(ctx->ec.sig_out[i & 1], 0);
+        widener.post(i, Widener::Job{ nullptr, nullptr, 0, 0, 0, (int)(i & 1), WireFmt{} });
+      }
+      first = i + 1;
+    }
+  }
+  const size_t n_lookahead = first;
+  for (size_t i = first; i < n_sub; ++i) {
     psigpu_ctx::Slot& sl = ctx->slot[i & 1];
     if (use_thread) {
       while (staged.load(std::memory_order_acquire) <= i && stage_err.load() == (int)hipSuccess) std::this_thread::yield();
@@ -5894,6 +6135,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
   if (n_reads) ctx->hits_per_read_hint = std::max(ctx->hits_per_read_hint * 0.9, (double)done / (double)n_reads);
   acc.n_hits = done;
   acc.wire_bytes_per_hit = (wire16 && !host_sort && wire_widest) ? wire_widest : 32u;
+  acc.lookahead_subbatches = (uint32_t)n_lookahead;
   ctx->last = acc;
   if (done == 0) { if (hp) g_pinned.put(hp); hp = nullptr; }
   out->data = hp;
@@ -5933,6 +6175,7 @@ int psigpu_get_counters(const psigpu_ctx* ctx, psigpu_counters* out)
   if (!ctx || !out) return PSIGPU_ERR_ARG;
   *out = ctx->last;
   out->stale_handbacks = ctx->stale_handbacks;
+  out->lookahead_fallbacks = ctx->lookahead_fallbacks;
   return PSIGPU_OK;
 }
 

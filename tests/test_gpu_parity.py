@@ -1475,6 +1475,63 @@ def test_probe_result_formats_agree(query_mode):
         f.close()
 
 
+@pytest.mark.parametrize('query_mode', ['kmer-table'], indirect=True)
+def test_host_entry_with_two_sub_batches_in_flight(query_mode):
+    """The host entry keeps two sub-batches in flight in the default mode when reads and offsets are pinned (the kernels of
+    sub-batch i + 1 are queued before the host waits for sub-batch i: enqueue_default): the answer of the synchronous
+    loop (option no_lookahead), from the second call of a context on; and what the five kernels alone do not settle
+    hands the rest of the chunk to the synchronous loop -- a seed with more hits than the in-place ordering takes (four
+    copies of the paths: duplicates), more hits than the sub-batch's buffer was sized for, a wire field too narrow."""
+    sg = synth.snv_graph(400_000, 12_000, n_block=30_000, seed=3)
+    g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path])
+    bases, off = synth.sim_reads_snv(sg, 6000, 150, seed=4)
+    k = 21
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(1, rng_seed=1)
+    pin = (psi_amd.pinned_copy(bases), psi_amd.pinned_copy(off))
+    src = (pin[0].array, pin[1].array)
+    pk = psi_amd.PackedReads(bases, off, pinned=True)
+    f.set_option('sub_bytes', 60_000)                       # 15 sub-batches
+    f.set_option('no_lookahead', 1)
+    want = f.seeds_all(src, step=k, rec_offset=11, sort_unique=True)
+    want_raw = f.seeds_all(src, step=k, rec_offset=11)
+    assert f.counters()['lookahead_subbatches'] == 0 and len(want) > 6000
+    f.set_option('no_lookahead', 0)
+    for uniform in (False, True):
+        got = f.seeds_all(src, step=k, rec_offset=11, sort_unique=True, uniform=uniform)
+        c = f.counters()
+        assert _eq(got, want) and c['lookahead_subbatches'] >= 10 and c['n_hits'] == len(want) and c['n_reads'] == 6000
+        assert c['n_seeds'] == 6000 * 7
+        raw = f.seeds_all(src, step=k, rec_offset=11, uniform=uniform)
+        assert _eq(raw, want_raw) and f.counters()['lookahead_subbatches'] >= 10
+        flags = psi_amd.ALL | (psi_amd.UNIFORM_READS if uniform else 0)
+        assert _eq(f.seeds_all_packed(pk, step=k, rec_offset=11, sort_unique=True, flags=flags), want)
+        assert f.counters()['lookahead_subbatches'] >= 10
+    assert f.counters()['lookahead_fallbacks'] == 0
+    # a wire field too narrow for some read offset: found when the sub-batch is finished, the chunk goes on synchronously
+    f.set_option('wire8_roff_bits', 5)
+    assert _eq(f.seeds_all(src, step=k, rec_offset=11, sort_unique=True), want)
+    c = f.counters()
+    assert c['lookahead_fallbacks'] == 1 and c['wire_bytes_per_hit'] == 16
+    f.set_option('wire8_roff_bits', 0)
+    assert _eq(f.seeds_all(src, step=k, rec_offset=11, sort_unique=True), want) and f.counters()['lookahead_subbatches'] >= 10
+    # ragged reads claimed to be of one length: refuted on the device, answered the general way
+    rag = np.concatenate([bases[:150 * 3000 - 7], bases[150 * 3000:]])
+    roff = off.copy(); roff[3000:] -= np.uint64(7)
+    rp = (psi_amd.pinned_copy(rag), psi_amd.pinned_copy(roff))
+    w2 = f.seeds_all((rag, roff), step=k, sort_unique=True)
+    assert _eq(f.seeds_all((rp[0].array, rp[1].array), step=k, sort_unique=True, uniform=True), w2)
+    f.close()
+    # duplicates (four full copies of each path): ordering a seed's hits in place is not enough -> the general sort
+    f = psi_amd.SeedFinder(g, k, mode='locus-table')
+    f.create_path_index(4, rng_seed=2)
+    f.set_option('sub_bytes', 60_000)
+    a = f.seeds_all(src, step=k, sort_unique=True)
+    b = f.seeds_all(src, step=k, sort_unique=True)
+    assert _eq(a, b) and f.counters()['lookahead_subbatches'] == 0          # (not the default mode: never the lookahead path)
+    f.close()
+
+
 def test_packed_device_entry_equals_ascii():
     """psigpu_find_seeds_device_packed: the device-resident chunk as 2-bit words."""
     import torch
