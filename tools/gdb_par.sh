@@ -10,7 +10,7 @@ mkdir -p "$ROOT/gpurun_out"
 pids=()
 for i in $(seq 0 $((N-1))); do
   a=$((F + i*1000)); b=$((a + E))
-  ( PSIGPU_SEGV_TRACE=1 FUZZ_TRACE=1 timeout ${FUZZ_TIMEOUT:-400} /opt/rocm/bin/rocgdb -q -batch \
+  ( PSIGPU_SEGV_TRACE=1 FUZZ_TRACE=1 timeout -s INT -k 60 ${FUZZ_TIMEOUT:-400} /opt/rocm/bin/rocgdb -q -batch \
       -ex "handle SIGUSR1 SIGUSR2 SIGPIPE SIGALRM nostop noprint pass" -ex run -ex "echo \n==== ALL THREADS ====\n" \
       -ex "thread apply all bt 30" --args "$PY" "$ROOT/tools/fuzz_modes.py" $a $b > "$ROOT/gpurun_out/gdb_${TAG:-r}_p$i.log" 2>&1 ) &
   pids+=($!)
