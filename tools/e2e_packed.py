@@ -42,7 +42,8 @@ def run(label, reps=15):
         ts.append((time.perf_counter() - t) * 1e3)
     c = f.counters()
     r = {'label': label, 'median_ms': float(np.median(ts)), 'min_ms': min(ts), 'max_ms': max(ts), 'hits': int(n),
-         'device_ms': float(c['ms_total']), 'wire': int(c['wire_bytes_per_hit'])}
+         'device_ms': float(c['ms_total']), 'wire': int(c['wire_bytes_per_hit']), 'lookahead_subbatches': int(c['lookahead_subbatches']),
+         'lookahead_fallbacks': int(c['lookahead_fallbacks'])}
     out.append(r)
     print(json.dumps(r), flush=True)
 
@@ -55,6 +56,10 @@ for w in (16, 32):
     f.set_option('wire', w)
     run('wire %d' % w)
 f.set_option('wire', 0)
+f.set_option('no_lookahead', 1)
+run('one sub-batch at a time (no lookahead)')
+f.set_option('no_lookahead', 0)
+run('two sub-batches in flight (default)')
 f.set_option('no_ahead', 1)
 run('two slots (no transfers queued ahead)')
 f.set_option('no_ahead', 0)
