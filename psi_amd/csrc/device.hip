@@ -3063,6 +3063,7 @@ struct psigpu_ctx {
     hsa_agent_t gpu{}, cpu{};
     uint32_t eng_in = 0, eng_out = 0;            // hsa_amd_sdma_engine_id_t bits
     hsa_signal_t sig_in[IN_RING]{}, sig_out[2]{};      // 1 while the transfer is in flight (two-slot path: sig_in[0..1])
+    hsa_signal_t sig_fast[3]{};                        // ... the transfers out of the lookahead path's three slots
   } ec;
   double hits_per_read_hint = 0.0;
   bool trace_call = false;         // the host-entry call in progress runs under PSIGPU_TRACE
@@ -3071,11 +3072,13 @@ struct psigpu_ctx {
   // sub-batch a hit buffer, a mapped block for its counters and an event.
   uint32_t fast_k = 0, fast_flags = 0;
   bool fast_on = false, fast_off = false;
+  static constexpr int N_FAST = 3;     // (two in the queue + the one whose records are on their way out)
   struct FastSlot {
-    DevBuf hits;
+    DevBuf hits, off, wire;
     void* h = nullptr; void* h_dev = nullptr;
+    void* h_wire = nullptr; size_t h_wire_cap = 0;
     hipEvent_t begin = nullptr, done = nullptr;
-  } fast[2];
+  } fast[N_FAST];
   bool opt_no_lookahead = false;
   uint64_t lookahead_fallbacks = 0;
   void* widener = nullptr;         // the host entry's widening threads (struct Widener, made by its first call)
@@ -3327,14 +3330,17 @@ void psigpu_destroy(psigpu_ctx* ctx)
     if (sl.out_done) (void)hipEventDestroy(sl.out_done);
   }
   for (auto& fs : ctx->fast) {
-    fs.hits.release();
+    fs.hits.release(); fs.off.release(); fs.wire.release();
     if (fs.h) (void)hipHostFree(fs.h);
+    if (fs.h_wire) (void)hipHostFree(fs.h_wire);
     if (fs.begin) (void)hipEventDestroy(fs.begin);
     if (fs.done) (void)hipEventDestroy(fs.done);
   }
   for (hipStream_t st : { ctx->s_in, ctx->s_comp, ctx->s_out }) if (st) (void)hipStreamDestroy(st);
-  for (int i = 0; i < ctx->ec.n_sig; ++i)      // (kept for the next context)
-    g_hsa.give(i < psigpu_ctx::EngineCopy::IN_RING ? ctx->ec.sig_in[i] : ctx->ec.sig_out[i - psigpu_ctx::EngineCopy::IN_RING]);
+  for (int i = 0; i < ctx->ec.n_sig; ++i) {    // (kept for the next context)
+    constexpr int R = psigpu_ctx::EngineCopy::IN_RING;
+    g_hsa.give(i < R ? ctx->ec.sig_in[i] : i < R + 2 ? ctx->ec.sig_out[i - R] : ctx->ec.sig_fast[i - R - 2]);
+  }
   if (ctx->have_events) for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -5508,8 +5514,8 @@ static void engine_copy_init(psigpu_ctx* ctx)
   if (rest == 0) return;                                      // a single engine: nothing to separate
   ec.eng_out = rest & (~rest + 1);
   constexpr int R = psigpu_ctx::EngineCopy::IN_RING;
-  for (int i = 0; i < R + 2; ++i) {
-    if (!g_hsa.take(i < R ? &ec.sig_in[i] : &ec.sig_out[i - R])) return;
+  for (int i = 0; i < R + 5; ++i) {
+    if (!g_hsa.take(i < R ? &ec.sig_in[i] : i < R + 2 ? &ec.sig_out[i - R] : &ec.sig_fast[i - R - 2])) return;
     ec.n_sig = i + 1;
   }
   ec.ok = true;
@@ -5774,7 +5780,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
   auto fail = [&](int st) {
     if (ahead) for (size_t j = 0; j < IN_RING; ++j) engine_wait(ctx->ec.sig_in[j]);      // transfers of reads still queued
     if (wd) wd->wait_finished(wd->posted.load());
-    if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }      // transfers into hp still in flight
+    if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); for (auto& sg : ctx->ec.sig_fast) engine_wait(sg); }      // transfers into hp still in flight
     else if (ctx->s_out) (void)hipStreamSynchronize(ctx->s_out);
     if (hp) g_pinned.put(hp);
     hp = nullptr;
@@ -5783,7 +5789,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
   auto out_reserve = [&](uint64_t want_records) -> int {
     if (want_records <= out_cap) return PSIGPU_OK;
     if (wd) wd->wait_finished(wd->posted.load());
-    if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }
+    if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); for (auto& sg : ctx->ec.sig_fast) engine_wait(sg); }
     else HIPCHK(ctx, hipStreamSynchronize(ctx->s_out));
     const uint64_t cap2 = want_records + want_records / 4 + 4096;
     psigpu_hit* np = (psigpu_hit*)g_pinned.get(cap2 * sizeof(psigpu_hit));
@@ -5823,7 +5829,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     wd = &widener;
     const unsigned hw = std::thread::hardware_concurrency();
     widener.begin(std::max(1u, std::min(8u, hw / 4)), n_sub, [ctx](int slot_) {
-      if (ctx->ec.ok) engine_wait(ctx->ec.sig_out[slot_]);
+      if (ctx->ec.ok) engine_wait(slot_ < 2 ? ctx->ec.sig_out[slot_] : ctx->ec.sig_fast[slot_ - 2]);      // (2 + q: the lookahead path's slot q)
       else { (void)hipSetDevice(ctx->device); (void)hipEventSynchronize(ctx->slot[slot_].out_done); }
     });
   }
@@ -5873,51 +5879,61 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     need(ctx->w_seed_key, (seeds_max + 1) * 8); need(ctx->w_seed_info, (seeds_max + 1) * 8);
     need(ctx->w_seedres, (seeds_max + 16) * 16);
     need(ctx->w_iv_tiles, (WAVES_MAX + 8) * 8); need(ctx->w_iv_tiles_off, (WAVES_MAX + 8) * 8);
-    for (int q = 0; q < 2; ++q) {
+    constexpr int NF = psigpu_ctx::N_FAST;
+    for (int q = 0; q < NF; ++q) {
       psigpu_ctx::FastSlot& fs = ctx->fast[q];
       need(fs.hits, (cap_max + 1) * sizeof(psigpu_hit));
-      need(ctx->slot[q].d_wire, (cap_max + 1) * 16);
-      need(ctx->slot[q].off, (nr_max + 1) * 8);
+      need(fs.wire, (cap_max + 1) * 16);
+      need(fs.off, (nr_max + 1) * 8);
       if (e == hipSuccess && !fs.h) {
         e = hipHostMalloc(&fs.h, sizeof(DevCounters) + 64, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer(&fs.h_dev, fs.h, 0);
         if (e == hipSuccess) e = hipEventCreate(&fs.begin);
         if (e == hipSuccess) e = hipEventCreate(&fs.done);
       }
+      if (e == hipSuccess && cap_max * 16 > fs.h_wire_cap) {
+        if (fs.h_wire) (void)hipHostFree(fs.h_wire);
+        fs.h_wire = nullptr; fs.h_wire_cap = 0;
+        e = hipHostMalloc(&fs.h_wire, cap_max * 16 + 4096, hipHostMallocDefault);
+        if (e == hipSuccess) fs.h_wire_cap = cap_max * 16 + 4096;
+      }
     }
     if (e != hipSuccess || seeds_max >= 0xFFFFFFF0ull) { (void)hipGetLastError(); fast = false; }      // (the synchronous loop reports what is wrong, if anything is)
-    struct Pending { unsigned long long serial; bool uniform; uint64_t cap; WireFmt wf; } pend[2];
+    struct Pending { unsigned long long serial; bool uniform; uint64_t cap; WireFmt wf; } pend[NF];
+    // Sub-batch j goes through slot j % 3: two sub-batches are in the queue while the records of a third are on their way out
+    // (its transfer reads the slot's wire buffer, the widening threads its landing buffer) -- with two slots the kernels of
+    // sub-batch i + 2 had to wait for the transfer of sub-batch i and the arrangement was slower than none (2.5 ms against 1.95).
     auto enqueue = [&](size_t j) -> int {
-      psigpu_ctx::Slot& sl = ctx->slot[j & 1];
+      const int q = (int)(j % NF);
+      psigpu_ctx::FastSlot& fs = ctx->fast[q];
       const uint64_t r0 = cut[j], nr = cut[j + 1] - r0, b0 = read_off[r0], nb = read_off[cut[j + 1]] - b0;
       engine_wait(ctx->ec.sig_in[j % IN_RING]);                 // its reads have landed
-      if (j >= 2) { engine_wait(ctx->ec.sig_out[j & 1]); widener.wait_finished(j - 1); }      // the slot's wire and landing buffers are free
-      k_rebase_offsets<<<64, 256, 0, sc>>>(reinterpret_cast<const uint64_t*>((const char*)(read_off + r0) + off_delta), sl.off.as<uint64_t>(), nr + 1);
+      if (j >= (size_t)NF) { engine_wait(ctx->ec.sig_fast[q]); widener.wait_finished(j - NF + 1); }      // the slot's wire and landing buffers are free
+      k_rebase_offsets<<<64, 256, 0, sc>>>(reinterpret_cast<const uint64_t*>((const char*)(read_off + r0) + off_delta), fs.off.as<uint64_t>(), nr + 1);
       PackedIn pk{ nullptr, 0, 0 };
       if (in.packed()) { pk.mask = in.mask ? ctx->in_mask.as<uint64_t>() : nullptr; pk.bias2 = b0 - org2; pk.biasm = b0 - orgm; }
       FastArgs a;
       a.d_in = in.packed() ? ctx->in_bases.as<char>() : (const char*)ctx->in_bases.p + b0;
       a.pk = in.packed() ? &pk : nullptr;
-      a.d_off = sl.off.as<uint64_t>();
+      a.d_off = fs.off.as<uint64_t>();
       a.nr = nr; a.nb = nb; a.k = k; a.step = stp; a.rec_base = rec_offset + r0;
       a.want_sort = want_sort; a.claim_uniform = (flags & PSIGPU_UNIFORM_READS) != 0;
-      a.wf = wire_fmt(nr); a.wire = &sl.d_wire;
+      a.wf = wire_fmt(nr); a.wire = &fs.wire;
       a.cap = (uint64_t)(ratio * (double)nr) + 4096;
-      a.slot = (int)(j & 1);
-      Pending& pd = pend[j & 1];
+      a.slot = q;
+      Pending& pd = pend[q];
       pd.cap = a.cap; pd.wf = a.wf;
       return enqueue_default(ctx, a, sc, &pd.serial, &pd.uniform);
     };
-    if (fast) { int st = enqueue(0); if (st != PSIGPU_OK) return fail(st); }
+    for (size_t j = 0; fast && j < std::min<size_t>(2, n_sub); ++j) { int st = enqueue(j); if (st != PSIGPU_OK) return fail(st); }
     for (size_t i = 0; fast && i < n_sub; ++i) {
       for (; issued < std::min(n_sub, i + IN_RING); ++issued)
         if (!issue_in(issued)) { ctx->err = "staging the reads: engine copy failed"; return fail(PSIGPU_ERR_DEVICE); }
-      if (i + 1 < n_sub) { int st = enqueue(i + 1); if (st != PSIGPU_OK) return fail(st); }
-      psigpu_ctx::FastSlot& fs = ctx->fast[i & 1];
-      psigpu_ctx::Slot& sl = ctx->slot[i & 1];
+      const int q = (int)(i % NF);
+      psigpu_ctx::FastSlot& fs = ctx->fast[q];
       {
         // (not hipEventSynchronize: with more work queued behind the event the runtime waits for a marker it appends to the
-        // stream -- i.e. for sub-batch i + 1 as well -- which undoes the arrangement: 3.4 ms per chunk against 2.3)
+        // stream -- i.e. for the next sub-batch as well -- which undoes the arrangement)
         hipError_t qe;
         uint32_t spins = 0;
         while ((qe = hipEventQuery(fs.done)) == hipErrorNotReady) { if (++spins > 2000) std::this_thread::yield(); }
@@ -5925,7 +5941,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
       }
       const DevCounters& h = *reinterpret_cast<const DevCounters*>(fs.h);
       const unsigned long long wflag = *reinterpret_cast<const unsigned long long*>((const char*)fs.h + sizeof(DevCounters) + 32);
-      const Pending& pd = pend[i & 1];
+      const Pending& pd = pend[q];
       const uint64_t r0 = cut[i], nr = cut[i + 1] - r0;
       const uint64_t n = h.n_hits_tab.v;
       if (h.serial.v != pd.serial) ++ctx->stale_handbacks;
@@ -5943,31 +5959,24 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
       acc.ms_locus_table_build = ctx->lkt_build_ms;
       { float t = 0; (void)hipEventElapsedTime(&t, fs.begin, fs.done); acc.ms_total += t; }
       acc.sorted_in_place += want_sort ? 1u : 0u;
-      for (int q = 0; q < STRIPES; ++q) ctx->last_max_read_len = std::max<uint64_t>(q ? ctx->last_max_read_len : 0, h.max_read_len.s[q].v);
       if (n) {
         if (done + n > out_cap) {
           const double per_read = (double)(done + n) / (double)(cut[i + 1]);
           int st = out_reserve(std::max<uint64_t>(done + n, (uint64_t)(per_read * 1.1 * (double)n_reads) + 1024));
           if (st != PSIGPU_OK) return fail(st);
         }
-        hipError_t e2 = hipSuccess;
-        if (n * 16 > sl.h_wire_cap) {
-          if (sl.h_wire) (void)hipHostFree(sl.h_wire);
-          sl.h_wire = nullptr; sl.h_wire_cap = 0;
-          const size_t want = n * 16 + n * 4 + 4096;
-          e2 = hipHostMalloc(&sl.h_wire, want, hipHostMallocDefault);
-          if (e2 == hipSuccess) sl.h_wire_cap = want;
+        if (!engine_copy(ctx, false, fs.h_wire, fs.wire.p, n * pd.wf.bytes, ctx->ec.sig_fast[q])) {
+          ctx->err = "copying the hits out: engine copy failed"; return fail(PSIGPU_ERR_DEVICE);
         }
-        if (e2 == hipSuccess && !engine_copy(ctx, false, sl.h_wire, sl.d_wire.p, n * pd.wf.bytes, ctx->ec.sig_out[i & 1])) e2 = hipErrorUnknown;
-        if (e2 != hipSuccess) { ctx->err = std::string("copying the hits out: ") + hipGetErrorString(e2); return fail(PSIGPU_ERR_DEVICE); }
-        widener.post(i, Widener::Job{ sl.h_wire, hp + done, n, ctx->id_base, rec_offset + r0, (int)(i & 1), pd.wf });
+        widener.post(i, Widener::Job{ fs.h_wire, hp + done, n, ctx->id_base, rec_offset + r0, 2 + q, pd.wf });
         wire_widest = std::max(wire_widest, pd.wf.bytes);
         done += n;
       } else {
-        hsa_signal_store_relaxed(ctx->ec.sig_out[i & 1], 0);
-        widener.post(i, Widener::Job{ nullptr, nullptr, 0, 0, 0, (int)(i & 1), WireFmt{} });
+        hsa_signal_store_relaxed(ctx->ec.sig_fast[q], 0);
+        widener.post(i, Widener::Job{ nullptr, nullptr, 0, 0, 0, 2 + q, WireFmt{} });
       }
       first = i + 1;
+      if (i + 2 < n_sub) { int st = enqueue(i + 2); if (st != PSIGPU_OK) return fail(st); }
     }
   }
   const size_t n_lookahead = first;
@@ -6112,7 +6121,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     acc.search_launches += pc.search_launches; acc.traverse_launches += pc.traverse_launches;
     acc.sorted_in_place += ctx->last.sorted_in_place;
   }
-  if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); }
+  if (ctx->ec.ok) { engine_wait(ctx->ec.sig_out[0]); engine_wait(ctx->ec.sig_out[1]); for (auto& sg : ctx->ec.sig_fast) engine_wait(sg); }
   else if (hipStreamSynchronize(ctx->s_out) != hipSuccess) { ctx->err = "hipStreamSynchronize (copy-out stream)"; return fail(PSIGPU_ERR_DEVICE); }
   if (wire16) widener.wait_finished(n_sub);
   if (trace) {
