@@ -63,6 +63,19 @@ run('two sub-batches in flight (default)')
 f.set_option('no_ahead', 1)
 run('two slots (no transfers queued ahead)')
 f.set_option('no_ahead', 0)
+# the two loops ALTERNATED call by call (the boxes are shared: a variant measured a second later meets another machine)
+ab = {0: [], 1: []}
+for i in range(240):
+    v = i & 1
+    f.set_option('no_lookahead', v)
+    t = time.perf_counter()
+    assert L.psigpu_find_seeds_packed(*calls[(i >> 1) % 2]) == 0
+    L.psigpu_free_hits(C.byref(hits))
+    if i >= 40:
+        ab[v].append((time.perf_counter() - t) * 1e3)
+f.set_option('no_lookahead', 0)
+print(json.dumps({'label': 'alternated, 100 calls each', 'two_in_flight_median_ms': float(np.median(ab[0])), 'two_in_flight_min_ms': min(ab[0]),
+                  'one_at_a_time_median_ms': float(np.median(ab[1])), 'one_at_a_time_min_ms': min(ab[1])}), flush=True)
 if os.environ.get('E2E_TRACE'):
     os.environ['PSIGPU_TRACE'] = '1'
     L.psigpu_find_seeds_packed(*calls[0]); L.psigpu_free_hits(C.byref(hits))
