@@ -366,18 +366,35 @@ def main():
                                          if wg else 'chr22 weak scaling (%s)' % wg_note))
     if wg:
         from psi_amd import shared
+        failed_mark = os.path.join(wg['dir'], 'build_failed')
         if rank == 0 and not wg['cached']:
-            wg_times = wg_build_and_export(wg, args, local_rank)
-            log('whole-genome set-up on rank 0: graph %.0f s, index %.0f s, export %.0f s' %
-                (wg_times['graph_s'], wg_times['index_build_s'], wg_times['export_s']))
+            try:
+                if os.path.exists(failed_mark):
+                    os.remove(failed_mark)
+                wg_times = wg_build_and_export(wg, args, local_rank)
+                log('whole-genome set-up on rank 0: graph %.0f s, index %.0f s, export %.0f s' %
+                    (wg_times['graph_s'], wg_times['index_build_s'], wg_times['export_s']))
+            except BaseException as ex:           # (memory, disk: every rank then takes the chr22 workload instead of waiting for nothing)
+                log('whole-genome set-up failed on rank 0 (%s: %s): falling back to configs[1] weak scaling' % (type(ex).__name__, ex))
+                try:
+                    os.makedirs(wg['dir'], exist_ok=True)
+                    open(failed_mark, 'w').write(repr(ex))
+                except OSError:
+                    pass
         # (the others wait for the manifest, not inside a collective: the build takes minutes)
         t_wait = time.time()
-        while not os.path.exists(os.path.join(wg['dir'], 'manifest.json')):
-            if time.time() - t_wait > 3000:
-                log('rank %d: gave up waiting for the shared index' % rank)
-                sys.exit(4)
+        while not os.path.exists(os.path.join(wg['dir'], 'manifest.json')) and not os.path.exists(failed_mark):
+            if time.time() - t_wait > 1500:
+                break
             time.sleep(0.5)
-        dist.barrier()
+        ok_here = os.path.exists(os.path.join(wg['dir'], 'manifest.json')) and not os.path.exists(failed_mark)
+        okt = torch.tensor([1 if ok_here else 0], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if not int(okt.item()):
+            wg_note = 'the whole-genome set-up failed or timed out on this host'
+            wg = None
+    if wg:
+        from psi_amd import shared
         g, px, extra = shared.import_views(wg['dir'])
         sg = SimArrays(wg['dir'], int(extra.get('n_block', 0)))
         args.reads = wg['reads_per_gpu']
