@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_PEAK_GBS = 63.0           # PCIe Gen5 x16, one direction (64 GT/s x 16 lanes, 128b/130b)
 BLOCK = 64                     # bytes per rank block / HBM sector
-PROFILE_ROUND = 'r03'
+PROFILE_ROUND = 'r04'
 TRAFFIC_FILES = {'kmer-table': '%s_k_traffic.json', 'locus-table': '%s_l_traffic.json', 'traverse': '%s_t_traffic.json',
                  # the fm-lf series (tools/profile.sh f1 / f2 / f3): locus-table mode with the LF kernels doing the work
                  'fm-lf/after_ftab': '%s_f1_traffic.json', 'fm-lf/no_ftab': '%s_f2_traffic.json',
@@ -545,10 +545,11 @@ def main():
             pl = tj.get('per_launch', {})
             # (a bench "kernel" may be several launches: the walk and the per-hit resolve of a sampled suffix array; the
             # partition and the per-bucket build of the chunk's seed table)
-            names = {'k_fm_locate': [['k_kmer_emit'], ['k_fm_locate_direct'], ['k_fm_walk', 'k_hits_resolve']],
+            names = {'k_fm_locate': [['void k_kmer_emit<true'], ['void k_kmer_emit<false'], ['k_kmer_emit'], ['k_fm_locate_direct'], ['k_fm_walk', 'k_hits_resolve']],
                      'k_fm_search': [['k_fm_search_direct'], ['void k_fm_search<false']],
                      'k_traverse': [['void k_traverse<false']],
-                     'k_seed_pack': [['k_seed_pack']],
+                     'k_kmer_probe': [['void k_kmer_probe<true'], ['void k_kmer_probe<false'], ['k_kmer_probe']],
+                     'k_seed_pack': [['void k_seed_pack<false, false, true'], ['void k_seed_pack<false, false, false'], ['k_seed_pack']],
                      'k_table_insert': [['k_sb_count', 'k_sb_scatter', 'k_sb_build']]}.get(dom, [[dom]])
             tot = lambda t: t.get('fetch_size_bytes', 0.0) + t.get('write_size_bytes', 0.0)      # noqa: E731
             find = lambda pre: next((kn for kn in pl if kn == pre or kn.startswith(pre + ',') or kn.startswith(pre + '>')), None)   # noqa: E731
