@@ -63,9 +63,9 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
         return 2.0 * (16 + 4) * c['n_seeds_valid']
     if kernel == 'k_fm_locate':
         if c['n_path_kmers']:
-            # k-mer table mode: K2 is a stream -- 16 bytes of probe results + 8 bytes of (read, offset)
+            # k-mer table mode: K2 is a stream -- 8 bytes of probe results (round 4; 16 before) + 8 bytes of (read, offset)
             # in per seed, one 32-byte record out per hit (positions were inline in the slots)
-            return 24.0 * c['n_seeds'] + 32.0 * (c['n_hits_on_path'] + c.get('n_hits_table', 0))      # (the traverser writes its own records)
+            return 16.0 * c['n_seeds'] + 32.0 * (c['n_hits_on_path'] + c.get('n_hits_table', 0))      # (the traverser writes its own records)
         # SA-order sampling at rate s: expected s-1 LF steps (one block each) + the 4-byte
         # sample, two 64-byte segment-table probes, one 32-byte record out; hits that come from the
         # locus k-mer table: one 16-byte entry in, one 32-byte record out
@@ -80,8 +80,9 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
         # the fraction came out above 1.)
         return 20.0 * c['n_seeds'] + (8 + 32.0) * c['n_hits_on_path'] + (16 + 32.0) * c['n_hits_table']
     if kernel in ('k_kmer_probe', 'k_lkt_probe'):
-        # per seed its 8-byte key in and 16 bytes of results out to K2; per N-free seed one 16-byte slot in
-        return (8 + 16.0) * c['n_seeds'] + 16.0 * c['n_seeds_valid']
+        # per seed its 8-byte key in and 8 bytes of results out to K2 (round 4; 16 before: the fraction is of FEWER bytes now);
+        # per N-free seed one 16-byte slot in
+        return (8 + (8.0 if kernel == 'k_kmer_probe' else 16.0)) * c['n_seeds'] + 16.0 * c['n_seeds_valid']
     if kernel == 'k_seed_pack':
         # each seed's k bytes of bases in, 8-byte key + 8-byte (read, offset) out
         return (k + 16.0) * c['n_seeds']
