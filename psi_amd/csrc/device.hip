@@ -3081,6 +3081,7 @@ struct psigpu_ctx {
   } fast[N_FAST];
   bool opt_no_lookahead = false;
   uint64_t lookahead_fallbacks = 0;
+  void* stager = nullptr;          // the host entry's helper thread for pageable reads (struct Worker)
   void* widener = nullptr;         // the host entry's widening threads (struct Widener, made by its first call)
   // psigpu_set_option
   uint64_t opt_sub_bytes = 0;
@@ -5345,6 +5346,48 @@ static inline void store_hit(psigpu_hit* dst, uint64_t node, uint64_t noff, uint
   __builtin_nontemporal_store(hi, reinterpret_cast<v2*>(dst) + 1);
 }
 
+// One helper thread that lives with the context and runs one job at a time (the stager of pageable reads: a call used to
+// start and join a thread of its own).
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  std::function<void()> job;
+  bool has = false, busy = false, quit = false;
+  void run(std::function<void()> f)
+  {
+    { std::lock_guard<std::mutex> lk(mu); job = std::move(f); has = true; busy = true; }
+    if (!th.joinable()) th = std::thread([this] { loop(); });
+    cv.notify_one();
+  }
+  void wait()                                   // the job, if any, has returned
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return !busy; });
+  }
+  void loop()
+  {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return quit || has; });
+        if (quit) return;
+        f = std::move(job); has = false;
+      }
+      f();
+      { std::lock_guard<std::mutex> lk(mu); busy = false; }
+      cv_done.notify_all();
+    }
+  }
+  ~Worker()
+  {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+
 struct Widener {
   struct Job { const void* src; psigpu_hit* dst; uint64_t n, id_base, rec_base; int slot; WireFmt fmt; };
   // The threads live as long as the context (round 4: a call used to start and join up to eight threads of its own,
@@ -5463,6 +5506,8 @@ static void widener_destroy(psigpu_ctx* ctx)
 {
   delete static_cast<Widener*>(ctx->widener);
   ctx->widener = nullptr;
+  delete static_cast<Worker*>(ctx->stager);
+  ctx->stager = nullptr;
 }
 
 // Streams and events of the host entry's pipeline, made on its first call.
@@ -5754,10 +5799,11 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
   std::atomic<size_t> staged{ 0 }, consumed{ 0 };
   std::atomic<int> stage_err{ (int)hipSuccess };
   std::atomic<bool> stop{ false };
-  std::thread stager;
   const bool use_thread = !pinned_in && n_sub > 1;
+  if (use_thread && !ctx->stager) ctx->stager = new Worker;
+  Worker* stager = static_cast<Worker*>(ctx->stager);
   if (use_thread) {
-    stager = std::thread([&] {
+    stager->run([&] {
       if (hipSetDevice(ctx->device) != hipSuccess) { stage_err = (int)hipErrorInvalidDevice; return; }
       for (size_t j = 0; j < n_sub && !stop; ++j) {
         while (j >= consumed.load(std::memory_order_acquire) + 2 && !stop) std::this_thread::yield();
@@ -5768,10 +5814,10 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
       }
     });
   }
-  struct Joiner {
-    std::thread& t; std::atomic<bool>& stop;
-    ~Joiner() { stop = true; if (t.joinable()) t.join(); }
-  } joiner{ stager, stop };
+  struct Joiner {                                   // (every way out: the helper has left the call's buffers)
+    Worker* w; bool used; std::atomic<bool>& stop;
+    ~Joiner() { stop = true; if (used && w) w->wait(); }
+  } joiner{ stager, use_thread, stop };
 
   // output: pinned, sized from what earlier calls produced per read; regrown when a chunk has more
   uint64_t out_cap = 0, done = 0;
