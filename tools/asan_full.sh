@@ -5,7 +5,7 @@
 # not offer (every device allocation then fails); the instrumentation clang emits for the host half of the .hip files
 # speaks the same runtime interface (v8).  Device code is NOT instrumented (-fno-gpu-sanitize).
 #   bash tools/asan_full.sh          builds asan_build/libpsi_gpu_asan.so + asan_build/libpsi_oracle.so   (no GPU needed)
-#   on the GPU box:  bash tools/asan_run.sh python tools/fuzz_modes.py A B
+#   on the GPU box:  bash tools/asan_full.sh && bash tools/asan_run.sh python tools/fuzz_modes.py A B   (asan_build/ is not shipped)
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/asan_build"
