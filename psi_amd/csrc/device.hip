@@ -805,8 +805,7 @@ k_sb_build(const ulonglong2* __restrict__ brec, const uint64_t* __restrict__ off
   TableSlot* t = in_lds ? tab : region;
   const uint32_t sh = 2 * (sb.k - pfx_len);
   const uint32_t sub_mask = (1u << (2 * sub)) - 1u;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    const ulonglong2 rec = brec[lo + i];
+  auto insert = [&](const ulonglong2 rec) {
     const uint64_t key = rec.x;
     const uint32_t s = (uint32_t)rec.y;
     const uint32_t pf = (uint32_t)(key >> sh) & sub_mask;
@@ -818,7 +817,22 @@ k_sb_build(const ulonglong2* __restrict__ brec, const uint64_t* __restrict__ off
       if (prev == key) { seed_next[s] = atomicExch(&t[h].dup, s); break; }
       h = h + 1 < m ? h + 1 : 0;
     }
-  }
+  };
+  if (in_lds) {
+    // a bucket that fits LDS has at most 2048 records: eight per thread, all requested before the first is inserted (one
+    // memory latency per workgroup instead of one per record: the loop of loads behind atomics was 7 latencies deep and the
+    // kernel, two workgroups per CU, waited for them: 0.154 -> 0.1x ms)
+    ulonglong2 r[SB_LDS_SLOTS / 2 / 256];
+#pragma unroll
+    for (uint32_t j = 0; j < SB_LDS_SLOTS / 2 / 256; ++j) {
+      const uint32_t i = threadIdx.x + 256 * j;
+      r[j] = i < n ? brec[lo + i] : make_ulonglong2(KEY_INVALID, 0);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < SB_LDS_SLOTS / 2 / 256; ++j)
+      if (threadIdx.x + 256 * j < n) insert(r[j]);
+  } else
+  for (uint32_t i = threadIdx.x; i < n; i += 256) insert(brec[lo + i]);
   __syncthreads();
   if (in_lds) {
     const uint4* src = reinterpret_cast<const uint4*>(tab);
