@@ -50,10 +50,10 @@ def main():
             npaths = rng.choice([0, 1, 1, 2, 3, 5])
             patched = npaths > 1 and rng.random() < 0.6
             want = np.array(brute.hit_set(g, [r.upper() for r in reads], k, step), dtype=np.uint64).reshape(-1, 4)
-            px = psi_amd.PathIndex.build(pg, k, npaths, rng_seed=seed, sa_rate=rng.choice([1, 1, 1, 2, 8]),
-                                         ftab_len=rng.choice([0, 0, 4, psi_amd.NO_FTAB]),
-                                         device=rng.choice([None, 0]), patched=patched,
-                                         context=rng.choice([0, k, k + 1, k + 7]) if patched else 0)
+            bargs = dict(rng_seed=seed, sa_rate=rng.choice([1, 1, 1, 2, 8]), ftab_len=rng.choice([0, 0, 4, psi_amd.NO_FTAB]),
+                         device=rng.choice([None, 0]), patched=patched,
+                         context=rng.choice([0, k, k + 1, k + 7]) if patched else 0)
+            px = psi_amd.PathIndex.build(pg, k, npaths, **bargs)
             # starting loci = brute-force definition over the trimmed paths (acyclic graphs only: the
             # brute force lists walks, the product's candidate sets handle repeats on their own)
             paths_ids = [[g.ids[r] for r in p] for p in px.paths()]
@@ -122,6 +122,24 @@ def main():
                         f3.set_path_index(px)
                         fresh = psi_amd.sort_unique(f3.seeds_all(reads, step=step))
                         print(' new finder:', 'ok' if (fresh.shape == want.shape and (fresh == want).all()) else 'WRONG TOO', flush=True)
+                        # what the finder was given: the index built again (same place, then on the host), its loci compared
+                        for dev in (bargs['device'], None):
+                            px2 = psi_amd.PathIndex.build(pg, k, npaths, **dict(bargs, device=dev))
+                            same_loci = all(bool((a == b).all()) if a.shape == b.shape else False for a, b in zip(px.loci, px2.loci))
+                            for o in ((), (('no_pfx_roots', 1),)):
+                                f4 = psi_amd.SeedFinder(pg, k, mode=mode, walk_cap=cap)
+                                for n_, v_ in o:
+                                    f4.set_option(n_, v_)
+                                f4.set_path_index(px2)
+                                r4 = psi_amd.sort_unique(f4.seeds_all(reads, step=step))
+                                print(' index rebuilt on', dev, o, '| loci equal to the first:', same_loci, '| result:',
+                                      'ok' if (r4.shape == want.shape and (r4 == want).all()) else 'WRONG', flush=True)
+                                f4.close()
+                        f5 = psi_amd.SeedFinder(pg, k, mode=mode, walk_cap=cap)
+                        f5.set_option('no_pfx_roots', 1)
+                        f5.set_path_index(px)
+                        r5 = psi_amd.sort_unique(f5.seeds_all(reads, step=step))
+                        print(' first index, no prefix roots:', 'ok' if (r5.shape == want.shape and (r5 == want).all()) else 'WRONG', flush=True)
                         sys.exit(1)
                     if rng.random() < 0.5 and k <= 31:      # (the oracle's k-mers are one word)
                         # psikt -r T over BOTH phases against the oracle's seeds_all( gocc_thr = T ): on-path k-mers
