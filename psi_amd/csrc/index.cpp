@@ -712,6 +712,49 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
     find_starting_loci(g, paths, x->path_head, x->path_tail, k, step, x->loci_node, x->loci_off);
   }
   lap("starting loci");
+  // PSIGPU_BUILD_VERIFY=1 (load campaigns: tools/fuzz_par.sh): what the device made is made again on the host and
+  // compared array by array -- a build that differs fails, naming the array and the first place, instead of
+  // surfacing later as a hit set that is one record short
+  if (opts.build_on_device && getenv("PSIGPU_BUILD_VERIFY")) {
+    std::string what;
+    auto differ = [&](const char* name, const void* a, size_t na, const void* b, size_t nb, size_t elem) {
+      if (!what.empty()) return;
+      if (na != nb) { what = std::string(name) + ": " + std::to_string(na) + " against " + std::to_string(nb) + " elements on the host"; return; }
+      if (na == 0 || memcmp(a, b, na * elem) == 0) return;
+      size_t i = 0;
+      while (memcmp((const char*)a + i * elem, (const char*)b + i * elem, elem) == 0) ++i;
+      what = std::string(name) + " differs from the host's at element " + std::to_string(i) + " of " + std::to_string(na);
+    };
+    psigpu_index_opts ho = opts;
+    ho.build_on_device = 0;
+    for (size_t pt = 0; pt < n_parts && what.empty(); ++pt) {
+      Index h;
+      const Index& d = pt ? x->more[pt - 1] : *x;
+      std::string herr;
+      if (build_part(g, ho, sa_rate, false, paths, x->path_head, x->path_tail, cuts[pt], cuts[pt + 1], &h, &herr) != PSIGPU_OK) {
+        what = "host build of the part failed: " + herr;      // (e.g. a text the host suffix sorter cannot take)
+        break;
+      }
+      differ("rank blocks", d.blocks.data(), d.blocks.size(), h.blocks.data(), h.blocks.size(), sizeof(RankBlock));
+      differ("suffix array samples", d.samples.data(), d.samples.size(), h.samples.data(), h.samples.size(), 4);
+      differ("exception rows", d.exc_row.data(), d.exc_row.size(), h.exc_row.data(), h.exc_row.size(), 4);
+      differ("exception positions", d.exc_sa.data(), d.exc_sa.size(), h.exc_sa.data(), h.exc_sa.size(), 4);
+      differ("exception super-block counts", d.exc_super.data(), d.exc_super.size(), h.exc_super.data(), h.exc_super.size(), 4);
+      differ("interval table", d.ftab.data(), d.ftab.size(), h.ftab.data(), h.ftab.size(), 4);
+      differ("4-bit text", d.text4.data(), d.text4.size(), h.text4.data(), h.text4.size(), 8);
+      differ("C", d.C, 4, h.C, 4, 8);
+    }
+    if (what.empty()) {
+      std::vector<uint32_t> hn, hoff;
+      find_starting_loci(g, paths, x->path_head, x->path_tail, k, step, hn, hoff);
+      differ("starting loci (node)", x->loci_node.data(), x->loci_node.size(), hn.data(), hn.size(), 4);
+      differ("starting loci (offset)", x->loci_off.data(), x->loci_off.size(), hoff.data(), hoff.size(), 4);
+    }
+    if (!what.empty()) {
+      fprintf(stderr, "[psigpu] PSIGPU_BUILD_VERIFY: device index build: %s\n", what.c_str());
+      *status = PSIGPU_ERR_DEVICE; *err = "device index build failed verification: " + what; delete x; return nullptr;
+    }
+  }
   *status = PSIGPU_OK;
   return x;
 }

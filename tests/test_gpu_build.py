@@ -104,3 +104,15 @@ def test_device_build_at_scale_and_queries():
     b = psi_amd.sort_unique(f.seeds_all((bases, off)))
     assert a.shape == b.shape and (a == b).all() and len(a) > 100_000
     f.close()
+
+
+def test_device_build_verified_against_the_host(monkeypatch):
+    """PSIGPU_BUILD_VERIFY (the load campaigns' switch): the device build made again on the host inside the library and
+    compared array by array; a build that passes is the one a plain device build returns."""
+    g = psi_amd.Graph.load(os.path.join(REF, 'm.gfa'))
+    plain = psi_amd.PathIndex.build(g, 21, 3, rng_seed=5, device=0)
+    monkeypatch.setenv('PSIGPU_BUILD_VERIFY', '1')
+    checked = psi_amd.PathIndex.build(g, 21, 3, rng_seed=5, device=0)
+    _same_index(plain, checked)
+    parts = psi_amd.PathIndex.build(g, 21, 3, rng_seed=5, device=0, max_part_text=int(plain.text_len) // 2 + 40)
+    assert parts.view.n_more_parts >= 1

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 pids=()
 for i in $(seq 0 $((N-1))); do
   a=$((F + i*1000)); b=$((a + E))
-  PSIGPU_SEGV_TRACE=1 FUZZ_TRACE=1 timeout ${FUZZ_TIMEOUT:-400} python tools/fuzz_modes.py $a $b > gpurun_out/fuzz_${TAG:-r}_p$i.log 2>&1 &
+  PSIGPU_BUILD_VERIFY=${PSIGPU_BUILD_VERIFY-1} PSIGPU_SEGV_TRACE=1 FUZZ_TRACE=1 timeout ${FUZZ_TIMEOUT:-400} python tools/fuzz_modes.py $a $b > gpurun_out/fuzz_${TAG:-r}_p$i.log 2>&1 &
   pids+=($!)
 done
 rc=0
