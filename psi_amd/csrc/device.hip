@@ -173,6 +173,18 @@ typedef TravItemT<uint64_t> TravItem;
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// A 16-byte record is ONE load.  Left alone, the compiler fetches the field a branch tests first and the rest of the record
+// behind the branch (k_kmer_probe: global_load_dwordx3 + a dependent global_load_dword per look; k_traverse: the node
+// record's meta word by a flat load, its bases and edge by a second): two memory latencies in a row per record where
+// one request brings the sector.  The empty asm makes all four words live at the point of the load.
+__device__ __forceinline__ void keep_whole(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ uint4 load16(const void* p)
+{
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  keep_whole(v);
+  return v;
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt()
 {
   return (1ull << lane_id()) - 1ull;
@@ -1741,14 +1753,14 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
       uint64_t h = kt_home(key, kt.n_slots);
       uint32_t t = 0;
       while (true) {
-        const uint4 v = *reinterpret_cast<const uint4*>(kt.ht + h);
+        const uint4 v = load16(kt.ht + h);
         const uint64_t w = (uint64_t)v.x | ((uint64_t)v.y << 32);
         const bool empty = v.z == NIL && v.w == NIL;          // (an all-T 31-mer with an EXT record is all ones in w)
         if (!empty && (w & K16_KEY) == key) {
           const uint64_t type = w >> 62;
           res.x = v.z; res.y = v.w;
           if (type == K16_EXT) {
-            const uint4 e = reinterpret_cast<const uint4*>(kt.ext + v.z)[1];      // off_a, off_b, on_cnt, off_cnt
+            const uint4 e = load16(reinterpret_cast<const uint4*>(kt.ext + v.z) + 1);      // off_a, off_b, on_cnt, off_cnt
             const uint2 cc = ext_counts(e, want_on, want_off, gocc_thr);
             res.z = RES_EXT | cc.x;
             res.w = cc.y;
@@ -2454,7 +2466,8 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
       const TableSlot* region = tb.ht + 2ull * lo;
       uint32_t h = sb_home(tkey, m);
       while (true) {
-        TableSlot sl = region[h];
+        const uint4 raw = load16(region + h);
+        TableSlot sl = { (unsigned long long)raw.x | ((unsigned long long)raw.y << 32), raw.z, raw.w };
         if (sl.key == tkey) { s = sl.val; dup = sl.dup; break; }
         if (sl.key == KEY_INVALID) break;
         h = h + 1 < m ? h + 1 : 0;
@@ -2589,7 +2602,10 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
     bool done = false;
     if (have) {
       uint32_t widx = it.node - wb;                                     // wraps above the window
-      NodeLite nl = widx < win_n ? window[widx] : g.lite[it.node];
+      uint4 nlw;                                                        // (one 16-byte read from either place)
+      if (widx < win_n) nlw = *reinterpret_cast<const uint4*>(&window[widx]); else nlw = *reinterpret_cast<const uint4*>(&g.lite[it.node]);
+      keep_whole(nlw);
+      NodeLite nl = { (uint64_t)nlw.x | ((uint64_t)nlw.y << 32), nlw.z, nlw.w };
       uint32_t depth = hibit(it.kmer) >> 1;
       KEY b = 0;
       uint32_t take, e1 = 0, coff = 0;
