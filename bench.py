@@ -48,7 +48,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
+def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0, implicit_info=False):
     """Algorithmic bytes one launch needs (DESIGN.md section 5): SURVEY.md 8(d)'s per-unit figures;
     for K1 the work the interval table / text verification replace is priced as what replaces it."""
     if kernel == 'k_fm_search':
@@ -65,7 +65,8 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
         if c['n_path_kmers']:
             # k-mer table mode: K2 is a stream -- 8 bytes of probe results (round 4; 16 before) + 8 bytes of (read, offset)
             # in per seed, one 32-byte record out per hit (positions were inline in the slots)
-            return 16.0 * c['n_seeds'] + 32.0 * (c['n_hits_on_path'] + c.get('n_hits_table', 0))      # (the traverser writes its own records)
+            # (equal read lengths answered from the table alone: no (read, offset) array -- 8 bytes in per seed)
+            return (8.0 if implicit_info else 16.0) * c['n_seeds'] + 32.0 * (c['n_hits_on_path'] + c.get('n_hits_table', 0))      # (the traverser writes its own records)
         # SA-order sampling at rate s: expected s-1 LF steps (one block each) + the 4-byte
         # sample, two 64-byte segment-table probes, one 32-byte record out; hits that come from the
         # locus k-mer table: one 16-byte entry in, one 32-byte record out
@@ -84,8 +85,8 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0):
         # per N-free seed one 16-byte slot in
         return (8 + (8.0 if kernel == 'k_kmer_probe' else 16.0)) * c['n_seeds'] + 16.0 * c['n_seeds_valid']
     if kernel == 'k_seed_pack':
-        # each seed's k bytes of bases in, 8-byte key + 8-byte (read, offset) out
-        return (k + 16.0) * c['n_seeds']
+        # each seed's k bytes of bases in, 8-byte key + 8-byte (read, offset) out (no (read, offset) when it is implicit)
+        return (k + (8.0 if implicit_info else 16.0)) * c['n_seeds']
     if kernel == 'k_traverse':
         # per k-walk from a starting locus (a launch resolves all of them, most by pruning):
         # ceil(k/4) label bytes + 4 per edge list touched + 16-byte seed-table probe (32 B at
@@ -534,7 +535,7 @@ def main():
         ix = ix or px
         dom = kernel or max(kern, key=lambda n: kern[n])
         avg_ms = kern[dom] / steps
-        abytes = algorithmic_bytes(dom, c, k, int(ix.view.sa_rate), int(ix.view.ftab_len))
+        abytes = algorithmic_bytes(dom, c, k, int(ix.view.sa_rate), int(ix.view.ftab_len), implicit_info=bool(uni) and mode == 'kmer-table')
         achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM-side traffic per launch from separate rocprofv3 --pmc passes over this same command
         # (tools/profile.sh -> profiles/<round>_*_traffic.json, committed); null when not collected

@@ -502,6 +502,8 @@ k_seed_scan_final(const uint64_t* __restrict__ read_off, uint64_t n, uint32_t k,
   }
 }
 
+static const bool env_plain_stores = getenv("PSIGPU_PLAIN_STORES") != nullptr;      // A/B: k_kmer_emit without the transposed record stores
+
 // PSIGPU_UNIFORM_READS: every read has the same length, so a seed's read and offset follow from its number -- no scan of
 // the reads' seed counts, no per-seed search for the owning read.  The first kernel of such a call: the counters zeroed,
 // the call's serial number, the seed count and the longest read where the scan kernels would have left them.
@@ -666,7 +668,7 @@ k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
         seed_key[s] = ok ? table_key(key) : KEY_INVALID;
       } else
       seed_key[s] = ok ? key : KEY_INVALID;
-      seed_info[s] = make_uint2((uint32_t)lo[0], (uint32_t)st[0]);
+      if (!UNIFORM || seed_info) seed_info[s] = make_uint2((uint32_t)lo[0], (uint32_t)st[0]);
       nok += ok;
       continue;
     }
@@ -709,7 +711,8 @@ k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
         seed_key[s] = ok ? table_key(key) : KEY_INVALID;
       } else
       seed_key[s] = ok ? key : KEY_INVALID;
-      seed_info[s] = make_uint2((uint32_t)lo[j], (uint32_t)st[j]);     // (read, offset in read)
+      // (UNIFORM, answered from the k-mer table alone: nobody reads it -- the emit kernel derives both from the seed's number)
+      if (!UNIFORM || seed_info) seed_info[s] = make_uint2((uint32_t)lo[j], (uint32_t)st[j]);     // (read, offset in read)
       nok += ok;
     }
   }
@@ -2192,9 +2195,34 @@ __device__ __forceinline__ void resolve_hit(const MapView& mv, const LocusEnt* _
 // bisecting the prefix of the counts (shuffles), so a seed with many occurrences is spread over the wave
 // instead of serialising one lane.  `woff` (wave-uniform) is the wave's next output slot.
 __device__ __forceinline__ void emit_round(const MapView& mv, const LocusEnt* __restrict__ ent, const SeedHits& sh, uint32_t cnt,
-                                           uint2 si, uint64_t& woff, uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap)
+                                           uint2 si, uint64_t& woff, uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap,
+                                           bool transpose = true)
 {
   const uint32_t lane = lane_id();
+  if (transpose && __all(cnt == 1) && woff + 64 <= cap) {
+    // One hit per seed (the usual round; asked before the prefix sums, which it does not need), the round's 64 records
+    // are 2 KB in a row.  A lane storing its own record stores two 16-byte halves 32 bytes apart -- an instruction covers
+    // half of every line it touches -- so the records are transposed by shuffles first: lane l stores half l & 1 of
+    // record l >> 1 (then of record 32 + (l >> 1)): 1 KB per instruction without holes (tools/probe_shape.hip: 4.3 ->
+    // 5.4 TB/s for this shape).  Offsets in nodes and reads are 32-bit values.
+    uint64_t nid, noff;
+    resolve_hit(mv, ent, sh, 0, nid, noff);
+    const uint64_t rid = rec_offset + si.x;
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(hits + woff);
+    const bool second = lane & 1u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int src = 32 * h + (int)(lane >> 1);
+      const uint32_t a0 = (uint32_t)__shfl((int)(uint32_t)nid, src), a1 = (uint32_t)__shfl((int)(uint32_t)(nid >> 32), src);
+      const uint32_t a2 = (uint32_t)__shfl((int)(uint32_t)noff, src);
+      const uint32_t b0 = (uint32_t)__shfl((int)(uint32_t)rid, src), b1 = (uint32_t)__shfl((int)(uint32_t)(rid >> 32), src);
+      const uint32_t b2 = (uint32_t)__shfl((int)si.y, src);
+      dst[64 * h + lane] = second ? make_ulonglong2((uint64_t)b0 | ((uint64_t)b1 << 32), (uint64_t)b2)
+                                  : make_ulonglong2((uint64_t)a0 | ((uint64_t)a1 << 32), (uint64_t)a2);
+    }
+    woff += 64;
+    return;
+  }
   uint32_t incl = cnt;
   for (int d = 1; d < 64; d <<= 1) {
     uint32_t t = (uint32_t)__shfl_up((int)incl, d);
@@ -2294,7 +2322,9 @@ k_kmer_emit(MapView mv, const uint4* __restrict__ seed_res, const KmerSlot* __re
             const LocusEnt* __restrict__ ent, const uint64_t* __restrict__ wave_total,
             const uint64_t* __restrict__ wave_total_off, const uint64_t* __restrict__ params,
             uint64_t seeds_cap, uint32_t per_wave, const uint2* __restrict__ seed_info, uint64_t rec_offset,
-            psigpu_hit* __restrict__ hits, uint64_t cap, DevCounters* ctr, bool want_on, bool want_off, uint32_t gocc_thr)
+            psigpu_hit* __restrict__ hits, uint64_t cap, DevCounters* ctr, bool want_on, bool want_off, uint32_t gocc_thr,
+            uint32_t uni_spr = 0, uint32_t uni_step = 0 /* seed_info == nullptr: seed s is seed s % spr of read s / spr */,
+            bool plain_stores = false /* A/B: PSIGPU_PLAIN_STORES */)
 {
   const uint32_t lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -2345,7 +2375,8 @@ k_kmer_emit(MapView mv, const uint4* __restrict__ seed_res, const KmerSlot* __re
                                 : make_uint4((uint32_t)r8, (uint32_t)(r8 >> 32) & ((1u << R8_NOFF_BITS) - 1u),
                                              (r8 & R8_ON) ? (1u | RES_INLINE) : 0u, (r8 & R8_OFF) ? (1u | RES_INLINE) : 0u);
         } else rr[g] = seed_res[item];
-        ss[g] = seed_info[item];
+        if (seed_info) ss[g] = seed_info[item];
+        else { const uint32_t rd = (uint32_t)item / uni_spr; ss[g] = make_uint2(rd, ((uint32_t)item - rd * uni_spr) * uni_step); }
       }
     }
 #pragma unroll
@@ -2371,7 +2402,7 @@ k_kmer_emit(MapView mv, const uint4* __restrict__ seed_res, const KmerSlot* __re
         if (coff) { sh.ofirst = r.x; sh.onoff = r.y; sh.ocnt = 1u | OFF_INLINE; }
       }
       const uint32_t cnt = sh.con + (sh.ocnt & ~OFF_INLINE);     // on-path occurrences first, then the loci
-      emit_round(mv, ent, sh, cnt, si, woff, rec_offset, hits, cap);
+      emit_round(mv, ent, sh, cnt, si, woff, rec_offset, hits, cap, !plain_stores);
     }
   }
 }
@@ -4478,15 +4509,20 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     HIPCHK(ctx, ctx->w_seed_wide.ensure((n_seeds + 1) * 16));
     HIPCHK(ctx, ctx->w_seed_pfx.ensure((n_seeds + 1) * 4));
   }
+  // equal read lengths, every seed answered from the k-mer table: a seed's read and offset are its number divided -- the
+  // (read, offset) array is neither written by the packer nor read by the emit kernel (16 of the step's ~100 bytes per seed)
+  static const bool env_explicit_info = getenv("PSIGPU_EXPLICIT_INFO") != nullptr;      // A/B
+  const bool implicit_info = uniform && use_kt && !need_table && !env_explicit_info;
+  uint2* const d_seed_info = implicit_info ? nullptr : ctx->w_seed_info.as<uint2>();
   if (n_seeds) {
     const unsigned pgrid = (unsigned)std::min<uint64_t>((n_seeds + 256 * SP - 1) / (256 * SP), 256 * 32);
     if (uniform && packed)
       k_seed_pack<false, true, true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, nullptr, n_reads, d_params, n_seeds, n_bases,
-                                                                k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
+                                                                k, step, ctx->w_seed_key.as<uint64_t>(), d_seed_info, ctr,
                                                                 nullptr, nullptr, 0, *packed, un);
     else if (uniform)
       k_seed_pack<false, false, true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, nullptr, n_reads, d_params, n_seeds, n_bases,
-                                                                 k, step, ctx->w_seed_key.as<uint64_t>(), ctx->w_seed_info.as<uint2>(), ctr,
+                                                                 k, step, ctx->w_seed_key.as<uint64_t>(), d_seed_info, ctr,
                                                                  nullptr, nullptr, 0, PackedIn{ nullptr, 0, 0 }, un);
     else if (wide && packed)
       k_seed_pack<true, true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases,
@@ -4764,13 +4800,13 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         if (res8)
           k_kmer_emit<true><<<grid, 256, 0, stream>>>(map_view(ctx->p0(), fm0), ctx->w_seedres.as<uint4>(), ctx->kt_ext.as<KmerSlot>(), oe,
                                                       ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), d_params,
-                                                      n_seeds, per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap, ctr,
-                                                      (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr_e);
+                                                      n_seeds, per_wave, d_seed_info, rec_offset, d_hits, cap, ctr,
+                                                      (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr_e, un.spr, step, env_plain_stores);
         else
         k_kmer_emit<false><<<grid, 256, 0, stream>>>(map_view(ctx->p0(), fm0), ctx->w_seedres.as<uint4>(), ctx->kt_ext.as<KmerSlot>(), oe,
                                               ctx->w_iv_tiles.as<uint64_t>(), ctx->w_iv_tiles_off.as<uint64_t>(), d_params,
-                                              n_seeds, per_wave, ctx->w_seed_info.as<uint2>(), rec_offset, d_hits, cap, ctr,
-                                              (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr_e);
+                                              n_seeds, per_wave, d_seed_info, rec_offset, d_hits, cap, ctr,
+                                              (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr_e, un.spr, step, env_plain_stores);
       } else {
         if (ctx->sa_rate != 1) {
           HIPCHK(ctx, ctx->w_hit_a.ensure((cap + 1) * 8));
@@ -5013,7 +5049,8 @@ static int enqueue_default(psigpu_ctx* ctx, const FastArgs& a, hipStream_t strea
   const unsigned pgrid = (unsigned)std::min<uint64_t>((n_seeds + 255) / 256, 256 * 32);
   const PackedIn pk0{ nullptr, 0, 0 };
   uint64_t* key = ctx->w_seed_key.as<uint64_t>();
-  uint2* info = ctx->w_seed_info.as<uint2>();
+  static const bool env_explicit_info = getenv("PSIGPU_EXPLICIT_INFO") != nullptr;      // A/B
+  uint2* info = (uniform && !env_explicit_info) ? nullptr : ctx->w_seed_info.as<uint2>();       // (equal lengths: derived from the seed's number, run_pipeline)
 #define PACK_ARGS(SO) a.d_in, a.d_off, SO, a.nr, d_params, n_seeds, a.nb, k, step, key, info, ctr, nullptr, nullptr, 0
   if (uniform && a.pk) k_seed_pack<false, true, true><<<pgrid, 256, 0, stream>>>(PACK_ARGS(nullptr), *a.pk, un);
   else if (uniform) k_seed_pack<false, false, true><<<pgrid, 256, 0, stream>>>(PACK_ARGS(nullptr), pk0, un);
@@ -5046,9 +5083,9 @@ static int enqueue_default(psigpu_ctx* ctx, const FastArgs& a, hipStream_t strea
   psigpu_hit* d_hits = fs.hits.as<psigpu_hit>();
   const LocusEnt* oe = ctx->lkt_ent.as<LocusEnt>();
   if (res8) k_kmer_emit<true><<<grid, 256, 0, stream>>>(mv, res, ctx->kt_ext.as<KmerSlot>(), oe, tiles, tiles_off, d_params, n_seeds, per_wave, info,
-                                                         a.rec_base, d_hits, a.cap, ctr, ctx->fast_on, ctx->fast_off, thr);
+                                                         a.rec_base, d_hits, a.cap, ctr, ctx->fast_on, ctx->fast_off, thr, un.spr, step, env_plain_stores);
   else k_kmer_emit<false><<<grid, 256, 0, stream>>>(mv, res, ctx->kt_ext.as<KmerSlot>(), oe, tiles, tiles_off, d_params, n_seeds, per_wave, info,
-                                                    a.rec_base, d_hits, a.cap, ctr, ctx->fast_on, ctx->fast_off, thr);
+                                                    a.rec_base, d_hits, a.cap, ctr, ctx->fast_on, ctx->fast_off, thr, un.spr, step, env_plain_stores);
   if (a.want_sort && a.cap) {
     int fsr = HitSorter::fix_grouped(d_hits, a.cap, &ctr->n_hits_tab.v, (uint64_t*)&ctr->not_grouped.v, stream, &ctx->err);
     if (fsr != PSIGPU_OK) return fsr;

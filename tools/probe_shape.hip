@@ -57,6 +57,54 @@ __global__ void __launch_bounds__(256) k_probe(const uint4* __restrict__ t, uint
   }
 }
 
+// the emit kernel's shape: 8 bytes in, one 32-byte record out per item -- w0: every lane stores its own record (two 16-byte
+// stores 32 bytes apart: an instruction covers half of every 64-byte line it touches); w1: the records of 32 lanes
+// transposed by shuffles so that an instruction stores 1 KB without holes
+template <int W>
+__global__ void __launch_bounds__(256) k_write(const uint64_t* __restrict__ in, uint64_t n, uint32_t per_wave, ulonglong2* __restrict__ out)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t s0 = wave * per_wave, s1 = min(n, s0 + per_wave);
+  for (uint64_t base = s0; base < s1; base += 64) {
+    const uint64_t item = base + lane;
+    const uint64_t r = item < s1 ? in[item] : 0;
+    const uint64_t nid = r & 0xFFFFFFFFu, noff = (r >> 32) & 0xFFFFFFFu, rid = item / 7, roff = (item % 7) * 21;
+    if (W == 0) {
+      if (item < s1) { out[2 * item] = make_ulonglong2(nid, noff); out[2 * item + 1] = make_ulonglong2(rid, roff); }
+    } else {
+      if (base + 64 <= s1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int src = 32 * h + (int)(lane >> 1);
+          const uint32_t a0 = __shfl((int)(uint32_t)nid, src), a1 = __shfl((int)(uint32_t)(nid >> 32), src), a2 = __shfl((int)(uint32_t)noff, src);
+          const uint32_t b0 = __shfl((int)(uint32_t)rid, src), b1 = __shfl((int)(uint32_t)(rid >> 32), src), b2 = __shfl((int)(uint32_t)roff, src);
+          const bool second = lane & 1;
+          const uint64_t x = second ? ((uint64_t)b0 | ((uint64_t)b1 << 32)) : ((uint64_t)a0 | ((uint64_t)a1 << 32));
+          const uint64_t y = second ? b2 : a2;
+          out[2 * base + 64 * h + lane] = make_ulonglong2(x, y);
+        }
+      } else if (item < s1) { out[2 * item] = make_ulonglong2(nid, noff); out[2 * item + 1] = make_ulonglong2(rid, roff); }
+    }
+  }
+}
+
+template <int W>
+static void run_w(const char* what, const uint64_t* in, uint64_t n, ulonglong2* out)
+{
+  const uint64_t n_waves = 8192;
+  const uint32_t per_wave = (uint32_t)(((n + n_waves - 1) / n_waves + 63) / 64 * 64);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) k_write<W><<<n_waves / 4, 256>>>(in, n, per_wave, out);
+  const int reps = 20;
+  hipEventRecord(a);
+  for (int i = 0; i < reps; ++i) k_write<W><<<n_waves / 4, 256>>>(in, n, per_wave, out);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  ms /= reps;
+  printf("%-64s %7.3f ms  %6.2f TB/s\n", what, ms, n * 40.0 / ms / 1e9);
+}
+
 template <int V>
 static void run(const char* what, const uint4* t, uint64_t n_slots, const uint64_t* keys, uint64_t n, uint64_t* out)
 {
@@ -91,5 +139,10 @@ int main()
   run<4>("v4 v0 with 28 M keys per launch", t, n_slots, keys, n4, out);
   run<5>("v5 v0 with two keys per lane in flight", t, n_slots, keys, n, out);
   run<0>("v0 again", t, n_slots, keys, n, out);
+  ulonglong2* recs;
+  if (hipMalloc(&recs, n * 32) != hipSuccess) { printf("alloc failed\n"); return 1; }
+  run_w<0>("w0 8 B in, 32-B record out, every lane its own record", keys, n, recs);
+  run_w<1>("w1 the same, records transposed: 1 KB per store instruction", keys, n, recs);
+  run_w<0>("w0 again", keys, n, recs);
   return 0;
 }
