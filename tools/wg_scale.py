@@ -55,12 +55,14 @@ def main():
     ap.add_argument('--mems', type=int, default=0, help='MEM mode (find_mems) on this many reads')
     ap.add_argument('--devices', default='0', help='GPUs to shard the reads over, e.g. 0-7 or 0,0,0 (one context + thread each)')
     ap.add_argument('--max-part-text', type=int, default=0, help='text symbols per index part (tests: several parts at small size)')
+    ap.add_argument('--general-reads', action='store_true', help='do not tell the library that all reads have one length (they have: 150 bp)')
     args = ap.parse_args()
     import threading
     import numpy as np
     import torch
     import psi_amd
     from psi_amd import synth
+    uni = 0 if args.general_reads else psi_amd.UNIFORM_READS       # (synth.sim_reads_*: every read has the same length)
 
     log = lambda *a: print(*a, file=sys.stderr, flush=True)   # noqa: E731
     devices = parse_devices(args.devices)
@@ -142,7 +144,7 @@ def main():
 
     def step(sh):
         sh.ptr, sh.n_hits = sh.f.seeds_all_device(sh.d_bases.data_ptr(), sh.d_off.data_ptr(), sh.r1 - sh.r0, sh.n_bases,
-                                                   rec_offset=sh.r0)
+                                                   rec_offset=sh.r0, flags=psi_amd.ALL | uni)
 
     in_threads(step)                              # warm-up (buffers sized)
     start = threading.Barrier(nd + 1)
@@ -248,7 +250,7 @@ def main():
             pin = (psi_amd.pinned_copy(bases[b0:b1]), psi_amd.pinned_copy((off[sh.r0:sh.r1 + 1] - off[sh.r0]).astype(np.uint64)))
             h = psi_amd.Hits()
             call = (sh.f.ctx, psi_amd._ptr(pin[0].array), psi_amd._ptr(pin[1].array), sh.r1 - sh.r0, args.k, args.k, sh.r0,
-                    psi_amd.ALL | psi_amd.SORT_UNIQUE, C.byref(h))
+                    psi_amd.ALL | psi_amd.SORT_UNIQUE | uni, C.byref(h))
             assert L.psigpu_find_seeds(*call) == 0          # warm: pinned pool, slot buffers
             L.psigpu_free_hits(C.byref(h))
             start.wait()
