@@ -904,6 +904,42 @@ def main():
         }
         out['host_entry_ms_per_step'] = t_pk * 1e3
 
+        # ---- the same steps with two chunks in flight (psigpu_find_seeds_device_begin / _end, ABI 6) ----------------------
+        # chunk i + 1 is queued before chunk i is ended: the device does not wait for the host between two steps.  NOT
+        # `value` (whose steps are synchronous calls, as in every round): what a loop that double-buffers its batches gets.
+        if args.mode == 'kmer-table':
+            bcalls = [(finder.ctx, d[0].data_ptr(), d[1].data_ptr(), args.reads, d[2], k, step, rec_offset, psi_amd.ALL | uni, stream) for d in dev]
+            dh, nh = C.c_void_p(), C.c_uint64()
+
+            def pipelined(n_steps):
+                tot = 0
+                if L.psigpu_find_seeds_device_begin(*bcalls[0]):
+                    raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
+                for i in range(n_steps):
+                    if i + 1 < n_steps and L.psigpu_find_seeds_device_begin(*bcalls[(i + 1) % nb]):
+                        raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
+                    if L.psigpu_find_seeds_device_end(finder.ctx, C.byref(dh), C.byref(nh)):
+                        raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
+                    tot += nh.value
+                return tot
+            pipelined(6)
+            torch.cuda.synchronize()
+            pb = []
+            for _ in range(max(3, min(60, int(0.3 / max(1e-6, args.steps * main_res['elapsed'] / main_res['steps']))))):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ph = pipelined(args.steps)
+                torch.cuda.synchronize()
+                pb.append((time.perf_counter() - t1) / args.steps)
+            pm = float(np.median(pb))
+            cp = finder.counters()
+            out['two_chunks_in_flight'] = {
+                'ms_per_step': pm * 1e3, 'ms_per_step_min': min(pb) * 1e3, 'ms_per_step_max': max(pb) * 1e3, 'blocks': len(pb),
+                'seeds_per_s': main_res['seeds'] / main_res['steps'] / pm, 'hits_per_step': ph // args.steps,
+                'queued_chunks': bool(cp['lookahead_subbatches']), 'fallbacks': int(cp['lookahead_fallbacks']),
+                'what': 'the steps of `value` through psigpu_find_seeds_device_begin / _end: the next chunk queued before the '
+                        'current one is ended (same kernels, same records; the host round trip between two steps hidden)'}
+
         # ---- the same steps without the equal-length claim (reads of any lengths: scan + search for a seed's read) --------
         if uni:
             res_g = time_mode(finder, 10, 3, args.mode, False, call_flags=0)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSIGPU_ABI_VERSION 5
+#define PSIGPU_ABI_VERSION 6
 #define PSIGPU_MAX_SEED_LEN 63u   /* psikt takes any -l (src/psikt.cpp:327); seeds are 2-bit packed into one 64-bit word up
                                     to 31 bases and into two words from 32 to 63 */
 #define PSIGPU_MAX_TABLE_SEED_LEN 31u   /* the tabulating query modes (k-mer table, locus table) hold one-word k-mers: longer
@@ -448,6 +448,27 @@ int psigpu_find_seeds_device_packed(psigpu_ctx* ctx, const uint64_t* d_packed, c
                                     const uint64_t* d_read_off, uint64_t n_reads, uint64_t n_bases, uint32_t k,
                                     uint32_t step, uint64_t rec_offset, uint32_t flags, void* stream,
                                     const psigpu_hit** d_hits, uint64_t* n_hits);
+
+/* Two chunks in flight (ABI 6).  A caller that has its next chunk resident before it needs the hits of the current one --
+ * a loop that double-buffers its read batches, what the reference's chunked loop (src/psikt.cpp:240-270: load a chunk,
+ * seeds_all, next chunk) becomes when loading and seeding overlap -- begins chunk i + 1 before it ends chunk i: the device
+ * does not wait for the host between two chunks (the synchronisation, the counters' way back, the next call's launches).
+ *   _begin   queues the chunk's kernels on `stream` and returns; at most two chunks may be begun and not ended
+ *            (PSIGPU_ERR_STATE for a third); arguments as for psigpu_find_seeds_device / _device_packed; the reads and
+ *            offsets must stay untouched until the chunk's _end
+ *   _end     waits for the OLDEST chunk begun and hands out its hits: library-owned device memory, valid until the third
+ *            _begin after the chunk's own (or the next call of another entry point of this context); psigpu_get_counters
+ *            describes that chunk
+ * A chunk that needs more than the default mode's kernels (another query mode, a walk-capped table with a traverser pass,
+ * tables not made yet, buffers that would have to grow under the chunk in flight, reads that are not of one length behind
+ * PSIGPU_UNIFORM_READS) is answered by psigpu_find_seeds_device inside its _end: same records, no overlap.  While chunks
+ * are begun and not ended every other entry point of the context returns PSIGPU_ERR_STATE. */
+int psigpu_find_seeds_device_begin(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off, uint64_t n_reads,
+                                   uint64_t n_bases, uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, void* stream);
+int psigpu_find_seeds_device_packed_begin(psigpu_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_n_mask,
+                                          const uint64_t* d_read_off, uint64_t n_reads, uint64_t n_bases, uint32_t k,
+                                          uint32_t step, uint64_t rec_offset, uint32_t flags, void* stream);
+int psigpu_find_seeds_device_end(psigpu_ctx* ctx, const psigpu_hit** d_hits, uint64_t* n_hits);
 
 /* Copies `n` records that psigpu_find_seeds_device left in HBM into host memory (blocking;
  * through this library's HIP runtime, so that a binding never has to load one of its own). */

@@ -144,6 +144,11 @@ ABI = [
     ('psigpu_find_seeds_device_packed', C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                                   C.c_uint64, C.c_uint32, _P, C.POINTER(_P), _U64P]),
     ('psigpu_set_option', C.c_int, [_P, C.c_char_p, C.c_uint64]),
+    ('psigpu_find_seeds_device_begin', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                 C.c_uint64, C.c_uint32, _P]),
+    ('psigpu_find_seeds_device_packed_begin', C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                        C.c_uint64, C.c_uint32, _P]),
+    ('psigpu_find_seeds_device_end', C.c_int, [_P, C.POINTER(_P), _U64P]),
     ('psigpu_find_seeds_device', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_uint64, C.c_uint32, _P, C.POINTER(_P), _U64P]),
     ('psigpu_get_counters', C.c_int, [_P, C.POINTER(Counters)]),
@@ -713,6 +718,25 @@ class SeedFinder:
         self._chk(lib().psigpu_find_seeds_device(self.ctx, d_bases_ptr, d_read_off_ptr, n_reads, n_bases,
                                                  self.seed_len, step, rec_offset, flags, stream,
                                                  C.byref(d_hits), C.byref(n)))
+        return d_hits.value, n.value
+
+    def seeds_all_device_begin(self, d_bases_ptr: int, d_read_off_ptr: int, n_reads: int, n_bases: int,
+                               step: int = 0, rec_offset: int = 0, flags: int = ALL, stream: int = 0) -> None:
+        """Queue a device-resident chunk and return (psigpu_find_seeds_device_begin): at most two chunks begun and not
+        ended; seeds_all_device_end() hands out the hits of the oldest."""
+        self._chk(lib().psigpu_find_seeds_device_begin(self.ctx, d_bases_ptr, d_read_off_ptr, n_reads, n_bases,
+                                                       self.seed_len, step, rec_offset, flags, stream))
+
+    def seeds_all_device_packed_begin(self, d_words_ptr: int, d_mask_ptr: int, d_read_off_ptr: int, n_reads: int, n_bases: int,
+                                      step: int = 0, rec_offset: int = 0, flags: int = ALL, stream: int = 0) -> None:
+        self._chk(lib().psigpu_find_seeds_device_packed_begin(self.ctx, d_words_ptr, d_mask_ptr, d_read_off_ptr, n_reads, n_bases,
+                                                              self.seed_len, step, rec_offset, flags, stream))
+
+    def seeds_all_device_end(self):
+        """(device pointer, n_hits) of the oldest chunk begun; valid until the third begin after that chunk's."""
+        d_hits = C.c_void_p()
+        n = C.c_uint64()
+        self._chk(lib().psigpu_find_seeds_device_end(self.ctx, C.byref(d_hits), C.byref(n)))
         return d_hits.value, n.value
 
     def seeds_all_device_packed(self, d_words_ptr: int, d_mask_ptr: int, d_read_off_ptr: int, n_reads: int, n_bases: int,

@@ -3142,6 +3142,17 @@ struct psigpu_ctx {
   } fast[N_FAST];
   bool opt_no_lookahead = false;
   uint64_t lookahead_fallbacks = 0;
+  // device-resident entry, two chunks in flight (psigpu_find_seeds_device_begin / _end): what was begun and not ended yet,
+  // oldest first.  A chunk that could be queued (the default mode's kernels alone: enqueue_default) sits in a FastSlot;
+  // any other chunk is answered by the synchronous entry when its turn to be ended comes.
+  struct DevPending {
+    bool queued = false;
+    const char* d_bases = nullptr; const uint64_t* d_mask = nullptr; bool packed = false; const uint64_t* d_off = nullptr;
+    uint64_t nr = 0, nb = 0, rec_offset = 0; uint32_t k = 0, step = 0, flags = 0; void* stream = nullptr;
+    unsigned long long serial = 0; bool uniform = false; uint64_t cap = 0; int slot = 0;
+  } dpend[2];
+  int dp_head = 0, dp_count = 0;
+  uint64_t dp_seq = 0;
   void* stager = nullptr;          // the host entry's helper thread for pageable reads (struct Worker)
   void* widener = nullptr;         // the host entry's widening threads (struct Widener, made by its first call)
   // psigpu_set_option
@@ -3371,6 +3382,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
 {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->dp_count) { (void)hipDeviceSynchronize(); ctx->dp_count = 0; }      // (chunks begun and never ended)
   widener_destroy(ctx);
   DevBuf* all[] = { &ctx->nodes, &ctx->lite, &ctx->node_id, &ctx->lab2, &ctx->labn, &ctx->edge_to, &ctx->loci, &ctx->w_bases,
                     &ctx->w_read_off, &ctx->w_cnt, &ctx->w_tiles, &ctx->w_seed_off, &ctx->w_seed_key,
@@ -3449,6 +3461,7 @@ static void lkt_release(psigpu_ctx* ctx)
 int psigpu_set_query_mode(psigpu_ctx* ctx, uint32_t mode, uint32_t walk_cap)
 {
   if (!ctx || mode > PSIGPU_MODE_AUTO) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   if (hipSetDevice(ctx->device) != hipSuccess) return PSIGPU_ERR_DEVICE;
   ctx->auto_mode = mode == PSIGPU_MODE_AUTO;
   ctx->auto_resolved = false;
@@ -3520,6 +3533,7 @@ int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value)
 int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
 {
   if (!ctx || !g) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   uint64_t n = g->n_nodes;
   if (n >= 0xFFFFFFF0ull) { ctx->err = "too many nodes"; return PSIGPU_ERR_ARG; }
@@ -3730,6 +3744,7 @@ static int load_part(psigpu_ctx* ctx, const psigpu_index_view* m, uint32_t sa_ra
 int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
 {
   if (!ctx || !x) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (x->sa_rate == 0 || (x->sa_rate & (x->sa_rate - 1))) { ctx->err = "bad sa_rate"; return PSIGPU_ERR_ARG; }
   // nothing inconsistent reaches the kernels
@@ -5092,7 +5107,7 @@ static int enqueue_default(psigpu_ctx* ctx, const FastArgs& a, hipStream_t strea
   }
   unsigned long long* h_wflag = reinterpret_cast<unsigned long long*>((char*)fs.h + sizeof(DevCounters) + 32);
   *h_wflag = 0;
-  if (a.cap) {
+  if (a.cap && a.wire) {
     if (a.wf.bytes == 8)
       k_hits_wire8<<<2048, 256, 0, stream>>>(d_hits, &ctr->n_hits_tab.v, &ctr->n_hits_off.v, 0, a.cap, ctx->id_base, a.rec_base, a.wf,
                                              a.wire->as<uint64_t>(), reinterpret_cast<unsigned long long*>((char*)fs.h_dev + sizeof(DevCounters) + 32));
@@ -5190,6 +5205,7 @@ int psigpu_find_seeds_device(psigpu_ctx* ctx, const char* d_bases, const uint64_
                              uint64_t rec_offset, uint32_t flags, void* stream,
                              const psigpu_hit** d_hits, uint64_t* n_hits)
 {
+  if (ctx && ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   return find_seeds_device(ctx, d_bases, nullptr, d_read_off, n_reads, n_bases, k, step, rec_offset, flags, stream, d_hits, n_hits);
 }
 
@@ -5199,9 +5215,143 @@ int psigpu_find_seeds_device_packed(psigpu_ctx* ctx, const uint64_t* d_packed, c
                                     const psigpu_hit** d_hits, uint64_t* n_hits)
 {
   if (n_bases && !d_packed) return PSIGPU_ERR_ARG;
+  if (ctx && ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   const PackedIn pk{ d_n_mask, 0, 0 };
   return find_seeds_device(ctx, reinterpret_cast<const char*>(d_packed), &pk, d_read_off, n_reads, n_bases, k, step, rec_offset, flags,
                            stream, d_hits, n_hits);
+}
+
+// ---- two chunks in flight through the device-resident entry ----------------------------------------------------
+// A step of the default mode is ~0.35 ms of kernels and ~0.04 ms in which the device waits for the host: the
+// synchronisation, the counters read, the return to the caller, the caller's next call, five launches.  A caller that
+// has the next chunk ready (a pipeline that double-buffers its read batches, as psikt's host entry does internally with
+// its sub-batches) begins it before it ends the current one: _begin queues a chunk's kernels and returns, _end waits
+// for the OLDEST chunk begun and hands out its hits.  At most two chunks are begun at a time; the hits of a chunk stay
+// valid until the third _begin after its own.  A chunk that needs more than the default mode's kernels (another query
+// mode, a traverser pass, tables not made yet, buffers that would have to grow under a chunk in flight) is answered by the
+// synchronous entry inside its _end -- same result, no overlap.
+static int dev_begin(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_mask, bool packed, const uint64_t* d_read_off,
+                     uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, void* stream)
+{
+  if (!ctx || (n_reads && !d_read_off) || (packed && n_bases && !d_bases)) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count == 2) { ctx->err = "two chunks are begun already: end one first"; return PSIGPU_ERR_STATE; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if ((flags & PSIGPU_ALL) == 0) flags |= PSIGPU_ALL;
+  psigpu_ctx::DevPending& p = ctx->dpend[(ctx->dp_head + ctx->dp_count) % 2];
+  p = psigpu_ctx::DevPending{};
+  p.d_bases = d_bases; p.d_mask = d_mask; p.packed = packed; p.d_off = d_read_off; p.nr = n_reads; p.nb = n_bases;
+  p.rec_offset = rec_offset; p.k = k; p.step = step; p.flags = flags; p.stream = stream;
+  const uint32_t stp = step ? step : k;
+  static const bool env_no_lookahead = getenv("PSIGPU_NO_LOOKAHEAD") != nullptr;
+  const bool want_sort = (flags & PSIGPU_SORT_UNIQUE) != 0;
+  bool fast = n_reads && n_bases && k && ctx->fast_k == k && ctx->fast_flags == (flags & PSIGPU_ALL) && ctx->lkt_ready && ctx->kt_ready &&
+              ctx->lkt_k == k && !env_no_lookahead && !ctx->opt_no_lookahead && !getenv("PSIGPU_TRACE") &&
+              !(want_sort && getenv("PSIGPU_NO_GROUPED_SORT") != nullptr);
+  const uint64_t seeds_max = n_bases / stp + n_reads;
+  if (fast && seeds_max >= 0xFFFFFFF0ull) fast = false;
+  if (fast) {
+    const uint64_t cap = std::max<uint64_t>(ctx->hits_cap_hint, 2 * seeds_max + (1u << 16));
+    const int q = (int)(ctx->dp_seq % psigpu_ctx::N_FAST);
+    psigpu_ctx::FastSlot& fs = ctx->fast[q];
+    // nothing may be regrown (freed) under a chunk in flight: with one begun, a buffer that is too small makes this chunk a synchronous one
+    struct Need { DevBuf* b; size_t bytes; };
+    const Need needs[] = { { &ctx->w_ctr, sizeof(DevCounters) }, { &ctx->w_total, 64 }, { &ctx->w_tiles, (n_reads / SCAN_TILE + 2) * 8 },
+                           { &ctx->w_seed_off, (n_reads + 1) * 8 }, { &ctx->w_seed_key, (seeds_max + 1) * 8 }, { &ctx->w_seed_info, (seeds_max + 1) * 8 },
+                           { &ctx->w_seedres, (seeds_max + 16) * 16 }, { &ctx->w_iv_tiles, (WAVES_MAX + 8) * 8 }, { &ctx->w_iv_tiles_off, (WAVES_MAX + 8) * 8 },
+                           { &fs.hits, (cap + 1) * sizeof(psigpu_hit) } };
+    bool grow = !fs.h;
+    for (const Need& nd : needs) grow = grow || nd.b->cap < nd.bytes;
+    if (grow && ctx->dp_count) fast = false;
+    else if (grow) {
+      // (all three slots at once: the next chunk is begun with this one in flight and must find its slot made)
+      hipError_t e = hipSuccess;
+      for (const Need& nd : needs) if (e == hipSuccess) e = nd.b->ensure(nd.bytes);
+      for (int s3 = 0; s3 < psigpu_ctx::N_FAST; ++s3) {
+        psigpu_ctx::FastSlot& f3 = ctx->fast[s3];
+        if (e == hipSuccess) e = f3.hits.ensure((cap + 1) * sizeof(psigpu_hit));
+        if (e == hipSuccess && !f3.h) {
+          e = hipHostMalloc(&f3.h, sizeof(DevCounters) + 64, hipHostMallocMapped);
+          if (e == hipSuccess) e = hipHostGetDevicePointer(&f3.h_dev, f3.h, 0);
+          if (e == hipSuccess) e = hipEventCreate(&f3.begin);
+          if (e == hipSuccess) e = hipEventCreate(&f3.done);
+        }
+      }
+      if (e != hipSuccess) { (void)hipGetLastError(); fast = false; }       // (the synchronous entry reports what is wrong, if anything is)
+    }
+    if (fast) {
+      PackedIn pk{ d_mask, 0, 0 };
+      FastArgs a;
+      a.d_in = d_bases; a.pk = packed ? &pk : nullptr; a.d_off = d_read_off;
+      a.nr = n_reads; a.nb = n_bases; a.k = k; a.step = stp; a.rec_base = rec_offset;
+      a.want_sort = want_sort; a.claim_uniform = (flags & PSIGPU_UNIFORM_READS) != 0;
+      a.wf = WireFmt{}; a.wire = nullptr; a.cap = cap; a.slot = q;
+      p.cap = cap; p.slot = q;
+      int st = enqueue_default(ctx, a, (hipStream_t)stream, &p.serial, &p.uniform);
+      if (st != PSIGPU_OK) return st;
+      p.queued = true;
+      ++ctx->dp_seq;
+    }
+  }
+  ++ctx->dp_count;
+  return PSIGPU_OK;
+}
+
+int psigpu_find_seeds_device_begin(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off, uint64_t n_reads, uint64_t n_bases,
+                                   uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, void* stream)
+{
+  return dev_begin(ctx, d_bases, nullptr, false, d_read_off, n_reads, n_bases, k, step, rec_offset, flags, stream);
+}
+
+int psigpu_find_seeds_device_packed_begin(psigpu_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_n_mask, const uint64_t* d_read_off,
+                                          uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t rec_offset,
+                                          uint32_t flags, void* stream)
+{
+  return dev_begin(ctx, reinterpret_cast<const char*>(d_packed), d_n_mask, true, d_read_off, n_reads, n_bases, k, step, rec_offset, flags, stream);
+}
+
+int psigpu_find_seeds_device_end(psigpu_ctx* ctx, const psigpu_hit** d_hits, uint64_t* n_hits)
+{
+  if (!ctx || !d_hits || !n_hits) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count == 0) { ctx->err = "no chunk was begun"; return PSIGPU_ERR_STATE; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const psigpu_ctx::DevPending p = ctx->dpend[ctx->dp_head];
+  ctx->dp_head = (ctx->dp_head + 1) % 2;
+  --ctx->dp_count;
+  if (p.queued) {
+    psigpu_ctx::FastSlot& fs = ctx->fast[p.slot];
+    {
+      // (polled, not hipEventSynchronize: with the next chunk queued behind the event the runtime would wait for that too)
+      hipError_t qe;
+      uint32_t spins = 0;
+      while ((qe = hipEventQuery(fs.done)) == hipErrorNotReady) { if (++spins > 2000) std::this_thread::yield(); }
+      if (qe != hipSuccess) { ctx->err = std::string("hipEventQuery: ") + hipGetErrorString(qe); return PSIGPU_ERR_DEVICE; }
+    }
+    const DevCounters& h = *reinterpret_cast<const DevCounters*>(fs.h);
+    const uint64_t n = h.n_hits_tab.v;
+    const bool want_sort = (p.flags & PSIGPU_SORT_UNIQUE) != 0;
+    if (h.serial.v != p.serial) ++ctx->stale_handbacks;
+    if (h.serial.v == p.serial && !(p.uniform && h.not_uniform.v) && n <= p.cap && !(want_sort && h.not_grouped.v)) {
+      psigpu_counters pc{};
+      pc.n_reads = p.nr; pc.n_seeds = h.n_seeds_true.v; pc.n_seeds_valid = h.n_seeds_valid.total();
+      pc.n_seeds_on_path = h.n_live.total(); pc.n_hits_on_path = h.n_hits_on.v; pc.n_hits_off_path = n - h.n_hits_on.v; pc.n_hits = n;
+      pc.n_loci = ctx->n_loci; pc.n_locus_kmers = ctx->fast_off ? ctx->lkt_n_ent : 0; pc.n_path_kmers = ctx->kt_n_path_kmers;
+      pc.ms_locus_table_build = ctx->lkt_build_ms;
+      { float t = 0; (void)hipEventElapsedTime(&t, fs.begin, fs.done); pc.ms_total = t; }
+      pc.sorted_in_place = want_sort ? 1u : 0u;
+      pc.lookahead_subbatches = 1;
+      pc.stale_handbacks = ctx->stale_handbacks;
+      ctx->last = pc;
+      ctx->hits_cap_hint = std::max<uint64_t>(ctx->hits_cap_hint, n + n / 8);
+      *d_hits = fs.hits.as<psigpu_hit>();
+      *n_hits = n;
+      return PSIGPU_OK;
+    }
+    // something the five kernels alone do not settle (reads of several lengths behind the claim, more hits than the
+    // slot holds, records not grouped by seed): the chunk again, the synchronous way, behind whatever else is queued
+    ++ctx->lookahead_fallbacks;
+  }
+  const PackedIn pk{ p.d_mask, 0, 0 };
+  return find_seeds_device(ctx, p.d_bases, p.packed ? &pk : nullptr, p.d_off, p.nr, p.nb, p.k, p.step, p.rec_offset, p.flags, p.stream, d_hits, n_hits);
 }
 
 int psigpu_find_mems(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off, uint64_t n_reads, uint32_t minlen,
@@ -5299,6 +5449,7 @@ int psigpu_copy_hits(psigpu_ctx* ctx, psigpu_hit* host_dst, const psigpu_hit* d_
 int psigpu_prepare(psigpu_ctx* ctx, uint32_t k)
 {
   if (!ctx) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (k == 0 || k > PSIGPU_MAX_SEED_LEN) { ctx->err = "seed length out of range (1..63)"; return PSIGPU_ERR_ARG; }
   if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
@@ -6275,6 +6426,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
 int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off, uint64_t n_reads,
                       uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, psigpu_hits* out)
 {
+  if (ctx && ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   ReadsIn in;
   in.ascii = bases;
   return find_seeds_host(ctx, in, read_off, n_reads, k, step, rec_offset, flags, out);
@@ -6284,6 +6436,7 @@ int psigpu_find_seeds_packed(psigpu_ctx* ctx, const uint64_t* packed, const uint
                              uint64_t n_reads, uint32_t k, uint32_t step, uint64_t rec_offset, uint32_t flags, psigpu_hits* out)
 {
   if (n_reads && read_off && read_off[n_reads] && !packed) return PSIGPU_ERR_ARG;
+  if (ctx && ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   ReadsIn in;
   static const uint64_t none = 0;
   in.words = packed ? packed : &none;           // (a chunk without bases: still "packed")

@@ -1879,3 +1879,89 @@ def test_index_parts_roundtrip_and_gocc(tmp_path, query_mode):
     fm1.set_path_index(one)
     assert _eq(f.find_mems(reads[:60], max_mem=4), fm1.find_mems(reads[:60], max_mem=4))
     f.close(); fm1.close()
+
+
+def test_device_entry_two_chunks_in_flight(query_mode):
+    """psigpu_find_seeds_device_begin / _end (ABI 6): chunk i + 1 queued before chunk i is ended -- the same records as the
+    synchronous entry for every chunk, whatever is in flight beside it: equal-length and ragged reads, the equal-length claim
+    true and false, raw and sorted, packed words, a chunk that is larger than anything the context has seen (answered
+    synchronously inside its end); in the other query modes, and with a walk-capped table, every chunk takes that route.  A third
+    begin and any other entry point while chunks are begun are refused."""
+    import torch
+    g, reads = _x_case()
+    k, step = 21, 3
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(1, rng_seed=3)
+    equal = [r[:100] for r in reads[:900] if len(r) >= 100]
+    ragged = _ragged_reads(reads[:500], k)
+    long_ = [r for r in reads if len(r) >= 100]
+    two_lengths = [r[:80] for r in long_[:120]] + [r[:100] for r in long_[120:240]]       # (their total is a multiple of their number)
+    assert len(two_lengths) == 240
+    chunks = []
+    for rs, flags in ((equal[:300], psi_amd.ALL | psi_amd.UNIFORM_READS), (ragged[:200], psi_amd.ALL),
+                      (two_lengths, psi_amd.ALL | psi_amd.UNIFORM_READS),              # the claim is false: answered again
+                      (equal[300:600], psi_amd.ALL | psi_amd.SORT_UNIQUE | psi_amd.UNIFORM_READS),
+                      (ragged[100:400], psi_amd.ALL | psi_amd.SORT_UNIQUE), (equal[100:800], psi_amd.ALL)):
+        bases, off = psi_amd.pack_reads(rs)
+        chunks.append((torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(rs), len(bases), flags))
+    want = []
+    for i, (d_b, d_o, nr, nb, flags) in enumerate(chunks):
+        ptr, n = f.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), nr, nb, step=step, rec_offset=1000 * i, flags=flags)
+        want.append(f.copy_hits(ptr, n))
+    assert all(len(w) for w in want)
+
+    def begin(i):
+        d_b, d_o, nr, nb, flags = chunks[i]
+        f.seeds_all_device_begin(d_b.data_ptr(), d_o.data_ptr(), nr, nb, step=step, rec_offset=1000 * i, flags=flags)
+
+    def end(i):
+        ptr, n = f.seeds_all_device_end()
+        got = f.copy_hits(ptr, n)
+        if chunks[i][4] & psi_amd.SORT_UNIQUE:
+            assert _eq(got, want[i]), i
+        else:
+            assert _eq(psi_amd.sort_unique(got), psi_amd.sort_unique(want[i])), i
+        assert f.counters()['n_hits'] == n
+
+    for _ in range(2):
+        begin(0)
+        for i in range(len(chunks)):
+            if i + 1 < len(chunks):
+                begin(i + 1)
+            end(i)
+    # the hits of a chunk outlive the next two begins
+    begin(0); begin(1)
+    ptr0, n0 = f.seeds_all_device_end()
+    begin(2)
+    assert _eq(psi_amd.sort_unique(f.copy_hits(ptr0, n0)), psi_amd.sort_unique(want[0]))
+    f.seeds_all_device_end()
+    begin(3)
+    with pytest.raises(psi_amd.PsiGpuError):
+        begin(4)                                          # two are begun
+    with pytest.raises(psi_amd.PsiGpuError):
+        f.seeds_all_device(chunks[0][0].data_ptr(), chunks[0][1].data_ptr(), chunks[0][2], chunks[0][3], step=step)
+    f.seeds_all_device_end(); f.seeds_all_device_end()
+    with pytest.raises(psi_amd.PsiGpuError):
+        f.seeds_all_device_end()                          # nothing begun
+    if query_mode == 'kmer-table':
+        assert f.counters()['lookahead_fallbacks'] >= 1       # (the false claim at least)
+        begin(0); begin(1)
+        f.seeds_all_device_end()
+        assert f.counters()['lookahead_subbatches'] == 1      # chunk 0 went through the queue
+        f.seeds_all_device_end()
+        assert f.counters()['lookahead_subbatches'] == 1      # and so did chunk 1, begun while chunk 0 was in flight
+    # packed words
+    rs = equal[:400]
+    bases, off = psi_amd.pack_reads(rs)
+    pr = psi_amd.PackedReads(bases, off)
+    d_w, d_m = torch.from_numpy(pr.words.view(np.int64)).cuda(), torch.from_numpy(pr._mask_store.view(np.int64)).cuda()
+    d_o = torch.from_numpy(off.astype(np.int64)).cuda()
+    ptr, n = f.seeds_all_device_packed(d_w.data_ptr(), d_m.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, flags=psi_amd.ALL | psi_amd.UNIFORM_READS)
+    wp = psi_amd.sort_unique(f.copy_hits(ptr, n))
+    for _ in range(2):
+        f.seeds_all_device_packed_begin(d_w.data_ptr(), d_m.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, flags=psi_amd.ALL | psi_amd.UNIFORM_READS)
+    for _ in range(2):
+        ptr, n = f.seeds_all_device_end()
+        assert _eq(psi_amd.sort_unique(f.copy_hits(ptr, n)), wp)
+    f.seeds_all_device_begin(chunks[0][0].data_ptr(), chunks[0][1].data_ptr(), chunks[0][2], chunks[0][3], step=step)
+    f.close()                                             # (a chunk begun and never ended: the context drains it)
