@@ -95,6 +95,17 @@ def worker(args, proc, tid, seeds, stats, lock):
             if not eq(got, psi_amd.sort_unique(w2)):
                 bad('device_entry', seed, {'k': k, 'step': step, 'npaths': npaths, 'mode': mode, 'life': life,
                                            'got': int(len(got)), 'want': int(len(want))})
+            # D2: the same chunk twice through begin / end, the second begun while the first is in flight (ABI 6)
+            if rng.random() < 0.5:
+                f.seeds_all_device_begin(d_b.data_ptr(), d_o.data_ptr(), len(reads), len(bases), step=step, rec_offset=rec0)
+                f.seeds_all_device_begin(d_b.data_ptr(), d_o.data_ptr(), len(reads), len(bases), step=step, rec_offset=rec0)
+                for _half in range(2):
+                    ptr, n = f.seeds_all_device_end()
+                    got = psi_amd.sort_unique(f.copy_hits(ptr, n))
+                    n_calls += 1
+                    if not eq(got, psi_amd.sort_unique(w2)):
+                        bad('device_entry_two_in_flight', seed, {'k': k, 'step': step, 'npaths': npaths, 'mode': mode, 'life': life,
+                                                                 'half': _half, 'got': int(len(got)), 'want': int(len(want))})
             # H: host entry, a few shapes per lifetime
             for rep in range(args.calls):
                 f.set_option('sub_bytes', rng.choice([16, 64, 200, 3000, 1 << 30]))
