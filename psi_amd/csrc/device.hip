@@ -32,6 +32,8 @@
 #include <execinfo.h>
 #include <memory>
 #include <signal.h>
+#include <sys/syscall.h>
+#include <ucontext.h>
 #include <unistd.h>
 #include <mutex>
 #include <string>
@@ -3324,15 +3326,43 @@ static int upload(psigpu_ctx* ctx, DevBuf& b, const T* src, uint64_t n, uint64_t
 
 extern "C" {
 
-// PSIGPU_SEGV_TRACE=1 (debugging aid): a backtrace of the faulting thread on stderr before the process dies
-static void segv_trace(int sig)
+// PSIGPU_SEGV_TRACE=1 (debugging aid): the signal, the faulting address, the instruction pointer and the thread on stderr FIRST
+// (formatted by hand: nothing here may allocate), then a backtrace of the faulting thread -- which walks the stack that may be
+// the thing that is broken; a process that died inside it used to leave nothing behind.
+static void segv_put_hex(char*& p, unsigned long long v)
+{
+  *p++ = '0'; *p++ = 'x';
+  bool on = false;
+  for (int sh = 60; sh >= 0; sh -= 4) {
+    const unsigned d = (unsigned)((v >> sh) & 15u);
+    if (d || on || sh == 0) { *p++ = (char)(d < 10 ? '0' + d : 'a' + d - 10); on = true; }
+  }
+}
+static void segv_trace(int sig, siginfo_t* si, void* uc_)
 {
   signal(sig, SIG_DFL);
   alarm(5);                                       // (a handler stuck behind a lock the dying thread holds must not hang the process)
+  char line[256];
+  char* p = line;
+  for (const char* c = "[psigpu] fatal signal "; *c; ++c) *p++ = *c;
+  segv_put_hex(p, (unsigned long long)sig);
+  for (const char* c = " address "; *c; ++c) *p++ = *c;
+  segv_put_hex(p, (unsigned long long)(uintptr_t)(si ? si->si_addr : nullptr));
+#if defined(__x86_64__)
+  if (uc_) {
+    const ucontext_t* uc = static_cast<const ucontext_t*>(uc_);
+    for (const char* c = " rip "; *c; ++c) *p++ = *c;
+    segv_put_hex(p, (unsigned long long)uc->uc_mcontext.gregs[REG_RIP]);
+    for (const char* c = " rsp "; *c; ++c) *p++ = *c;
+    segv_put_hex(p, (unsigned long long)uc->uc_mcontext.gregs[REG_RSP]);
+  }
+#endif
+  for (const char* c = " thread "; *c; ++c) *p++ = *c;
+  segv_put_hex(p, (unsigned long long)syscall(SYS_gettid));
+  for (const char* c = "; backtrace of the faulting thread:\n"; *c; ++c) *p++ = *c;
+  (void)!write(2, line, (size_t)(p - line));
   void* frames[64];
   const int nf = backtrace(frames, 64);
-  static const char msg[] = "[psigpu] fatal signal, backtrace of the faulting thread:\n";
-  (void)!write(2, msg, sizeof msg - 1);
   backtrace_symbols_fd(frames, nf, 2);
   raise(sig);
 }
@@ -3346,7 +3376,7 @@ psigpu_ctx* psigpu_create(int device)
     stack_t ss{}; ss.ss_sp = alt; ss.ss_size = sizeof alt;
     (void)sigaltstack(&ss, nullptr);
     struct sigaction sa{};
-    sa.sa_handler = segv_trace; sa.sa_flags = SA_ONSTACK;
+    sa.sa_sigaction = segv_trace; sa.sa_flags = SA_ONSTACK | SA_SIGINFO;
     for (int sg : { SIGSEGV, SIGBUS, SIGABRT, SIGFPE }) (void)sigaction(sg, &sa, nullptr);
     return true;
   }();
