@@ -450,7 +450,7 @@ int psigpu_find_seeds_device_packed(psigpu_ctx* ctx, const uint64_t* d_packed, c
                                     const psigpu_hit** d_hits, uint64_t* n_hits);
 
 /* Two chunks in flight (ABI 6).  A caller that has its next chunk resident before it needs the hits of the current one --
- * a loop that double-buffers its read batches, what the reference's chunked loop (src/psikt.cpp:240-270: load a chunk,
+ * a loop that double-buffers its read batches, what the reference's chunked loop (src/psikt.cpp:190-206: load a chunk,
  * seeds_all, next chunk) becomes when loading and seeding overlap -- begins chunk i + 1 before it ends chunk i: the device
  * does not wait for the host between two chunks (the synchronisation, the counters' way back, the next call's launches).
  *   _begin   queues the chunk's kernels on `stream` and returns; at most two chunks may be begun and not ended
