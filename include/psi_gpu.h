@@ -470,6 +470,13 @@ int psigpu_find_seeds_device_packed_begin(psigpu_ctx* ctx, const uint64_t* d_pac
                                           uint32_t step, uint64_t rec_offset, uint32_t flags, void* stream);
 int psigpu_find_seeds_device_end(psigpu_ctx* ctx, const psigpu_hit** d_hits, uint64_t* n_hits);
 
+/* Has anything the finder READS on the device changed since it was loaded?  Every array psigpu_load_graph / psigpu_load_index
+ * put on the device left a checksum behind; this recomputes them (a few milliseconds for 9 GB).  *n_changed = the arrays
+ * whose content is no longer what was loaded, `report` (may be NULL) their names.  A diagnostic of the load campaigns
+ * (tools/fuzz_modes.py asks it when a hit set is wrong); with PSIGPU_VERIFY_UPLOAD=1 in the environment every upload is
+ * also compared with its host source when it is made (PSIGPU_ERR_DEVICE from the loader on a difference). */
+int psigpu_verify_resident(psigpu_ctx* ctx, uint32_t* n_changed, char* report, uint64_t report_cap);
+
 /* Copies `n` records that psigpu_find_seeds_device left in HBM into host memory (blocking;
  * through this library's HIP runtime, so that a binding never has to load one of its own). */
 int psigpu_copy_hits(psigpu_ctx* ctx, psigpu_hit* host_dst, const psigpu_hit* d_src, uint64_t n);

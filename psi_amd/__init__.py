@@ -149,6 +149,7 @@ ABI = [
     ('psigpu_find_seeds_device_packed_begin', C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                                         C.c_uint64, C.c_uint32, _P]),
     ('psigpu_find_seeds_device_end', C.c_int, [_P, C.POINTER(_P), _U64P]),
+    ('psigpu_verify_resident', C.c_int, [_P, C.POINTER(C.c_uint32), C.c_char_p, C.c_uint64]),
     ('psigpu_find_seeds_device', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_uint64, C.c_uint32, _P, C.POINTER(_P), _U64P]),
     ('psigpu_get_counters', C.c_int, [_P, C.POINTER(Counters)]),
@@ -738,6 +739,14 @@ class SeedFinder:
         n = C.c_uint64()
         self._chk(lib().psigpu_find_seeds_device_end(self.ctx, C.byref(d_hits), C.byref(n)))
         return d_hits.value, n.value
+
+    def verify_resident(self) -> str:
+        """'' when every array the loaders put on the device still has the content it was loaded with, else the names of
+        those that changed (psigpu_verify_resident)."""
+        n = C.c_uint32()
+        buf = C.create_string_buffer(4096)
+        self._chk(lib().psigpu_verify_resident(self.ctx, C.byref(n), buf, 4096))
+        return buf.value.decode() if n.value else ''
 
     def seeds_all_device_packed(self, d_words_ptr: int, d_mask_ptr: int, d_read_off_ptr: int, n_reads: int, n_bases: int,
                                 step: int = 0, rec_offset: int = 0, flags: int = ALL, stream: int = 0):

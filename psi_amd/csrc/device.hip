@@ -3144,6 +3144,10 @@ struct psigpu_ctx {
   } fast[N_FAST];
   bool opt_no_lookahead = false;
   uint64_t lookahead_fallbacks = 0;
+  // what the graph and the index left on the device, with a checksum of every array taken when it was loaded
+  // (psigpu_verify_resident: has anything of it changed since?)
+  struct Resident { std::string name; const DevBuf* buf; const void* at; uint64_t bytes; uint64_t sum; };
+  std::vector<Resident> resident;
   // device-resident entry, two chunks in flight (psigpu_find_seeds_device_begin / _end): what was begun and not ended yet,
   // oldest first.  A chunk that could be queued (the default mode's kernels alone: enqueue_default) sits in a FastSlot;
   // any other chunk is answered by the synchronous entry when its turn to be ended comes.
@@ -3313,14 +3317,83 @@ static int upload_large(psigpu_ctx* ctx, void* dst, const void* src, size_t byte
   return PSIGPU_OK;
 }
 
-template <typename T>
-static int upload(psigpu_ctx* ctx, DevBuf& b, const T* src, uint64_t n, uint64_t pad_elems = 0)
+// ---- what the device holds of the graph and the index, checked against what was put there ------------------------
+// Three wrong answers of the load campaigns have in common the data a freshly loaded finder reads, not a
+// kernel.  Every array the loaders put on the device leaves a 64-bit checksum behind (a grid-stride kernel: 9 GB in a few
+// milliseconds); psigpu_verify_resident recomputes them -- "has anything the finder reads changed since it was loaded?" --
+// and with PSIGPU_VERIFY_UPLOAD=1 every upload is also checked against the same sum over its HOST source (one pass of
+// the CPU over the array: campaigns only).
+__device__ __host__ inline uint64_t resident_mix(uint64_t w, uint64_t i)
 {
+  uint64_t x = w + 0x9E3779B97F4A7C15ull * (i + 1);
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
+  return x;
+}
+__global__ void __launch_bounds__(256) k_checksum(const uint64_t* __restrict__ p, uint64_t n_words, unsigned long long* __restrict__ out)
+{
+  uint64_t acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) acc += resident_mix(p[i], i);
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+  if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+}
+static int device_checksum(psigpu_ctx* ctx, const void* d, uint64_t bytes, uint64_t* sum)
+{
+  *sum = 0;
+  const uint64_t n_words = bytes / 8;                 // (a tail of fewer than eight bytes is left out on both sides)
+  if (n_words == 0) return PSIGPU_OK;
+  TmpBuf acc;
+  HIPCHK(ctx, acc.alloc(8));
+  HIPCHK(ctx, hipMemset(acc.p, 0, 8));
+  const unsigned grid = (unsigned)std::min<uint64_t>((n_words + 255) / 256, 256 * 16);
+  k_checksum<<<grid, 256>>>(reinterpret_cast<const uint64_t*>(d), n_words, acc.as<unsigned long long>());
+  HIPCHK(ctx, hipMemcpy(sum, acc.p, 8, hipMemcpyDeviceToHost));
+  return PSIGPU_OK;
+}
+static uint64_t host_checksum(const void* h, uint64_t bytes)
+{
+  const uint64_t n_words = bytes / 8;
+  std::atomic<uint64_t> acc{ 0 };
+  const char* c = static_cast<const char*>(h);
+  parallel_for(n_words, 1u << 20, [&](uint64_t i0, uint64_t i1) {
+    uint64_t a = 0;
+    for (uint64_t i = i0; i < i1; ++i) { uint64_t w; memcpy(&w, c + 8 * i, 8); a += resident_mix(w, i); }
+    acc.fetch_add(a, std::memory_order_relaxed);
+  });
+  return acc.load();
+}
+// record (and, on request, verify against the host source) what was just put at `at` (inside b)
+static int resident_note(psigpu_ctx* ctx, const char* name, const DevBuf& b, const void* at, const void* host_src, uint64_t bytes)
+{
+  const bool env_verify = getenv("PSIGPU_VERIFY_UPLOAD") != nullptr;      // (read per load: a campaign switches it on for its own finders)
+  uint64_t sum = 0;
+  int st = device_checksum(ctx, at, bytes, &sum);
+  if (st != PSIGPU_OK) return st;
+  if (env_verify && host_src && sum != host_checksum(host_src, bytes)) {
+    fprintf(stderr, "[psigpu] PSIGPU_VERIFY_UPLOAD: %s (%llu bytes) is not on the device what it is on the host\n", name, (unsigned long long)bytes);
+    ctx->err = std::string("upload of ") + name + " failed verification";
+    return PSIGPU_ERR_DEVICE;
+  }
+  for (auto& r : ctx->resident)
+    if (r.buf == &b && r.at == at) { r.name = name; r.bytes = bytes; r.sum = sum; return PSIGPU_OK; }
+  ctx->resident.push_back(psigpu_ctx::Resident{ name, &b, at, bytes, sum });
+  return PSIGPU_OK;
+}
+static void resident_forget(psigpu_ctx* ctx, const DevBuf& b)
+{
+  auto& v = ctx->resident;
+  v.erase(std::remove_if(v.begin(), v.end(), [&](const psigpu_ctx::Resident& r) { return r.buf == &b; }), v.end());
+}
+
+template <typename T>
+static int upload(psigpu_ctx* ctx, DevBuf& b, const T* src, uint64_t n, uint64_t pad_elems = 0, const char* name = nullptr)
+{
+  if (name) resident_forget(ctx, b);
   HIPCHK(ctx, b.ensure((n + pad_elems) * sizeof(T) + 16));
   if (n * sizeof(T) >= (64u << 20)) { int st = upload_large(ctx, b.p, src, n * sizeof(T)); if (st != PSIGPU_OK) return st; }
   else
   if (n) HIPCHK(ctx, hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
   if (pad_elems) HIPCHK(ctx, hipMemset((char*)b.p + n * sizeof(T), 0, pad_elems * sizeof(T)));
+  if (name && n) return resident_note(ctx, name, b, b.p, src, n * sizeof(T));
   return PSIGPU_OK;
 }
 
@@ -3555,6 +3628,9 @@ int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value)
   else if (n == "no_lookahead") ctx->opt_no_lookahead = value != 0;
   else if (n == "expected_calls") { ctx->opt_expected_calls = value; ctx->auto_resolved = false; }
   else if (n == "expected_seeds") { ctx->opt_expected_seeds = value; ctx->auto_resolved = false; }
+  else if (n == "corrupt_resident") {                       // (test hook: one word of the starting loci changed on the device)
+    if (ctx->loci.p && ctx->n_loci) { const uint32_t v = (uint32_t)value; (void)hipMemcpy(ctx->loci.p, &v, 4, hipMemcpyHostToDevice); }
+  }
   else if (n == "wire8_roff_bits") { ctx->opt_wire8_roff_cap = (uint32_t)value; ctx->wire8_overflowed = false; }      // (test hook)
   else { ctx->err = "unknown option '" + n + "'"; return PSIGPU_ERR_ARG; }
   return PSIGPU_OK;
@@ -3666,12 +3742,12 @@ int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
   }
   });
   int st;
-  if ((st = upload(ctx, ctx->lite, lite.data(), n, 1))) return st;
-  if ((st = upload(ctx, ctx->nodes, recs.data(), n, 1))) return st;
-  if ((st = upload(ctx, ctx->node_id, g->node_id, n, 1))) return st;
-  if ((st = upload(ctx, ctx->lab2, lab2.data(), lab2.size()))) return st;
-  if ((st = upload(ctx, ctx->labn, labn.data(), labn.size()))) return st;
-  if ((st = upload(ctx, ctx->edge_to, g->edge_to, n ? g->edge_off[n] : 0, 1))) return st;
+  if ((st = upload(ctx, ctx->lite, lite.data(), n, 1, "graph: 16-byte node records"))) return st;
+  if ((st = upload(ctx, ctx->nodes, recs.data(), n, 1, "graph: 32-byte node records"))) return st;
+  if ((st = upload(ctx, ctx->node_id, g->node_id, n, 1, "graph: node ids"))) return st;
+  if ((st = upload(ctx, ctx->lab2, lab2.data(), lab2.size(), 0, "graph: 2-bit labels"))) return st;
+  if ((st = upload(ctx, ctx->labn, labn.data(), labn.size(), 0, "graph: N mask"))) return st;
+  if ((st = upload(ctx, ctx->edge_to, g->edge_to, n ? g->edge_off[n] : 0, 1, "graph: edge targets"))) return st;
   ctx->n_nodes = n;
   ctx->have_graph = true;
   ctx->id_base = n ? g->node_id[0] : 0;
@@ -3715,9 +3791,9 @@ static int upload_segments(psigpu_ctx* ctx, const psigpu_index_view* x, const st
   if (foreign) { ctx->err = "index does not belong to this graph"; return PSIGPU_ERR_ARG; }
   segs[x->n_segs] = SegRec{ x->seg_start[x->n_segs], 0, 0 };
   int st;
-  if ((st = upload(ctx, seg, segs.data(), segs.size(), 1))) return st;
-  if ((st = upload(ctx, seg_dir, x->seg_dir, x->n_dir, 1))) return st;
-  return upload(ctx, seg_rank, x->seg_node, x->n_segs, 1);
+  if ((st = upload(ctx, seg, segs.data(), segs.size(), 1, "index: segment table"))) return st;
+  if ((st = upload(ctx, seg_dir, x->seg_dir, x->n_dir, 1, "index: segment directory"))) return st;
+  return upload(ctx, seg_rank, x->seg_node, x->n_segs, 1, "index: segment node ranks");
 }
 
 // one part's arrays -> the device; every array length follows from the part's text length
@@ -3745,9 +3821,9 @@ static int load_part(psigpu_ctx* ctx, const psigpu_index_view* m, uint32_t sa_ra
   }
   int st;
   fp.release();
-  if ((st = upload(ctx, fp.blocks, (const RankBlock*)m->bwt_blocks, fm_ok ? m->n_blocks : 0, 1))) return st;
+  if ((st = upload(ctx, fp.blocks, (const RankBlock*)m->bwt_blocks, fm_ok ? m->n_blocks : 0, 1, "index: rank blocks"))) return st;
   fp.exc_shift = fm_ok ? m->exc_shift : EXC_SUPER_SHIFT;
-  if ((st = upload(ctx, fp.samples, m->sa_samples, m->n_samples, 1))) return st;
+  if ((st = upload(ctx, fp.samples, m->sa_samples, m->n_samples, 1, "index: suffix array samples"))) return st;
   {
     // the exception rows and, behind them, the per-super-block counts (FMView::exc_super)
     const uint64_t n_super = fm_ok ? ((m->n_blocks - 1) >> m->exc_shift) + 1 : 0;
@@ -3755,14 +3831,16 @@ static int load_part(psigpu_ctx* ctx, const psigpu_index_view* m, uint32_t sa_ra
     if (m->n_exc) HIPCHK(ctx, hipMemcpy(fp.exc_row.p, m->exc_row, m->n_exc * 4, hipMemcpyHostToDevice));
     if (n_super) HIPCHK(ctx, hipMemcpy(fp.exc_row.as<uint32_t>() + m->n_exc, m->exc_super, n_super * 4, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemset(fp.exc_row.as<uint32_t>() + m->n_exc + n_super, 0, 4));
+    resident_forget(ctx, fp.exc_row);
+    if (m->n_exc) { int rs = resident_note(ctx, "index: exception rows", fp.exc_row, fp.exc_row.p, m->exc_row, m->n_exc * 4); if (rs != PSIGPU_OK) return rs; }
   }
-  if ((st = upload(ctx, fp.exc_sa, m->exc_sa, m->n_exc, 1))) return st;
+  if ((st = upload(ctx, fp.exc_sa, m->exc_sa, m->n_exc, 1, "index: exception positions"))) return st;
   if (m->text4) {
-    if ((st = upload(ctx, fp.text4, m->text4, m->text_len / 16 + 2))) return st;
+    if ((st = upload(ctx, fp.text4, m->text4, m->text_len / 16 + 2, 0, "index: 4-bit text"))) return st;
     fp.have_text4 = true;
   }
   if (m->ftab_len && m->ftab) {
-    if ((st = upload(ctx, fp.ftab, m->ftab, 2ull << (2 * m->ftab_len)))) return st;
+    if ((st = upload(ctx, fp.ftab, m->ftab, 2ull << (2 * m->ftab_len), 0, "index: interval table"))) return st;
     fp.ftab_len = m->ftab_len;
   }
   if ((st = upload_segments(ctx, m, ids, fp.seg, fp.seg_dir, fp.seg_rank))) return st;
@@ -3801,6 +3879,9 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
   int st;
   std::vector<uint64_t> ids(ctx->n_nodes);
   if (ctx->n_nodes) HIPCHK(ctx, hipMemcpy(ids.data(), ctx->node_id.p, ctx->n_nodes * 8, hipMemcpyDeviceToHost));
+  // (the checksums of the index arrays go with the arrays: every part is loaded again below)
+  ctx->resident.erase(std::remove_if(ctx->resident.begin(), ctx->resident.end(),
+                                     [](const psigpu_ctx::Resident& r) { return r.name.compare(0, 6, "index:") == 0; }), ctx->resident.end());
   while (ctx->parts.size() > 1) { ctx->parts.back()->release(); ctx->parts.pop_back(); }
   if ((st = load_part(ctx, x, x->sa_rate, fm_ok, ids, ctx->p0()))) return st;
   // further parts (an index whose text passes the 32-bit row limit): each a complete FM index of its own
@@ -3818,7 +3899,7 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
     parallel_for(x->n_loci, 1u << 16, [&](uint64_t i0, uint64_t i1) {
       for (uint64_t i = i0; i < i1; ++i) lcp[i] = make_uint2(x->loci_node[i], x->loci_off[i]);
     });
-    if ((st = upload(ctx, ctx->loci, lcp, x->n_loci, 1))) return st;
+    if ((st = upload(ctx, ctx->loci, lcp, x->n_loci, 1, "index: starting loci"))) return st;
   }
   // (the per-row records of the FM modes are made when an FM mode first answers a chunk: the default mode
   // never reads them, and at whole-genome size they are 70 GB)
@@ -6480,6 +6561,32 @@ void psigpu_free_hits(psigpu_hits* hits)
   if (hits->data) g_pinned.put(hits->data);
   hits->data = nullptr;
   hits->n = 0;
+}
+
+int psigpu_verify_resident(psigpu_ctx* ctx, uint32_t* n_changed, char* report, uint64_t report_cap)
+{
+  if (!ctx || !n_changed) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  *n_changed = 0;
+  std::string rep;
+  for (const auto& r : ctx->resident) {
+    uint64_t sum = 0;
+    int st = device_checksum(ctx, r.at, r.bytes, &sum);
+    if (st != PSIGPU_OK) return st;
+    if (sum != r.sum || r.buf->p != r.at) {
+      ++*n_changed;
+      if (!rep.empty()) rep += "; ";
+      rep += r.name + " (" + std::to_string(r.bytes) + " bytes)";
+    }
+  }
+  if (report && report_cap) {
+    const size_t m = std::min<size_t>(rep.size(), (size_t)report_cap - 1);
+    memcpy(report, rep.data(), m);
+    report[m] = 0;
+  }
+  return PSIGPU_OK;
 }
 
 int psigpu_get_counters(const psigpu_ctx* ctx, psigpu_counters* out)

@@ -1965,3 +1965,33 @@ def test_device_entry_two_chunks_in_flight(query_mode):
         assert _eq(psi_amd.sort_unique(f.copy_hits(ptr, n)), wp)
     f.seeds_all_device_begin(chunks[0][0].data_ptr(), chunks[0][1].data_ptr(), chunks[0][2], chunks[0][3], step=step)
     f.close()                                             # (a chunk begun and never ended: the context drains it)
+
+
+def test_resident_arrays_keep_their_checksums():
+    """psigpu_verify_resident: every array the loaders put on the device is what it was when it was loaded -- after queries
+    in every entry point -- and a word changed behind the library's back (test hook) is reported by the array's name; loading
+    the index again makes the record whole.  PSIGPU_VERIFY_UPLOAD compares every upload with its host source."""
+    g, reads = _x_case()
+    k = 21
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(2, rng_seed=3)
+    assert f.verify_resident() == ''
+    want = psi_amd.sort_unique(f.seeds_all(reads[:300], step=5))
+    f.find_mems(reads[:50])
+    assert f.verify_resident() == ''
+    f.set_option('corrupt_resident', 0x7FFFFFF0)
+    rep = f.verify_resident()
+    assert 'starting loci' in rep and 'rank blocks' not in rep, rep
+    f.set_path_index(f.pindex)
+    assert f.verify_resident() == ''
+    assert _eq(psi_amd.sort_unique(f.seeds_all(reads[:300], step=5)), want)
+    f.close()
+    os.environ['PSIGPU_VERIFY_UPLOAD'] = '1'
+    try:
+        f = psi_amd.SeedFinder(g, k)
+        f.create_path_index(2, rng_seed=3)
+        assert f.verify_resident() == ''
+        assert _eq(psi_amd.sort_unique(f.seeds_all(reads[:300], step=5)), want)
+        f.close()
+    finally:
+        os.environ.pop('PSIGPU_VERIFY_UPLOAD', None)

@@ -115,6 +115,8 @@ def main():
                               'patched', patched, f.counters(), flush=True)
                         a, b = set(map(tuple, got.tolist())), set(map(tuple, want.tolist()))
                         print(' extra', sorted(a - b)[:6], 'missing', sorted(b - a)[:6], flush=True)
+                        # is what the finder reads on the device still what was loaded?
+                        print(' arrays on the device that changed since they were loaded:', repr(f.verify_resident()), flush=True)
                         # the same finder again (a glitch of that call, or of what the finder built?), then a new finder
                         again = psi_amd.sort_unique(f.seeds_all(reads, step=step))
                         print(' same finder again:', 'ok' if (again.shape == want.shape and (again == want).all()) else 'WRONG AGAIN', flush=True)
@@ -185,10 +187,18 @@ def main():
                         f2.set_path_index(px)
                         gm = f2.find_mems(reads, max_mem=mm)
                         wm = np.array(brute.find_mems(g, paths_ids, reads, k, px.trims(), gocc, mm), dtype=np.uint64).reshape(-1, 6)
-                        f2.close()
                         if not (gm.shape == wm.shape and (gm == wm).all()):
-                            print('MEM MISMATCH', seed, k, npaths, patched, gocc, mm, gm.shape, wm.shape, flush=True)
+                            print('MEM MISMATCH', seed, k, npaths, patched, gocc, mm, gm.shape, wm.shape,
+                                  '| arrays of THIS finder that changed on the device since they were loaded:', repr(f2.verify_resident()), flush=True)
+                            f6 = psi_amd.SeedFinder(pg, k, mode=mode, gocc_threshold=gocc)
+                            f6.set_path_index(px)
+                            g6 = f6.find_mems(reads, max_mem=mm)
+                            a6, b6 = set(map(tuple, gm.tolist())), set(map(tuple, wm.tolist()))
+                            print(' extra', sorted(a6 - b6)[:4], 'missing', sorted(b6 - a6)[:4], 'duplicates', len(gm) - len(a6),
+                                  '| a new finder:', 'ok' if (g6.shape == wm.shape and (g6 == wm).all()) else 'WRONG TOO',
+                                  '| arrays on the device that changed since they were loaded:', repr(f6.verify_resident()), flush=True)
                             sys.exit(1)
+                        f2.close()
                     f.close()
                     n_cases += 1
         if (seed - first) % 25 == 24:
