@@ -37,6 +37,14 @@ def test_no_gpu_means_loud_failure(ref_data):
     g = psi_amd.Graph.load(os.path.join(ref_data, 'tiny.gfa'))
     with pytest.raises(psi_amd.PsiGpuError):
         psi_amd.SeedFinder(g, 10)
+    # ... and the entry points that take a context refuse a null one (no device is touched for that)
+    L = psi_amd.lib()
+    import ctypes as C
+    n, n32, p = C.c_uint64(), C.c_uint32(), C.c_void_p()
+    assert L.psigpu_find_seeds_device_begin(None, None, None, 0, 0, 10, 0, 0, psi_amd.ALL, None) == 1      # PSIGPU_ERR_ARG
+    assert L.psigpu_find_seeds_device_packed_begin(None, None, None, None, 0, 0, 10, 0, 0, psi_amd.ALL, None) == 1
+    assert L.psigpu_find_seeds_device_end(None, C.byref(p), C.byref(n)) == 1
+    assert L.psigpu_verify_resident(None, C.byref(n32), None, 0) == 1
 
 
 # ---------------------------------------------------------------------------------------
