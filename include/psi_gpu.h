@@ -455,10 +455,13 @@ int psigpu_find_seeds_device_packed(psigpu_ctx* ctx, const uint64_t* d_packed, c
  * does not wait for the host between two chunks (the synchronisation, the counters' way back, the next call's launches).
  *   _begin   queues the chunk's kernels on `stream` and returns; at most two chunks may be begun and not ended
  *            (PSIGPU_ERR_STATE for a third); arguments as for psigpu_find_seeds_device / _device_packed; the reads and
- *            offsets must stay untouched until the chunk's _end
- *   _end     waits for the OLDEST chunk begun and hands out its hits: library-owned device memory, valid until the third
- *            _begin after the chunk's own (or the next call of another entry point of this context); psigpu_get_counters
- *            describes that chunk
+ *            offsets must stay untouched until the chunk's _end.  The chunks in flight share one workspace and are kept
+ *            apart by stream order alone: a _begin on another stream than the chunk still in flight is refused
+ *            (PSIGPU_ERR_STATE); with nothing in flight any stream will do
+ *   _end     waits for the OLDEST chunk begun and hands out its hits: library-owned device memory, valid until the NEXT
+ *            _end of this context (or the next call of another entry point of it) -- a chunk answered inside its _end
+ *            by the synchronous entry (below) leaves its records in the buffer the next such chunk reuses; work queued on
+ *            the chunk's stream before that next _end is ordered before the reuse.  psigpu_get_counters describes that chunk
  * A chunk that needs more than the default mode's kernels (another query mode, a walk-capped table with a traverser pass,
  * tables not made yet, buffers that would have to grow under the chunk in flight, reads that are not of one length behind
  * PSIGPU_UNIFORM_READS) is answered by psigpu_find_seeds_device inside its _end: same records, no overlap.  While chunks
@@ -509,7 +512,8 @@ typedef struct psigpu_counters {
   uint64_t n_locate_steps;                     /* LF steps K2 walked from occurrences to sampled suffix-array rows (sa_rate > 1) */
   uint32_t lookahead_subbatches;               /* psigpu_find_seeds*: sub-batches of the call whose kernels were queued while the one
                                                 * before was still in flight (default mode, reads and offsets in pinned memory) */
-  uint32_t reserved3;
+  uint32_t fused_step;                         /* 1: the call's seeds were packed, probed and emitted by ONE kernel (k_kmer_step: default mode,
+                                                * every seed answered by the k-mer table); ms_probe is then that kernel, ms_locate 0 */
   uint64_t lookahead_fallbacks;                /* since the context was made: chunks handed from that arrangement to the synchronous
                                                 * loop (more hits than expected, a seed with many hits, a wire field too narrow ...) */
   uint64_t stale_handbacks;                    /* since the context was made: calls whose counter block came back from the device with

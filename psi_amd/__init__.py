@@ -84,7 +84,7 @@ class Counters(C.Structure):
                 ('ms_total', C.c_float), ('ms_probe', C.c_float), ('ms_locus_table_build', C.c_float),
                 ('search_launches', C.c_uint32),
                 ('traverse_launches', C.c_uint32), ('sorted_in_place', C.c_uint32), ('wire_bytes_per_hit', C.c_uint32),
-                ('n_locate_steps', C.c_uint64), ('lookahead_subbatches', C.c_uint32), ('reserved3', C.c_uint32),
+                ('n_locate_steps', C.c_uint64), ('lookahead_subbatches', C.c_uint32), ('fused_step', C.c_uint32),
                 ('lookahead_fallbacks', C.c_uint64), ('stale_handbacks', C.c_uint64)]
 
     def as_dict(self):
@@ -734,7 +734,7 @@ class SeedFinder:
                                                               self.seed_len, step, rec_offset, flags, stream))
 
     def seeds_all_device_end(self):
-        """(device pointer, n_hits) of the oldest chunk begun; valid until the third begin after that chunk's."""
+        """(device pointer, n_hits) of the oldest chunk begun; valid until the next end() on this finder."""
         d_hits = C.c_void_p()
         n = C.c_uint64()
         self._chk(lib().psigpu_find_seeds_device_end(self.ctx, C.byref(d_hits), C.byref(n)))

@@ -153,6 +153,9 @@ struct DevCounters {
   PaddedCounter serial;          // the call's serial number, stored by the kernel that zeroes the counters: what comes back to the
                                  // host must carry the serial of THIS call (a stale hand-back is detected, not believed)
   PaddedCounter dbg0, dbg1;      // diagnostics (builds with -DTRAV_STATS)
+  PaddedCounter ticket;          // k_kmer_step: the next tile to hand out (workgroups take tiles in the order they start)
+  StripedCounter n_hits_on_s;    // ... its on-path hits, added per workgroup (the host adds them to n_hits_on)
+  __host__ unsigned long long hits_on() const { return n_hits_on.v + n_hits_on_s.total(); }
 };
 
 // Seeds of up to 31 bases are one 64-bit word (2 bits per base, first base most significant) and that is what every
@@ -1736,6 +1739,39 @@ __device__ __forceinline__ uint2 ext_counts(const uint4 e /* off_a, off_b, on_cn
   return r;
 }
 
+// One seed's look-up: the slot of `key` found along the probe sequence that starts at `h` with the slot `v` already
+// loaded (the caller issues the first load of several seeds before it looks at any: their latencies overlap).  Returns what
+// k_kmer_emit turns into records: (x, y) the position or the record's index, z / w the on-path and off-path counts.
+__device__ __forceinline__ uint4 kt_resolve(const KmerTableView& kt, uint64_t key, uint64_t h, uint4 v, bool want_on, bool want_off,
+                                            uint32_t gocc_thr)
+{
+  uint4 res = make_uint4(0, 0, 0, 0);
+  uint32_t t = 0;
+  while (true) {
+    const uint64_t w = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    const bool empty = v.z == NIL && v.w == NIL;          // (an all-T 31-mer with an EXT record is all ones in w)
+    if (!empty && (w & K16_KEY) == key) {
+      const uint64_t type = w >> 62;
+      res.x = v.z; res.y = v.w;
+      if (type == K16_EXT) {
+        const uint4 e = load16(reinterpret_cast<const uint4*>(kt.ext + v.z) + 1);      // off_a, off_b, on_cnt, off_cnt
+        const uint2 cc = ext_counts(e, want_on, want_off, gocc_thr);
+        res.z = RES_EXT | cc.x;
+        res.w = cc.y;
+      } else {
+        if (want_on && type != K16_OFF1) res.z = 1u | RES_INLINE;
+        // (one occurrence and one locus at the same position, both phases asked for: one hit)
+        if (want_off && type != K16_ON1 && !(want_on && type == K16_BOTH1)) res.w = 1u | RES_INLINE;
+      }
+      break;
+    }
+    if (empty) break;
+    h = kt_next(h, t, kt.n_slots);
+    v = load16(kt.ht + h);
+  }
+  return res;
+}
+
 template <bool R8>
 __global__ void __launch_bounds__(256)
 k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params,
@@ -1755,30 +1791,8 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
     const uint64_t key = seed_key[seed];
     uint4 res = make_uint4(0, 0, 0, 0);
     if (key != KEY_INVALID) {
-      uint64_t h = kt_home(key, kt.n_slots);
-      uint32_t t = 0;
-      while (true) {
-        const uint4 v = load16(kt.ht + h);
-        const uint64_t w = (uint64_t)v.x | ((uint64_t)v.y << 32);
-        const bool empty = v.z == NIL && v.w == NIL;          // (an all-T 31-mer with an EXT record is all ones in w)
-        if (!empty && (w & K16_KEY) == key) {
-          const uint64_t type = w >> 62;
-          res.x = v.z; res.y = v.w;
-          if (type == K16_EXT) {
-            const uint4 e = load16(reinterpret_cast<const uint4*>(kt.ext + v.z) + 1);      // off_a, off_b, on_cnt, off_cnt
-            const uint2 cc = ext_counts(e, want_on, want_off, gocc_thr);
-            res.z = RES_EXT | cc.x;
-            res.w = cc.y;
-          } else {
-            if (want_on && type != K16_OFF1) res.z = 1u | RES_INLINE;
-            // (one occurrence and one locus at the same position, both phases asked for: one hit)
-            if (want_off && type != K16_ON1 && !(want_on && type == K16_BOTH1)) res.w = 1u | RES_INLINE;
-          }
-          break;
-        }
-        if (empty) break;
-        h = kt_next(h, t, kt.n_slots);
-      }
+      const uint64_t h = kt_home(key, kt.n_slots);
+      res = kt_resolve(kt, key, h, load16(kt.ht + h), want_on, want_off, gocc_thr);
     }
     if constexpr (R8) {
       uint64_t r8 = (uint64_t)res.x;
@@ -2311,6 +2325,31 @@ k_fm_locate_direct(MapView mv, SeedOut so, bool have_off, const LocusEnt* __rest
   }
 }
 
+// ... and what the emission needs of a seed, from its look-up result (the 16-byte form); EXT: the record is read here
+__device__ __forceinline__ SeedHits res_to_hits(const uint4 r, const KmerSlot* __restrict__ ext, bool want_on, bool want_off, uint32_t gocc_thr,
+                                                bool counts_from_record)
+{
+  SeedHits sh = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  sh.con = r.z & RES_CNT;
+  uint32_t coff = r.w & ~RES_INLINE;
+  if (r.z & RES_EXT) {
+    if (counts_from_record || (sh.con | coff)) {
+      const uint4* e = reinterpret_cast<const uint4*>(ext + r.x);
+      const uint4 e0 = e[0], e1 = e[1];               // key, on_a, on_b | off_a, off_b, on_cnt, off_cnt
+      if (counts_from_record) { const uint2 cc = ext_counts(e1, want_on, want_off, gocc_thr); sh.con = cc.x; coff = cc.y; }
+      if (sh.con) {
+        if (e1.z & KT_INLINE) { sh.on_node = e0.z; sh.on_noff = e0.w; sh.aux = AUX_RESOLVED; }
+        else { sh.lo = e0.z; sh.aux = AUX_ONPOS; }
+      }
+      if (coff) { sh.ofirst = e1.x; sh.onoff = e1.y; sh.ocnt = (e1.w & KT_INLINE) ? (1u | OFF_INLINE) : coff; }
+    }
+  } else {
+    if (sh.con) { sh.on_node = r.x; sh.on_noff = r.y; sh.aux = AUX_RESOLVED; }
+    if (coff) { sh.ofirst = r.x; sh.onoff = r.y; sh.ocnt = 1u | OFF_INLINE; }
+  }
+  return sh;
+}
+
 // K2 of the k-mer table mode: a stream.  The probe left 16 bytes per seed (k_kmer_probe); this
 // kernel turns them into records at the scan-given offsets.  EMIT_G rounds of 64 seeds are
 // requested together, then emitted one after the other in seed order, with the same two paths as
@@ -2383,29 +2422,206 @@ k_kmer_emit(MapView mv, const uint4* __restrict__ seed_res, const KmerSlot* __re
     }
 #pragma unroll
     for (int g = 0; g < EMIT_G; ++g) {
-      const uint4 r = rr[g];
       const uint2 si = ss[g];
-      SeedHits sh = { 0, 0, 0, 0, 0, 0, 0, 0 };
-      sh.con = r.z & RES_CNT;
-      uint32_t coff = r.w & ~RES_INLINE;
-      if (r.z & RES_EXT) {
-        if (R8 || (sh.con | coff)) {
-          const uint4* e = reinterpret_cast<const uint4*>(ext + r.x);
-          const uint4 e0 = e[0], e1 = e[1];               // key, on_a, on_b | off_a, off_b, on_cnt, off_cnt
-          if constexpr (R8) { const uint2 cc = ext_counts(e1, want_on, want_off, gocc_thr); sh.con = cc.x; coff = cc.y; }
-          if (sh.con) {
-            if (e1.z & KT_INLINE) { sh.on_node = e0.z; sh.on_noff = e0.w; sh.aux = AUX_RESOLVED; }
-            else { sh.lo = e0.z; sh.aux = AUX_ONPOS; }
-          }
-          if (coff) { sh.ofirst = e1.x; sh.onoff = e1.y; sh.ocnt = (e1.w & KT_INLINE) ? (1u | OFF_INLINE) : coff; }
-        }
-      } else {
-        if (sh.con) { sh.on_node = r.x; sh.on_noff = r.y; sh.aux = AUX_RESOLVED; }
-        if (coff) { sh.ofirst = r.x; sh.onoff = r.y; sh.ocnt = 1u | OFF_INLINE; }
-      }
+      const SeedHits sh = res_to_hits(rr[g], ext, want_on, want_off, gocc_thr, R8);
       const uint32_t cnt = sh.con + (sh.ocnt & ~OFF_INLINE);     // on-path occurrences first, then the loci
       emit_round(mv, ent, sh, cnt, si, woff, rec_offset, hits, cap, !plain_stores);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// The default step in ONE kernel (round 5): seeding, the k-mer table probe and the emission of a TILE of seeds by one
+// workgroup, where rounds 1-4 ran k_seed_pack -> k_kmer_probe -> k_kmer_emit with 8 bytes of key and 8 bytes of result per
+// seed written and read back in between (a third of the step's traffic, two launches, and a probe kernel with one load
+// in flight per lane).  A workgroup takes the next tile (KS_R rounds of 256 seeds; a ticket, so tiles start in order),
+// packs its seeds' keys in registers, issues the first table load of all its rounds before it looks at any, counts the
+// tile's hits and learns its first output slot by a decoupled look-back over the tiles before it: tile_state[t] is ONE
+// 64-bit word -- flag (aggregate / inclusive prefix), the call's serial number, the count -- so a word is either this
+// call's or ignored and nothing needs a fence.  The records come out in seed order exactly as k_kmer_emit writes them
+// (emit_round: the transposed stores, the spread of a seed with many hits over the wave).
+// The general (not equal-length) reads locate their read as k_seed_pack does, from the scanned seed offsets.
+// ------------------------------------------------------------------------------------
+constexpr int KS_R = 4;
+constexpr uint32_t KS_TILE = 256 * KS_R;
+constexpr uint64_t KS_AGG = 1ull << 62, KS_PFX = 2ull << 62, KS_VAL = (1ull << 40) - 1;
+constexpr uint32_t KS_SERIAL = (1u << 22) - 1;
+__device__ __forceinline__ uint64_t ks_word(uint64_t flag, uint32_t serial22, uint64_t v) { return flag | ((uint64_t)serial22 << 40) | v; }
+
+template <bool PACKED, bool UNIFORM>
+__global__ void __launch_bounds__(256)
+k_kmer_step(const char* __restrict__ bases, const uint64_t* __restrict__ read_off, const uint64_t* __restrict__ seed_off, uint64_t n_reads,
+            const uint64_t* __restrict__ params, uint64_t seeds_cap, uint64_t n_bases, uint32_t k, uint32_t step, PackedIn pk, UniformIn un,
+            KmerTableView kt, MapView mv, const LocusEnt* __restrict__ ent, bool want_on, bool want_off, uint32_t gocc_thr,
+            uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap, uint64_t* tile_state, uint32_t serial22,
+            DevCounters* ctr, bool plain_stores)
+{
+  __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_cnt[KS_R * 4];
+  __shared__ uint64_t s_prefix;
+  const uint32_t lane = lane_id(), wib = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_tile = (uint32_t)atomicAdd(&ctr->ticket.v, 1ull);
+  __syncthreads();
+  const uint64_t tile = s_tile;
+  const uint64_t n_seeds = min(params[0], seeds_cap), ratio = params[1];
+  const uint64_t t0 = tile * KS_TILE;
+  if (t0 >= n_seeds) return;                      // (the grid is sized by the upper bound of the seed count)
+
+  // ---- the seeds of this lane: read, offset in the read, key ----------------------------------------------------
+  uint64_t key[KS_R];
+  uint2 si[KS_R];
+  uint32_t nok = 0;
+  const uint32_t nw = (k + 7) >> 3;
+#pragma unroll
+  for (int r = 0; r < KS_R; ++r) {
+    const uint64_t s = t0 + (uint64_t)r * 256 + threadIdx.x;
+    key[r] = KEY_INVALID; si[r] = make_uint2(0, 0);
+    if (s >= n_seeds) continue;
+    uint64_t rd, so0, ro;
+    if constexpr (UNIFORM) {
+      rd = (uint32_t)s / un.spr; so0 = rd * un.spr; ro = rd * un.len;
+      // the claim, checked where it is used: this read starts and ends where equal lengths put it
+      if (read_off[rd] != ro || read_off[rd + 1] != ro + un.len) ctr->not_uniform.v = 1ull;
+    } else {
+      rd = __umul64hi(s, ratio);
+      if (rd >= n_reads) rd = n_reads - 1;
+      so0 = seed_off[rd];
+      const uint64_t so1 = seed_off[rd + 1];
+      if (!(so0 <= s && s < so1)) {               // wrong guess (ragged reads): gallop to a bracket, bisect
+        uint64_t l = rd, hi;
+        if (so0 <= s) {
+          uint64_t d = 1;
+          while (l + d < n_reads && seed_off[l + d] <= s) { l += d; d <<= 1; }
+          hi = min(l + d, n_reads);
+        } else {
+          uint64_t d = 1;
+          hi = l;
+          while (d < hi && seed_off[hi - d] > s) { hi -= d; d <<= 1; }
+          l = d < hi ? hi - d : 0;
+        }
+        while (hi - l > 1) {                      // invariant: seed_off[l] <= s < seed_off[hi]
+          const uint64_t mid = (l + hi) >> 1;
+          if (seed_off[mid] <= s) l = mid; else hi = mid;
+        }
+        rd = l; so0 = seed_off[l];
+      }
+      ro = read_off[rd];
+    }
+    const uint64_t st = (s - so0) * step;
+    si[r] = make_uint2((uint32_t)rd, (uint32_t)st);
+    uint64_t kk = 0;
+    uint32_t ok = 1;
+    if constexpr (PACKED) {
+      const uint64_t* __restrict__ P = reinterpret_cast<const uint64_t*>(bases);
+      const uint64_t q = ro + st + pk.bias2;
+      const uint64_t w = q >> 5;
+      const uint32_t sh = 2u * (uint32_t)(q & 31);
+      const uint64_t w0 = P[w], w1 = P[w + 1];    // (the buffer is padded: the word behind the window is loaded, none of its bits used)
+      kk = (sh ? (w0 << sh) | (w1 >> (64 - sh)) : w0) >> (64 - 2 * k);
+      if (pk.mask) {
+        const uint64_t qm = ro + st + pk.biasm;
+        const uint32_t ms = (uint32_t)(qm & 63);
+        const uint64_t m0 = pk.mask[qm >> 6], m1 = pk.mask[(qm >> 6) + 1];
+        const uint64_t win = ms ? (m0 >> ms) | (m1 << (64 - ms)) : m0;
+        ok = (win & ((1ull << k) - 1ull)) == 0;
+      }
+    } else {
+      const uint64_t abs0 = ro + st;
+      if (abs0 + 8ull * nw <= n_bases) {
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w)
+          if (w < nw) {
+            uint64_t x;
+            __builtin_memcpy(&x, bases + abs0 + 8 * w, 8);
+            const uint32_t take = min(8u, k - 8 * w);
+            kk = (kk << (2 * take)) | pack8(x, take, ok);
+          }
+      } else {
+        const char* p = bases + abs0;
+        for (uint32_t i = 0; i < k; ++i) {        // tail of the buffer: byte loads
+          int b = base2(p[i]);
+          if (b < 0) { ok = 0; b = 0; }
+          kk = (kk << 2) | (uint64_t)b;
+        }
+      }
+    }
+    key[r] = ok ? kk : KEY_INVALID;
+    nok += ok;
+  }
+
+  // ---- one probe per seed: every round's first load in flight before the first is looked at ----------------------------
+  uint64_t h[KS_R];
+  uint4 v[KS_R];
+#pragma unroll
+  for (int r = 0; r < KS_R; ++r) {
+    h[r] = 0; v[r] = make_uint4(0, 0, NIL, NIL);
+    if (key[r] != KEY_INVALID) { h[r] = kt_home(key[r], kt.n_slots); v[r] = load16(kt.ht + h[r]); }
+  }
+  uint4 res[KS_R];
+  uint32_t on_sum = 0, n_live = 0;
+#pragma unroll
+  for (int r = 0; r < KS_R; ++r) {
+    res[r] = make_uint4(0, 0, 0, 0);
+    if (key[r] != KEY_INVALID) res[r] = kt_resolve(kt, key[r], h[r], v[r], want_on, want_off, gocc_thr);
+    const uint32_t con = res[r].z & RES_CNT, coff = res[r].w & ~RES_INLINE;
+    on_sum += con; n_live += con != 0;
+    uint32_t c = con + coff;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (lane == 0) s_cnt[r * 4 + wib] = c;
+  }
+  for (int d = 32; d > 0; d >>= 1) { nok += __shfl_down(nok, d); on_sum += __shfl_down(on_sum, d); n_live += __shfl_down(n_live, d); }
+  if (lane == 0) {
+    if (nok) ctr->n_seeds_valid.add((unsigned long long)nok);
+    if (n_live) ctr->n_live.add((unsigned long long)n_live);
+    if (on_sum) ctr->n_hits_on_s.add((unsigned long long)on_sum);
+  }
+  __syncthreads();
+
+  // ---- first output slot of the tile: decoupled look-back (wave 0) ---------------------------------------------------
+  if (wib == 0) {
+    uint64_t agg = 0;
+#pragma unroll
+    for (int i = 0; i < KS_R * 4; ++i) agg += s_cnt[i];
+    uint64_t excl = 0;
+    if (tile != 0) {
+      if (lane == 0) __hip_atomic_store(&tile_state[tile], ks_word(KS_AGG, serial22, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t top = (int64_t)tile - 1;              // the window: tiles top, top - 1, ... top - 63 on lanes 0 .. 63
+      while (true) {
+        const int64_t idx = top - (int64_t)lane;
+        // (before tile 0: an inclusive prefix of nothing)
+        const uint64_t w = idx >= 0 ? __hip_atomic_load(&tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ks_word(KS_PFX, serial22, 0);
+        const bool ready = (w >> 62) != 0 && (uint32_t)((w >> 40) & KS_SERIAL) == serial22;
+        const uint64_t m_ready = __ballot(ready), m_pfx = __ballot(ready && (w >> 62) == 2);
+        const uint32_t n_ready = m_ready == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m_ready) - 1u;      // tiles ready from the window's top
+        const uint32_t first_pfx = m_pfx ? (uint32_t)__ffsll((long long)m_pfx) - 1u : 64u;
+        if (first_pfx < n_ready || (first_pfx == 64u && n_ready == 64u)) {
+          const uint32_t upto = first_pfx < 64u ? first_pfx : 63u;      // add lanes 0 .. upto
+          uint64_t part = lane <= upto ? (w & KS_VAL) : 0ull;
+          for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+          excl += part;
+          if (first_pfx < 64u) break;
+          top -= 64;
+        } else __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    if (lane == 0) {
+      __hip_atomic_store(&tile_state[tile], ks_word(KS_PFX, serial22, excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_prefix = excl;
+      if (t0 + KS_TILE >= n_seeds) ctr->n_hits_tab.v = excl + agg;      // the last tile: what the step wrote (or would have, past cap)
+    }
+  }
+  __syncthreads();
+
+  // ---- records ---------------------------------------------------------------------------------------------------
+  uint64_t woff = s_prefix;
+#pragma unroll
+  for (int r = 0; r < KS_R; ++r) {
+    uint64_t mine = woff;
+    for (uint32_t w = 0; w < wib; ++w) mine += s_cnt[r * 4 + w];
+    const SeedHits sh = res_to_hits(res[r], kt.ext, want_on, want_off, gocc_thr, false);
+    const uint32_t cnt = sh.con + (sh.ocnt & ~OFF_INLINE);     // on-path occurrences first, then the loci
+    emit_round(mv, ent, sh, cnt, si[r], mine, rec_offset, hits, cap, !plain_stores);
+    woff += (uint64_t)s_cnt[r * 4] + s_cnt[r * 4 + 1] + s_cnt[r * 4 + 2] + s_cnt[r * 4 + 3];
   }
 }
 
@@ -3083,6 +3299,9 @@ struct psigpu_ctx {
   float lkt_build_ms = 0.f;
   std::string lkt_note;
   DevBuf w_seedout, w_seedres, w_iv_tiles_off, w_defer, w_hit_a, w_hit_seed;
+  DevBuf w_tilestate;              // k_kmer_step's look-back words, one per tile (a word carries the serial of the call that wrote it)
+  const void* tilestate_clean = nullptr;      // the allocation that was last zeroed whole
+  bool opt_no_fused = false;       // A/B, tests: the default step as three kernels (k_seed_pack, k_kmer_probe, k_kmer_emit)
   // per-call workspace (grow-only)
   DevBuf in_bases;                 // host entry, reads in pinned memory: the chunk's reads (transfers queued ahead of the compute loop)
   DevBuf in_mask;                  // ... packed reads: their "not ACGT" bits
@@ -3159,6 +3378,8 @@ struct psigpu_ctx {
   } dpend[2];
   int dp_head = 0, dp_count = 0;
   uint64_t dp_seq = 0;
+  void* dp_stream = nullptr;       // the stream of the chunks in flight (one stream for all of them: the workspace is shared)
+  std::vector<void*> retired;      // hit buffers outgrown by a _begin while a caller may still read them: freed by the next _end
   void* stager = nullptr;          // the host entry's helper thread for pageable reads (struct Worker)
   void* widener = nullptr;         // the host entry's widening threads (struct Widener, made by its first call)
   // psigpu_set_option
@@ -3317,6 +3538,21 @@ static int upload_large(psigpu_ctx* ctx, void* dst, const void* src, size_t byte
   return PSIGPU_OK;
 }
 
+// A/B switches of the load campaigns (read per call: a campaign sets them for its own finders).
+// PSIGPU_AB_LOAD_HOLE=1 brings back what the loaders did before round 5: pads filled on the null stream with nobody waiting,
+// no device synchronisation when a loader returns, no read-back of checksums (which happened to order the fills).
+// PSIGPU_AB_NO_PAD_ZERO=1 leaves the pads as allocated (with PSIGPU_POISON: a known byte) -- does any answer depend on them?
+static bool ab_load_hole() { return getenv("PSIGPU_AB_LOAD_HOLE") != nullptr; }
+static bool ab_no_pad_zero() { return getenv("PSIGPU_AB_NO_PAD_ZERO") != nullptr; }
+// every loader ends here: whatever it queued on any stream (fills, table kernels) has run when the caller gets control back
+static int loader_fence(psigpu_ctx* ctx)
+{
+  if (ab_load_hole()) return PSIGPU_OK;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { ctx->err = std::string("hipDeviceSynchronize (end of a loader): ") + hipGetErrorString(e); return PSIGPU_ERR_DEVICE; }
+  return PSIGPU_OK;
+}
+
 // ---- what the device holds of the graph and the index, checked against what was put there ------------------------
 // Three wrong answers of the load campaigns have in common the data a freshly loaded finder reads, not a
 // kernel.  Every array the loaders put on the device leaves a 64-bit checksum behind (a grid-stride kernel: 9 GB in a few
@@ -3392,8 +3628,13 @@ static int upload(psigpu_ctx* ctx, DevBuf& b, const T* src, uint64_t n, uint64_t
   if (n * sizeof(T) >= (64u << 20)) { int st = upload_large(ctx, b.p, src, n * sizeof(T)); if (st != PSIGPU_OK) return st; }
   else
   if (n) HIPCHK(ctx, hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
-  if (pad_elems) HIPCHK(ctx, hipMemset((char*)b.p + n * sizeof(T), 0, pad_elems * sizeof(T)));
-  if (name && n) return resident_note(ctx, name, b, b.p, src, n * sizeof(T));
+  if (pad_elems && !ab_no_pad_zero()) {
+    // hipMemset on the null stream returns before the fill has run, and the query kernels run on non-blocking streams that
+    // do not order against the null stream: the host waits for the fill here (round-4 review: the loaders' ordering hole)
+    HIPCHK(ctx, hipMemsetAsync((char*)b.p + n * sizeof(T), 0, pad_elems * sizeof(T), nullptr));
+    if (!ab_load_hole()) HIPCHK(ctx, hipStreamSynchronize(nullptr));
+  }
+  if (name && n && !ab_load_hole()) return resident_note(ctx, name, b, b.p, src, n * sizeof(T));
   return PSIGPU_OK;
 }
 
@@ -3485,7 +3726,18 @@ void psigpu_destroy(psigpu_ctx* ctx)
 {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->dp_count) { (void)hipDeviceSynchronize(); ctx->dp_count = 0; }      // (chunks begun and never ended)
+  // nothing of this context may still be running or landing when its memory goes back to the allocator: every stream
+  // (chunks begun and never ended, a caller's stream the last call ran on), then every engine copy -- those are not
+  // HIP's and no HIP call waits for them (bounded: a signal nobody will ever lower must not hang a destructor)
+  (void)hipDeviceSynchronize();
+  ctx->dp_count = 0;
+  for (int i = 0; i < ctx->ec.n_sig; ++i) {
+    constexpr int R = psigpu_ctx::EngineCopy::IN_RING;
+    const hsa_signal_t sg = i < R ? ctx->ec.sig_in[i] : i < R + 2 ? ctx->ec.sig_out[i - R] : ctx->ec.sig_fast[i - R - 2];
+    for (int spin = 0; spin < 2000 && hsa_signal_wait_scacquire(sg, HSA_SIGNAL_CONDITION_LT, 1, 1000000, HSA_WAIT_STATE_BLOCKED) >= 1; ++spin) { }
+  }
+  for (void* old : ctx->retired) (void)hipFree(old);
+  ctx->retired.clear();
   widener_destroy(ctx);
   DevBuf* all[] = { &ctx->nodes, &ctx->lite, &ctx->node_id, &ctx->lab2, &ctx->labn, &ctx->edge_to, &ctx->loci, &ctx->w_bases,
                     &ctx->w_read_off, &ctx->w_cnt, &ctx->w_tiles, &ctx->w_seed_off, &ctx->w_seed_key,
@@ -3495,7 +3747,7 @@ void psigpu_destroy(psigpu_ctx* ctx)
                     &ctx->w_iv_tiles_off, &ctx->w_defer, &ctx->kt_ht, &ctx->kt_ext, &ctx->w_seedres };
   for (auto* b : all) b->release();
   ctx->ids_sorted.release(); ctx->w_sorted[0].release(); ctx->w_sorted[1].release(); ctx->w_count.release();
-  ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release(); ctx->pfx_roots.release();
+  ctx->kt_onpos.release(); ctx->w_hit_a.release(); ctx->w_hit_seed.release(); ctx->pfx_roots.release(); ctx->w_tilestate.release();
   for (DevBuf* b : { &ctx->w_sb_cnt, &ctx->w_sb_off, &ctx->w_sb_tiles, &ctx->w_sb_key, &ctx->w_seed_wide, &ctx->w_seed_pfx }) b->release();
   for (auto& m : ctx->parts) m->release();
   ctx->w_hits_alt.release(); ctx->in_bases.release(); ctx->in_mask.release();
@@ -3536,6 +3788,7 @@ static void drop_row_records(psigpu_ctx* ctx);
 int psigpu_set_gocc_threshold(psigpu_ctx* ctx, uint32_t thr)
 {
   if (!ctx) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   if (thr && ctx->kt_ready && ctx->kt_dedup) {       // the table holds positions, the threshold counts occurrences: rebuilt
     if (hipSetDevice(ctx->device) != hipSuccess) return PSIGPU_ERR_DEVICE;
     lkt_release(ctx);
@@ -3606,6 +3859,7 @@ static void resolve_auto_mode(psigpu_ctx* ctx)
 int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags)
 {
   if (!ctx) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   if (hipSetDevice(ctx->device) != hipSuccess) return PSIGPU_ERR_DEVICE;
   if ((flags ^ ctx->tune) & PSIGPU_TUNE_NO_ROWRECS) drop_row_records(ctx);      // made (or not) by the next FM query
   if (((flags ^ ctx->tune) & PSIGPU_TUNE_NO_PATH_TABLE) && ctx->query_mode == PSIGPU_MODE_TRAVERSE) lkt_release(ctx);
@@ -3616,6 +3870,7 @@ int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags)
 int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value)
 {
   if (!ctx || !name) return PSIGPU_ERR_ARG;
+  if (ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   const std::string n(name);
   if (n == "sub_bytes") ctx->opt_sub_bytes = value;
   else if (n == "no_ahead") ctx->opt_no_ahead = value != 0;
@@ -3626,6 +3881,7 @@ int psigpu_set_option(psigpu_ctx* ctx, const char* name, uint64_t value)
   } else if (n == "no_pfx_roots") ctx->opt_no_pfx_roots = value != 0;
   else if (n == "res16") ctx->opt_res16 = value != 0;
   else if (n == "no_lookahead") ctx->opt_no_lookahead = value != 0;
+  else if (n == "no_fused") ctx->opt_no_fused = value != 0;
   else if (n == "expected_calls") { ctx->opt_expected_calls = value; ctx->auto_resolved = false; }
   else if (n == "expected_seeds") { ctx->opt_expected_seeds = value; ctx->auto_resolved = false; }
   else if (n == "corrupt_resident") {                       // (test hook: one word of the starting loci changed on the device)
@@ -3767,7 +4023,7 @@ int psigpu_load_graph(psigpu_ctx* ctx, const psigpu_graph_view* g)
     if ((st = upload(ctx, ctx->ids_sorted, ids.data(), n, 1))) return st;
   }
   lkt_release(ctx);
-  return PSIGPU_OK;
+  return loader_fence(ctx);
 }
 
 static int build_row_records(psigpu_ctx* ctx, uint32_t k);
@@ -3830,9 +4086,10 @@ static int load_part(psigpu_ctx* ctx, const psigpu_index_view* m, uint32_t sa_ra
     HIPCHK(ctx, fp.exc_row.ensure((m->n_exc + n_super + 1) * 4 + 16));
     if (m->n_exc) HIPCHK(ctx, hipMemcpy(fp.exc_row.p, m->exc_row, m->n_exc * 4, hipMemcpyHostToDevice));
     if (n_super) HIPCHK(ctx, hipMemcpy(fp.exc_row.as<uint32_t>() + m->n_exc, m->exc_super, n_super * 4, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemset(fp.exc_row.as<uint32_t>() + m->n_exc + n_super, 0, 4));
+    if (!ab_no_pad_zero()) HIPCHK(ctx, hipMemsetAsync(fp.exc_row.as<uint32_t>() + m->n_exc + n_super, 0, 4, nullptr));
+    if (!ab_load_hole()) HIPCHK(ctx, hipStreamSynchronize(nullptr));
     resident_forget(ctx, fp.exc_row);
-    if (m->n_exc) { int rs = resident_note(ctx, "index: exception rows", fp.exc_row, fp.exc_row.p, m->exc_row, m->n_exc * 4); if (rs != PSIGPU_OK) return rs; }
+    if (m->n_exc && !ab_load_hole()) { int rs = resident_note(ctx, "index: exception rows", fp.exc_row, fp.exc_row.p, m->exc_row, m->n_exc * 4); if (rs != PSIGPU_OK) return rs; }
   }
   if ((st = upload(ctx, fp.exc_sa, m->exc_sa, m->n_exc, 1, "index: exception positions"))) return st;
   if (m->text4) {
@@ -3912,7 +4169,7 @@ int psigpu_load_index(psigpu_ctx* ctx, const psigpu_index_view* x)
   lkt_release(ctx);
   pfx_release(ctx);
   ctx->auto_resolved = false;
-  return PSIGPU_OK;
+  return loader_fence(ctx);
 }
 
 // Per-row records of the FM modes (SaRec for seed length k, and the located suffix array): derived from
@@ -4468,6 +4725,25 @@ static GraphView graph_view(const psigpu_ctx* ctx)
   return gv;
 }
 
+// the look-back words of k_kmer_step for a call of at most `n_seeds` seeds: every word is either zero or carries the
+// serial of the call that wrote it, so they are zeroed only when the allocation is new and when the 22-bit serial wraps
+static int tilestate_ready(psigpu_ctx* ctx, uint64_t n_seeds, hipStream_t stream, bool may_grow)
+{
+  const size_t bytes = (n_seeds / KS_TILE + 66) * 8;
+  if (!may_grow && ctx->w_tilestate.cap < bytes) return PSIGPU_ERR_NOMEM;
+  HIPCHK(ctx, ctx->w_tilestate.ensure(bytes));
+  if (ctx->tilestate_clean != ctx->w_tilestate.p || (ctx->serial & KS_SERIAL) == 0) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->w_tilestate.p, 0, ctx->w_tilestate.cap, stream));
+    ctx->tilestate_clean = ctx->w_tilestate.p;
+  }
+  return PSIGPU_OK;
+}
+static bool fused_step_wanted(const psigpu_ctx* ctx)
+{
+  static const bool env_no_fused = getenv("PSIGPU_NO_FUSED") != nullptr;      // A/B
+  return !env_no_fused && !ctx->opt_no_fused;
+}
+
 static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_read_off,
                         uint64_t n_reads, uint64_t n_bases, uint32_t k, uint32_t step, uint64_t rec_offset,
                         uint32_t flags, hipStream_t stream, uint64_t* n_hits_out, DevBuf* wire = nullptr,
@@ -4640,7 +4916,10 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   static const bool env_explicit_info = getenv("PSIGPU_EXPLICIT_INFO") != nullptr;      // A/B
   const bool implicit_info = uniform && use_kt && !need_table && !env_explicit_info;
   uint2* const d_seed_info = implicit_info ? nullptr : ctx->w_seed_info.as<uint2>();
-  if (n_seeds) {
+  // the default step in one kernel (k_kmer_step): every seed answered by the k-mer table, no traverser behind it
+  const bool fused = use_kt && n_seeds && !need_table && !wide && fused_step_wanted(ctx);
+  if (fused) { int ts = tilestate_ready(ctx, n_seeds, stream, true); if (ts != PSIGPU_OK) return ts; }
+  if (n_seeds && !fused) {
     const unsigned pgrid = (unsigned)std::min<uint64_t>((n_seeds + 256 * SP - 1) / (256 * SP), 256 * 32);
     if (uniform && packed)
       k_seed_pack<false, true, true><<<pgrid, 256, 0, stream>>>(d_bases, d_read_off, nullptr, n_reads, d_params, n_seeds, n_bases,
@@ -4856,7 +5135,22 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
         // and k_parts_combine applies the threshold to the sum
         const bool combine = on_paths && n_fm > 1;
         const uint32_t thr_k1 = combine ? 0xFFFFFFFFu : thr;
-        if (kprobe) {
+        if (kprobe && fused) {
+          const KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
+          const MapView mv = map_view(ctx->p0(), fm_view(ctx->p0()));
+          const unsigned sgrid = (unsigned)((n_seeds + KS_TILE - 1) / KS_TILE);
+          const PackedIn pk0 = packed ? *packed : PackedIn{ nullptr, 0, 0 };
+          const uint32_t serial22 = (uint32_t)(ctx->serial & KS_SERIAL);
+#define STEP_ARGS d_bases, d_read_off, ctx->w_seed_off.as<uint64_t>(), n_reads, d_params, n_seeds, n_bases, k, step, pk0, un, kt, mv, \
+                  ctx->lkt_ent.as<LocusEnt>(), (flags & PSIGPU_ON_PATHS) != 0, want_off && use_lkt, thr, rec_offset, d_hits, cap, \
+                  ctx->w_tilestate.as<uint64_t>(), serial22, ctr, env_plain_stores
+          if (uniform && packed) k_kmer_step<true, true><<<sgrid, 256, 0, stream>>>(STEP_ARGS);
+          else if (uniform) k_kmer_step<false, true><<<sgrid, 256, 0, stream>>>(STEP_ARGS);
+          else if (packed) k_kmer_step<true, false><<<sgrid, 256, 0, stream>>>(STEP_ARGS);
+          else k_kmer_step<false, false><<<sgrid, 256, 0, stream>>>(STEP_ARGS);
+#undef STEP_ARGS
+          probed = true;
+        } else if (kprobe) {
           KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
           if (res8)
             k_kmer_probe<true><<<grid, 256, 0, stream>>>(kt, ctx->w_seed_key.as<uint64_t>(), d_params, n_seeds, per_wave,
@@ -4918,9 +5212,11 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
             k_wave_offsets<<<1, 1024, 0, stream>>>(tiles_of(p), (probe && p == 0) ? ctx->w_iv_tiles_off.as<uint64_t>() : nullptr, n_waves,
                                                    (uint64_t*)&ctr->n_hits_on.v, (uint64_t*)&ctr->n_hits_tab.v, p != 0);
       }
-      if (!(lean_ev && kprobe && !off_paths)) EVREC(4, stream);
+      if (!(lean_ev && kprobe && !off_paths) && !fused) EVREC(4, stream);
       const LocusEnt* oe = (probe || kprobe) ? ctx->lkt_ent.as<LocusEnt>() : nullptr;
-      if (kprobe) {
+      if (fused) {
+        // (the records are out already)
+      } else if (kprobe) {
         const FMView fm0 = fm_view(ctx->p0());
         const uint32_t thr_e = ctx->gocc_thr ? ctx->gocc_thr : 0xFFFFFFFFu;
         if (res8)
@@ -5085,10 +5381,15 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
     static const bool env_debug = getenv("PSIGPU_DEBUG") != nullptr;
     if (env_debug)
       fprintf(stderr, "[psigpu] attempt %d: seeds %llu of %llu, hits on %llu tab %llu off %llu, chunks %llu of %llu, spill %llu, cap %llu (kprobe %d on %d off %d probe %d)\n",
-              attempt, (unsigned long long)true_seeds, (unsigned long long)n_seeds, h.n_hits_on.v, h.n_hits_tab.v, h.n_hits_off.v, h.n_chunks.v,
+              attempt, (unsigned long long)true_seeds, (unsigned long long)n_seeds, h.hits_on(), h.n_hits_tab.v, h.n_hits_off.v, h.n_chunks.v,
               (unsigned long long)cap_chunks, h.n_spill.v, (unsigned long long)cap, (int)kprobe, (int)on_paths, (int)off_paths, (int)probe);
     if (total_hits > cap) { overflow = true; cap = total_hits + total_hits / 16 + 1024; }
     if (!overflow) break;
+    if (fused) {
+      // the one kernel of the step wrote what fitted and counted the rest: the call again with room for all of it
+      ctx->hits_cap_hint = std::max<uint64_t>(ctx->hits_cap_hint, cap);
+      return run_pipeline(ctx, d_bases, d_read_off, n_reads, n_bases, k, step, rec_offset, flags_in, stream, n_hits_out, wire, packed, wfmt);
+    }
     if (attempt == MAX_ATTEMPTS - 1) { ctx->err = "hit buffer / spill queue overflow"; return PSIGPU_ERR_NOMEM; }
     HIPCHK(ctx, hipMemsetAsync(&ctr->n_kpaths, 0, sizeof(StripedCounter), stream));
     HIPCHK(ctx, hipMemsetAsync(&ctr->n_spill.v, 0, 8, stream));
@@ -5100,8 +5401,8 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   pc.n_seeds = true_seeds;
   pc.n_seeds_valid = h.n_seeds_valid.total();
   pc.n_seeds_on_path = h.n_live.total();
-  pc.n_hits_on_path = h.n_hits_on.v;
-  pc.n_hits_off_path = (h.n_hits_tab.v - h.n_hits_on.v) + h.n_hits_off.v;
+  pc.n_hits_on_path = h.hits_on();
+  pc.n_hits_off_path = (h.n_hits_tab.v - h.hits_on()) + h.n_hits_off.v;
   pc.n_hits = total_hits;
   pc.n_kpaths = h.n_kpaths.total();
   pc.n_lf_steps = h.n_lf_steps.total();
@@ -5114,8 +5415,9 @@ static int run_pipeline(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_
   pc.ms_pack = lean_ev ? 0.f : ms(0, 1); pc.ms_table = off_paths ? ms(2, 6) : 0.f;
   pc.ms_search = on_paths ? ms(3, 10) : 0.f;          // K1
   // table probe + the scan of the per-wave totals
-  pc.ms_probe = lean_k ? 0.f : kprobe ? (lean_ev ? 0.f : ms(1, 4)) : (probe ? ms(10, 4) : 0.f);
-  pc.ms_locate = lean_k ? 0.f : (on_paths || probe || kprobe) ? ((kprobe && !off_paths) ? ms(4, ctx->grouped_state ? 11 : 8) : ms(4, 5)) : 0.f;
+  pc.ms_probe = lean_k ? 0.f : kprobe ? (lean_ev ? 0.f : fused ? ms(1, ctx->grouped_state ? 11 : 8) : ms(1, 4)) : (probe ? ms(10, 4) : 0.f);
+  pc.ms_locate = (lean_k || fused) ? 0.f : (on_paths || probe || kprobe) ? ((kprobe && !off_paths) ? ms(4, ctx->grouped_state ? 11 : 8) : ms(4, 5)) : 0.f;
+  pc.fused_step = fused ? 1u : 0u;
   pc.ms_traverse = off_paths ? ms(6, 7) : 0.f;        // runs beside K1/K2 on the second stream
   pc.ms_total = ms(0, 8);
   if (ctx->grouped_state) { pc.ms_sort = ms(11, 8); pc.ms_total -= pc.ms_sort; }     // (added back by the caller with the sort's time)
@@ -5172,6 +5474,37 @@ static int enqueue_default(psigpu_ctx* ctx, const FastArgs& a, hipStream_t strea
     k_seed_scan_final<<<(unsigned)n_tiles, SCAN_THREADS, 0, stream>>>(a.d_off, a.nr, k, step, ctx->w_tiles.as<uint64_t>(),
                                                                     ctx->w_seed_off.as<uint64_t>(), ctx->w_total.as<uint64_t>(), ctr);
   }
+  const uint32_t thr = ctx->gocc_thr ? ctx->gocc_thr : 0xFFFFFFFFu;
+  psigpu_hit* d_hits = fs.hits.as<psigpu_hit>();
+  MapView mv;
+  {
+    const psigpu_ctx::FmPart& fp = ctx->p0();
+    mv.samples = fp.samples.as<uint32_t>(); mv.sa_rate = ctx->sa_rate;
+    mv.exc_sa = fp.exc_sa.as<uint32_t>();
+    mv.seg = fp.seg.as<SegRec>(); mv.seg_dir = fp.seg_dir.as<uint32_t>();
+    mv.sarec = nullptr; mv.sarec_rem = k - fp.ftab_len;
+    mv.node_id = ctx->node_id.as<uint64_t>(); mv.id_base = ctx->id_base; mv.id_affine = ctx->id_affine;
+    mv.loci = ctx->loci.as<uint2>();
+    mv.on_pos = ctx->kt_onpos.as<uint2>();
+    mv.saloc = fp.have_saloc ? fp.saloc.as<uint2>() : nullptr;
+  }
+  const KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
+  const LocusEnt* oe = ctx->lkt_ent.as<LocusEnt>();
+  // (the look-back words must be there already: nothing grows under a chunk in flight -- the caller checked)
+  const bool fused = fused_step_wanted(ctx);
+  if (fused) { int ts = tilestate_ready(ctx, n_seeds, stream, false); if (ts != PSIGPU_OK) { ctx->err = "look-back words not sized for this sub-batch"; return ts; } }
+  if (fused) {
+    const unsigned sgrid = (unsigned)((n_seeds + KS_TILE - 1) / KS_TILE);
+    const PackedIn pkf = a.pk ? *a.pk : PackedIn{ nullptr, 0, 0 };
+    const uint32_t serial22 = (uint32_t)(serial & KS_SERIAL);
+#define STEP_ARGS a.d_in, a.d_off, ctx->w_seed_off.as<uint64_t>(), a.nr, d_params, n_seeds, a.nb, k, step, pkf, un, kt, mv, oe, ctx->fast_on, \
+                  ctx->fast_off, thr, a.rec_base, d_hits, a.cap, ctx->w_tilestate.as<uint64_t>(), serial22, ctr, env_plain_stores
+    if (uniform && a.pk) k_kmer_step<true, true><<<sgrid, 256, 0, stream>>>(STEP_ARGS);
+    else if (uniform) k_kmer_step<false, true><<<sgrid, 256, 0, stream>>>(STEP_ARGS);
+    else if (a.pk) k_kmer_step<true, false><<<sgrid, 256, 0, stream>>>(STEP_ARGS);
+    else k_kmer_step<false, false><<<sgrid, 256, 0, stream>>>(STEP_ARGS);
+#undef STEP_ARGS
+  } else {
   const unsigned pgrid = (unsigned)std::min<uint64_t>((n_seeds + 255) / 256, 256 * 32);
   const PackedIn pk0{ nullptr, 0, 0 };
   uint64_t* key = ctx->w_seed_key.as<uint64_t>();
@@ -5187,31 +5520,18 @@ static int enqueue_default(psigpu_ctx* ctx, const FastArgs& a, hipStream_t strea
   n_waves = (n_waves + 3) / 4 * 4;
   const uint32_t per_wave = (uint32_t)(((n_seeds + n_waves - 1) / n_waves + 63) / 64 * 64);
   const unsigned grid = (unsigned)(n_waves / 4);
-  const uint32_t thr = ctx->gocc_thr ? ctx->gocc_thr : 0xFFFFFFFFu;
   static const bool env_res16 = getenv("PSIGPU_RES16") != nullptr;
   const bool res8 = !env_res16 && !ctx->opt_res16 && ctx->max_node_len < (1ull << R8_NOFF_BITS);
-  const KmerTableView kt = { ctx->kt_ht.as<Slot16>(), ctx->kt_ht_size, ctx->kt_ext.as<KmerSlot>() };
   uint4* res = ctx->w_seedres.as<uint4>();
   uint64_t* tiles = ctx->w_iv_tiles.as<uint64_t>();
   uint64_t* tiles_off = ctx->w_iv_tiles_off.as<uint64_t>();
   if (res8) k_kmer_probe<true><<<grid, 256, 0, stream>>>(kt, key, d_params, n_seeds, per_wave, ctx->fast_on, ctx->fast_off, thr, res, tiles, tiles_off, ctr);
   else k_kmer_probe<false><<<grid, 256, 0, stream>>>(kt, key, d_params, n_seeds, per_wave, ctx->fast_on, ctx->fast_off, thr, res, tiles, tiles_off, ctr);
-  const psigpu_ctx::FmPart& fp = ctx->p0();
-  MapView mv;
-  mv.samples = fp.samples.as<uint32_t>(); mv.sa_rate = ctx->sa_rate;
-  mv.exc_sa = fp.exc_sa.as<uint32_t>();
-  mv.seg = fp.seg.as<SegRec>(); mv.seg_dir = fp.seg_dir.as<uint32_t>();
-  mv.sarec = nullptr; mv.sarec_rem = k - fp.ftab_len;
-  mv.node_id = ctx->node_id.as<uint64_t>(); mv.id_base = ctx->id_base; mv.id_affine = ctx->id_affine;
-  mv.loci = ctx->loci.as<uint2>();
-  mv.on_pos = ctx->kt_onpos.as<uint2>();
-  mv.saloc = fp.have_saloc ? fp.saloc.as<uint2>() : nullptr;
-  psigpu_hit* d_hits = fs.hits.as<psigpu_hit>();
-  const LocusEnt* oe = ctx->lkt_ent.as<LocusEnt>();
   if (res8) k_kmer_emit<true><<<grid, 256, 0, stream>>>(mv, res, ctx->kt_ext.as<KmerSlot>(), oe, tiles, tiles_off, d_params, n_seeds, per_wave, info,
                                                          a.rec_base, d_hits, a.cap, ctr, ctx->fast_on, ctx->fast_off, thr, un.spr, step, env_plain_stores);
   else k_kmer_emit<false><<<grid, 256, 0, stream>>>(mv, res, ctx->kt_ext.as<KmerSlot>(), oe, tiles, tiles_off, d_params, n_seeds, per_wave, info,
                                                     a.rec_base, d_hits, a.cap, ctr, ctx->fast_on, ctx->fast_off, thr, un.spr, step, env_plain_stores);
+  }
   if (a.want_sort && a.cap) {
     int fsr = HitSorter::fix_grouped(d_hits, a.cap, &ctr->n_hits_tab.v, (uint64_t*)&ctr->not_grouped.v, stream, &ctx->err);
     if (fsr != PSIGPU_OK) return fsr;
@@ -5337,8 +5657,8 @@ int psigpu_find_seeds_device_packed(psigpu_ctx* ctx, const uint64_t* d_packed, c
 // synchronisation, the counters read, the return to the caller, the caller's next call, five launches.  A caller that
 // has the next chunk ready (a pipeline that double-buffers its read batches, as psikt's host entry does internally with
 // its sub-batches) begins it before it ends the current one: _begin queues a chunk's kernels and returns, _end waits
-// for the OLDEST chunk begun and hands out its hits.  At most two chunks are begun at a time; the hits of a chunk stay
-// valid until the third _begin after its own.  A chunk that needs more than the default mode's kernels (another query
+// for the OLDEST chunk begun and hands out its hits.  At most two chunks are begun at a time (on ONE stream); the hits of a
+// chunk stay valid until the next _end.  A chunk that needs more than the default mode's kernels (another query
 // mode, a traverser pass, tables not made yet, buffers that would have to grow under a chunk in flight) is answered by the
 // synchronous entry inside its _end -- same result, no overlap.
 static int dev_begin(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_mask, bool packed, const uint64_t* d_read_off,
@@ -5346,6 +5666,12 @@ static int dev_begin(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_mas
 {
   if (!ctx || (n_reads && !d_read_off) || (packed && n_bases && !d_bases)) return PSIGPU_ERR_ARG;
   if (ctx->dp_count == 2) { ctx->err = "two chunks are begun already: end one first"; return PSIGPU_ERR_STATE; }
+  // the chunks in flight share one workspace (seed keys, probe results, counters) and only stream order keeps them apart
+  if (ctx->dp_count && stream != ctx->dp_stream) {
+    ctx->err = "a chunk is in flight on another stream: every chunk begun before the oldest is ended must use the same stream";
+    return PSIGPU_ERR_STATE;
+  }
+  ctx->dp_stream = stream;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if ((flags & PSIGPU_ALL) == 0) flags |= PSIGPU_ALL;
   psigpu_ctx::DevPending& p = ctx->dpend[(ctx->dp_head + ctx->dp_count) % 2];
@@ -5366,9 +5692,12 @@ static int dev_begin(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_mas
     psigpu_ctx::FastSlot& fs = ctx->fast[q];
     // nothing may be regrown (freed) under a chunk in flight: with one begun, a buffer that is too small makes this chunk a synchronous one
     struct Need { DevBuf* b; size_t bytes; };
+    const bool fz = fused_step_wanted(ctx);        // (one kernel per chunk: no key / result arrays)
     const Need needs[] = { { &ctx->w_ctr, sizeof(DevCounters) }, { &ctx->w_total, 64 }, { &ctx->w_tiles, (n_reads / SCAN_TILE + 2) * 8 },
-                           { &ctx->w_seed_off, (n_reads + 1) * 8 }, { &ctx->w_seed_key, (seeds_max + 1) * 8 }, { &ctx->w_seed_info, (seeds_max + 1) * 8 },
-                           { &ctx->w_seedres, (seeds_max + 16) * 16 }, { &ctx->w_iv_tiles, (WAVES_MAX + 8) * 8 }, { &ctx->w_iv_tiles_off, (WAVES_MAX + 8) * 8 },
+                           { &ctx->w_seed_off, (n_reads + 1) * 8 }, { &ctx->w_seed_key, fz ? 0 : (seeds_max + 1) * 8 },
+                           { &ctx->w_seed_info, fz ? 0 : (seeds_max + 1) * 8 }, { &ctx->w_seedres, fz ? 0 : (seeds_max + 16) * 16 },
+                           { &ctx->w_iv_tiles, fz ? (size_t)0 : (size_t)(WAVES_MAX + 8) * 8 }, { &ctx->w_iv_tiles_off, fz ? (size_t)0 : (size_t)(WAVES_MAX + 8) * 8 },
+                           { &ctx->w_tilestate, fz ? (seeds_max / KS_TILE + 66) * 8 : 0 },
                            { &fs.hits, (cap + 1) * sizeof(psigpu_hit) } };
     bool grow = !fs.h;
     for (const Need& nd : needs) grow = grow || nd.b->cap < nd.bytes;
@@ -5376,9 +5705,13 @@ static int dev_begin(psigpu_ctx* ctx, const char* d_bases, const uint64_t* d_mas
     else if (grow) {
       // (all three slots at once: the next chunk is begun with this one in flight and must find its slot made)
       hipError_t e = hipSuccess;
-      for (const Need& nd : needs) if (e == hipSuccess) e = nd.b->ensure(nd.bytes);
+      for (const Need& nd : needs) if (e == hipSuccess && nd.b != &fs.hits) e = nd.b->ensure(nd.bytes);
       for (int s3 = 0; s3 < psigpu_ctx::N_FAST; ++s3) {
         psigpu_ctx::FastSlot& f3 = ctx->fast[s3];
+        if (f3.hits.p && f3.hits.cap < (cap + 1) * sizeof(psigpu_hit)) {      // (the last _end may have handed this buffer out)
+          ctx->retired.push_back(f3.hits.p);
+          f3.hits.p = nullptr; f3.hits.cap = 0;
+        }
         if (e == hipSuccess) e = f3.hits.ensure((cap + 1) * sizeof(psigpu_hit));
         if (e == hipSuccess && !f3.h) {
           e = hipHostMalloc(&f3.h, sizeof(DevCounters) + 64, hipHostMallocMapped);
@@ -5425,6 +5758,8 @@ int psigpu_find_seeds_device_end(psigpu_ctx* ctx, const psigpu_hit** d_hits, uin
   if (!ctx || !d_hits || !n_hits) return PSIGPU_ERR_ARG;
   if (ctx->dp_count == 0) { ctx->err = "no chunk was begun"; return PSIGPU_ERR_STATE; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (void* old : ctx->retired) (void)hipFree(old);       // (what the previous _end handed out ends its life here: psi_gpu.h)
+  ctx->retired.clear();
   const psigpu_ctx::DevPending p = ctx->dpend[ctx->dp_head];
   ctx->dp_head = (ctx->dp_head + 1) % 2;
   --ctx->dp_count;
@@ -5444,12 +5779,13 @@ int psigpu_find_seeds_device_end(psigpu_ctx* ctx, const psigpu_hit** d_hits, uin
     if (h.serial.v == p.serial && !(p.uniform && h.not_uniform.v) && n <= p.cap && !(want_sort && h.not_grouped.v)) {
       psigpu_counters pc{};
       pc.n_reads = p.nr; pc.n_seeds = h.n_seeds_true.v; pc.n_seeds_valid = h.n_seeds_valid.total();
-      pc.n_seeds_on_path = h.n_live.total(); pc.n_hits_on_path = h.n_hits_on.v; pc.n_hits_off_path = n - h.n_hits_on.v; pc.n_hits = n;
+      pc.n_seeds_on_path = h.n_live.total(); pc.n_hits_on_path = h.hits_on(); pc.n_hits_off_path = n - h.hits_on(); pc.n_hits = n;
       pc.n_loci = ctx->n_loci; pc.n_locus_kmers = ctx->fast_off ? ctx->lkt_n_ent : 0; pc.n_path_kmers = ctx->kt_n_path_kmers;
       pc.ms_locus_table_build = ctx->lkt_build_ms;
       { float t = 0; (void)hipEventElapsedTime(&t, fs.begin, fs.done); pc.ms_total = t; }
       pc.sorted_in_place = want_sort ? 1u : 0u;
       pc.lookahead_subbatches = 1;
+      pc.fused_step = fused_step_wanted(ctx) ? 1u : 0u;
       pc.stale_handbacks = ctx->stale_handbacks;
       ctx->last = pc;
       ctx->hits_cap_hint = std::max<uint64_t>(ctx->hits_cap_hint, n + n / 8);
@@ -5470,6 +5806,7 @@ int psigpu_find_mems(psigpu_ctx* ctx, const char* bases, const uint64_t* read_of
 {
   if (!ctx || !out || (n_reads && (!read_off || !bases))) return PSIGPU_ERR_ARG;
   out->n = 0; out->data = nullptr;
+  if (ctx->dp_count) { ctx->err = "chunks were begun and not ended (psigpu_find_seeds_device_end)"; return PSIGPU_ERR_STATE; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (!ctx->have_graph || !ctx->have_index) { ctx->err = "graph / index not loaded"; return PSIGPU_ERR_STATE; }
   if (minlen == 0) { ctx->err = "minimum match length must be positive"; return PSIGPU_ERR_ARG; }
@@ -5579,7 +5916,7 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k)
     st = build_row_records(ctx, ctx->index_k);
     ctx->rows_tried = st == PSIGPU_OK;
   }
-  return st;
+  return st == PSIGPU_OK ? loader_fence(ctx) : st;
 }
 
 void* psigpu_host_alloc(uint64_t bytes)
@@ -6251,9 +6588,12 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
     auto need = [&](DevBuf& b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
     need(ctx->w_ctr, sizeof(DevCounters)); need(ctx->w_total, 64);
     need(ctx->w_tiles, (nr_max / SCAN_TILE + 2) * 8); need(ctx->w_seed_off, (nr_max + 1) * 8);
-    need(ctx->w_seed_key, (seeds_max + 1) * 8); need(ctx->w_seed_info, (seeds_max + 1) * 8);
-    need(ctx->w_seedres, (seeds_max + 16) * 16);
-    need(ctx->w_iv_tiles, (WAVES_MAX + 8) * 8); need(ctx->w_iv_tiles_off, (WAVES_MAX + 8) * 8);
+    if (fused_step_wanted(ctx)) need(ctx->w_tilestate, (seeds_max / KS_TILE + 66) * 8);      // (one kernel per sub-batch: keys and results stay in registers)
+    else {
+      need(ctx->w_seed_key, (seeds_max + 1) * 8); need(ctx->w_seed_info, (seeds_max + 1) * 8);
+      need(ctx->w_seedres, (seeds_max + 16) * 16);
+      need(ctx->w_iv_tiles, (WAVES_MAX + 8) * 8); need(ctx->w_iv_tiles_off, (WAVES_MAX + 8) * 8);
+    }
     constexpr int NF = psigpu_ctx::N_FAST;
     for (int q = 0; q < NF; ++q) {
       psigpu_ctx::FastSlot& fs = ctx->fast[q];
@@ -6329,7 +6669,7 @@ static int find_seeds_host(psigpu_ctx* ctx, const ReadsIn& in, const uint64_t* r
         break;
       }
       acc.n_reads += nr; acc.n_seeds += h.n_seeds_true.v; acc.n_seeds_valid += h.n_seeds_valid.total();
-      acc.n_seeds_on_path += h.n_live.total(); acc.n_hits_on_path += h.n_hits_on.v; acc.n_hits_off_path += n - h.n_hits_on.v;
+      acc.n_seeds_on_path += h.n_live.total(); acc.n_hits_on_path += h.hits_on(); acc.n_hits_off_path += n - h.hits_on();
       acc.n_loci = ctx->n_loci; acc.n_locus_kmers = ctx->fast_off ? ctx->lkt_n_ent : 0; acc.n_path_kmers = ctx->kt_n_path_kmers;
       acc.ms_locus_table_build = ctx->lkt_build_ms;
       { float t = 0; (void)hipEventElapsedTime(&t, fs.begin, fs.done); acc.ms_total += t; }
@@ -6573,9 +6913,10 @@ int psigpu_verify_resident(psigpu_ctx* ctx, uint32_t* n_changed, char* report, u
   std::string rep;
   for (const auto& r : ctx->resident) {
     uint64_t sum = 0;
-    int st = device_checksum(ctx, r.at, r.bytes, &sum);
-    if (st != PSIGPU_OK) return st;
-    if (sum != r.sum || r.buf->p != r.at) {
+    // (an array released or regrown since it was noted is "changed" without a kernel reading what may be freed memory)
+    const bool moved = r.buf->p != r.at || r.bytes > r.buf->cap;
+    if (!moved) { int st = device_checksum(ctx, r.at, r.bytes, &sum); if (st != PSIGPU_OK) return st; }
+    if (moved || sum != r.sum) {
       ++*n_changed;
       if (!rep.empty()) rep += "; ";
       rep += r.name + " (" + std::to_string(r.bytes) + " bytes)";

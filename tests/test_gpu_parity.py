@@ -1929,7 +1929,7 @@ def test_device_entry_two_chunks_in_flight(query_mode):
             if i + 1 < len(chunks):
                 begin(i + 1)
             end(i)
-    # the hits of a chunk outlive the next two begins
+    # the hits of a chunk stay valid until the next end (psi_gpu.h), whatever is begun in between
     begin(0); begin(1)
     ptr0, n0 = f.seeds_all_device_end()
     begin(2)
@@ -1940,7 +1940,42 @@ def test_device_entry_two_chunks_in_flight(query_mode):
         begin(4)                                          # two are begun
     with pytest.raises(psi_amd.PsiGpuError):
         f.seeds_all_device(chunks[0][0].data_ptr(), chunks[0][1].data_ptr(), chunks[0][2], chunks[0][3], step=step)
+    # ... and so is every other entry point that touches what the chunks in flight use (round-4 advisor)
+    for refused in (lambda: f.find_mems(equal[:5]), lambda: f.set_gocc_threshold(3), lambda: f.set_tuning(0),
+                    lambda: f.set_option('no_lookahead', 1), lambda: f.prepare(), lambda: f.verify_resident()):
+        with pytest.raises(psi_amd.PsiGpuError):
+            refused()
+    # a chunk on another stream than the one in flight is refused: the workspace is shared, stream order is all that separates them
+    other = torch.cuda.Stream()
+    with pytest.raises(psi_amd.PsiGpuError):
+        f.seeds_all_device_begin(chunks[0][0].data_ptr(), chunks[0][1].data_ptr(), chunks[0][2], chunks[0][3], step=step, stream=other.cuda_stream)
     f.seeds_all_device_end(); f.seeds_all_device_end()
+    # (with nothing in flight any stream will do, and the next chunk must follow it there)
+    torch.cuda.synchronize()
+    d_b, d_o, nr, nb, flags = chunks[0]
+    f.seeds_all_device_begin(d_b.data_ptr(), d_o.data_ptr(), nr, nb, step=step, rec_offset=0, flags=flags, stream=other.cuda_stream)
+    with pytest.raises(psi_amd.PsiGpuError):
+        begin(1)
+    f.seeds_all_device_begin(d_b.data_ptr(), d_o.data_ptr(), nr, nb, step=step, rec_offset=0, flags=flags, stream=other.cuda_stream)
+    for _ in range(2):
+        ptr, n = f.seeds_all_device_end()
+        assert _eq(psi_amd.sort_unique(f.copy_hits(ptr, n)), psi_amd.sort_unique(want[0]))
+    # two chunks answered inside their end (the false claim, twice) back to back: each one's records are whole when handed out
+    begin(2); begin(2)
+    for _ in range(2):
+        ptr, n = f.seeds_all_device_end()
+        assert _eq(psi_amd.sort_unique(f.copy_hits(ptr, n)), psi_amd.sort_unique(want[2]))
+    # a context that has to grow its hit buffers under a caller that still holds the previous end's records
+    begin(0)
+    ptr0, n0 = f.seeds_all_device_end()
+    big = equal * 6
+    bb, bo = psi_amd.pack_reads(big)
+    d_bb, d_bo = torch.from_numpy(bb).cuda(), torch.from_numpy(bo.astype(np.int64)).cuda()
+    f.seeds_all_device_begin(d_bb.data_ptr(), d_bo.data_ptr(), len(big), len(bb), step=1, flags=psi_amd.ALL | psi_amd.UNIFORM_READS)
+    assert _eq(psi_amd.sort_unique(f.copy_hits(ptr0, n0)), psi_amd.sort_unique(want[0]))      # (still chunk 0's, not freed)
+    ptr, n = f.seeds_all_device_end()
+    pb, nb_ = f.seeds_all_device(d_bb.data_ptr(), d_bo.data_ptr(), len(big), len(bb), step=1, flags=psi_amd.ALL | psi_amd.UNIFORM_READS)
+    assert n == nb_ and n > n0
     with pytest.raises(psi_amd.PsiGpuError):
         f.seeds_all_device_end()                          # nothing begun
     if query_mode == 'kmer-table':

@@ -933,3 +933,36 @@ def test_pathindex_shim_reference_golden(tmp_path, ref_data):
                            '29 205 24', '35 205 18']                                               # :266-281
     assert get('covered') == ['1 0 1']
     assert get('loaded') == ['3 ' + ' '.join(trimmed)]
+
+
+# ---------------------------------------------------------------------------------------
+def test_bench_line_is_small():
+    """The driver keeps a bounded tail of bench.py's stdout: round 4's 20.8 KB line was not parsed (BENCH_r04.json:
+    parsed null).  The line made from a recorded full report stays under 6 KB, is strict JSON, and carries the keys
+    the contract names -- the SURVEY 8(d) end-to-end rate at top level beside the device-resident `value`."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r04_bench_final.json')))
+    line = bench.slim_line(full, 'gpurun_out/bench_full.json')
+    text = json.dumps(line, allow_nan=False)
+    assert len(text) <= bench.LINE_LIMIT < 12000
+    assert '\n' not in text
+    back = json.loads(text)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'value_end_to_end', 'end_to_end',
+                'parity_vs_cpu_sample'):
+        assert key in back, key
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(back['roofline'])
+    assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(back['cpu_baseline'])
+    assert 'workload' in back['config'] and 'model' not in back['config']
+    assert abs(back['value'] - full['value']) <= 1e-5 * full['value']
+    assert abs(back['value_end_to_end'] - full['end_to_end']['value']) <= 1e-5 * full['end_to_end']['value']
+    # a report swollen by a long multi-GPU section still fits: optional parts are shed, the contract's keys stay
+    fat = dict(full, multi_gpu={'n_ranks': 8, 'backend': 'nccl', 'per_gpu': [{'ms_per_step': 0.1 * i} for i in range(4000)],
+                                'properties': {}})
+    text = json.dumps(bench.slim_line(fat), allow_nan=False)
+    assert len(text) <= bench.LINE_LIMIT
+    assert all(k in json.loads(text) for k in ('value', 'roofline', 'cpu_baseline'))
+    # the LF kernel's algorithmic bytes count one rank block per LF step: no series prices itself above the peak
+    c = {'n_seeds_valid': 7_000_000, 'n_lf_steps': 7_000_000 * 21, 'n_rows_verified': 0}
+    assert bench.algorithmic_bytes('k_fm_search', c, 21, 1, 0) == 64.0 * 7_000_000 * 21
