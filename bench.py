@@ -84,6 +84,11 @@ def algorithmic_bytes(kernel, c, k, sa_rate, ftab_len=0, implicit_info=False):
         # SURVEY 8(d) prices locate + map -- sample + two segment-table sectors, 164 B -- which this layout does not read:
         # the fraction came out above 1.)
         return 20.0 * c['n_seeds'] + (8 + 32.0) * c['n_hits_on_path'] + (16 + 32.0) * c['n_hits_table']
+    if kernel == 'k_kmer_step':
+        # the default step as ONE kernel (round 5): per seed its k bases in (ASCII, one byte each), per read its two offsets (the
+        # equal-length claim is checked against them), per N-free seed one 16-byte table slot, per hit one 32-byte record out;
+        # keys and probe results never leave the registers
+        return float(k) * c['n_seeds'] + 16.0 * c['n_reads'] + 16.0 * c['n_seeds_valid'] + 32.0 * (c['n_hits_on_path'] + c.get('n_hits_table', 0))
     if kernel in ('k_kmer_probe', 'k_lkt_probe'):
         # per seed its 8-byte key in and 8 bytes of results out to K2 (round 4; 16 before: the fraction is of FEWER bytes now);
         # per N-free seed one 16-byte slot in
@@ -216,7 +221,7 @@ def slim_line(out, full_path=None):
     line['config'] = {'workload': wl if len(wl) <= 420 else wl[:417] + '...'}
     for k_ in ('reads_per_gpu', 'read_len', 'k', 'seed_step', 'indexed_paths', 'nodes', 'text_len', 'starting_loci', 'sa_rate',
                'query_mode', 'seeds_per_step_per_gpu', 'hits_per_step_per_gpu', 'locus_kmers', 'path_kmers', 'table_build_ms',
-               'index_build_s', 'index_built_on', 'parallelism', 'whole_genome'):
+               'index_build_s', 'index_built_on', 'parallelism', 'whole_genome', 'record_order'):
         if k_ in cfg:
             line['config'][k_] = cfg[k_]
     rf = out.get('roofline') or {}
@@ -459,6 +464,7 @@ def main():
     ap.add_argument('--wg-snvs', type=int, default=0)
     ap.add_argument('--wg-nblock', type=int, default=0)
     ap.add_argument('--wg-reads', type=int, default=0, help='reads per GPU of the N > 1 workload (default 12.5 M: 100 M over 8)')
+    ap.add_argument('--ordered', action='store_true', help='the timed steps without PSIGPU_ANY_ORDER: raw records seed by seed in read order')
     ap.add_argument('--full-out', default='', help='where the full report goes (default gpurun_out/bench_full.json, else ./bench_full.json)')
     ap.add_argument('--mode', choices=('kmer-table', 'locus-table', 'traverse'), default='kmer-table',
                     help="kmer-table: path k-mers and the starting loci's k-walks tabulated once in HBM, one probe "
@@ -602,13 +608,18 @@ def main():
         d_hits, n_out = C.c_void_p(), C.c_uint64()
         # the timed loop goes through the C ABI with prebuilt arguments: the binding's conveniences
         # (argument objects, a dict of counters) cost tens of microseconds per call
-        calls = [(f.ctx, d[0].data_ptr(), d[1].data_ptr(), args.reads, d[2], k, step, rec_offset, psi_amd.ALL | call_flags, stream,
+        # (PSIGPU_ANY_ORDER: raw records in any order, as the reference's callback stream is -- the default mode's kernel then
+        # takes a tile's output range with one atomic add instead of a look-back; --ordered times the default without the flag)
+        order_flag = 0 if args.ordered else psi_amd.ANY_ORDER
+        calls = [(f.ctx, d[0].data_ptr(), d[1].data_ptr(), args.reads, d[2], k, step, rec_offset, psi_amd.ALL | call_flags | order_flag, stream,
                   C.byref(d_hits), C.byref(n_out)) for d in dev]
         for i in range(warmup):
             if L.psigpu_find_seeds_device(*calls[i % nb]):
                 raise RuntimeError(L.psigpu_last_error(f.ctx).decode())
         # (the on-path phase is a probe of a k-mer table in the default mode, and in traverse mode unless the FM route is asked for)
         probe_name = 'k_kmer_probe' if (mode == 'kmer-table' or (mode == 'traverse' and c0['n_path_kmers'])) else 'k_lkt_probe'
+        if c0.get('fused_step'):
+            probe_name = 'k_kmer_step'          # seeding + probe + emission in one kernel: ms_probe is all of it
         kern = {'k_fm_search': 0.0, 'k_fm_locate': 0.0, 'k_traverse': 0.0, 'k_table_insert': 0.0, probe_name: 0.0,
                 'k_seed_pack': 0.0}
         # BLOCKS of exactly `steps` steps, each bracketed by barrier + synchronize on both sides and each giving one
@@ -696,6 +707,7 @@ def main():
                      'k_fm_search': [['k_fm_search_direct'], ['void k_fm_search<false']],
                      'k_traverse': [['void k_traverse<false']],
                      'k_kmer_probe': [['void k_kmer_probe<true'], ['void k_kmer_probe<false'], ['k_kmer_probe']],
+                     'k_kmer_step': [['void k_kmer_step<false, true'], ['void k_kmer_step<true, true'], ['void k_kmer_step<false, false'], ['k_kmer_step']],
                      'k_seed_pack': [['void k_seed_pack<false, false, true'], ['void k_seed_pack<false, false, false'], ['k_seed_pack']],
                      'k_table_insert': [['k_sb_count', 'k_sb_scatter', 'k_sb_build']]}.get(dom, [[dom]])
             tot = lambda t: t.get('fetch_size_bytes', 0.0) + t.get('write_size_bytes', 0.0)      # noqa: E731
@@ -727,7 +739,7 @@ def main():
             out['random_load_peak_source'] = 'psigpu_measure_random_loads (64-byte sector per quad, 4 GiB table), this run'
             out['lf_steps_per_launch'] = int(c['n_lf_steps'])
             out['lf_steps_per_s'] = c['n_lf_steps'] / (avg_ms * 1e-3)
-        if dom == 'k_kmer_probe':
+        if dom in ('k_kmer_probe', 'k_kmer_step'):
             # secondary bound: divergent 16-byte loads per second against the rate
             # tools/rand_sector2.hip measures on this part for a table of this size
             out['random_loads_per_s'] = c['n_seeds_valid'] / (avg_ms * 1e-3) if avg_ms > 0 else None
@@ -835,14 +847,16 @@ def main():
     if world > 1:
         # ---- per-GPU rates (each rank's own steps, before it waits at the barrier) --------------------------------
         c_m = main_res['c']
-        probe_ms = main_res['kern'].get('k_kmer_probe', 0.0) / max(1, main_res['steps'])
+        pk_name = 'k_kmer_step' if 'k_kmer_step' in main_res['kern'] else 'k_kmer_probe'
+        c_m['n_hits_table'] = c_m.get('n_hits_table', 0)
+        probe_ms = main_res['kern'].get(pk_name, 0.0) / max(1, main_res['steps'])
         mine_t = torch.tensor([main_res['own_ms_per_step'], float(c_m['n_seeds']), probe_ms,
-                               algorithmic_bytes('k_kmer_probe', c_m, k, args.sa_rate) if probe_ms else 0.0, t_up, t_prep],
+                               algorithmic_bytes(pk_name, c_m, k, args.sa_rate) if probe_ms else 0.0, t_up, t_prep],
                               dtype=torch.float64, device=red_dev)
         allt = [torch.zeros_like(mine_t) for _ in range(world)]
         dist.all_gather(allt, mine_t)
         per_gpu = [{'rank': r, 'ms_per_step': float(x[0]), 'seeds_per_s': float(x[1]) / (float(x[0]) * 1e-3) if float(x[0]) else 0.0,
-                    'k_kmer_probe_ms': float(x[2]),
+                    'k_kmer_probe_ms': float(x[2]),          # (k_kmer_step when the default step is one kernel)
                     'roofline_frac': (float(x[3]) / (float(x[2]) * 1e-3) / 1e9 / HBM_PEAK_GBS) if float(x[2]) else None,
                     'index_upload_s': float(x[4]), 'tables_s': float(x[5])} for r, x in enumerate(allt)]
         # ---- SURVEY 8(d) through every GPU's own host link at once: psigpu_find_seeds_packed on every rank ----------
@@ -937,7 +951,7 @@ def main():
                 'index_build_s': t_ix, 'index_built_on': 'host' if args.host_build else 'device',
                 'seeds_per_step_per_gpu': int(c['n_seeds']), 'hits_per_step_per_gpu': int(c['n_hits']),
                 'hits_on_path': int(c['n_hits_on_path']), 'hits_off_path': int(c['n_hits_off_path']),
-                'uniform_reads_flag': not args.general_reads,
+                'uniform_reads_flag': not args.general_reads, 'record_order': 'read order' if args.ordered else 'any (PSIGPU_ANY_ORDER)',
                 'query_mode': args.mode, 'locus_kmers': int(c['n_locus_kmers']), 'path_kmers': int(c['n_path_kmers']),
                 'table_build_ms': float(c['ms_locus_table_build']), 'prepare_wall_s': t_prep,
                 'loci_traversed_per_step': int(c['n_loci_traversed']),
@@ -1053,7 +1067,8 @@ def main():
         # chunk i + 1 is queued before chunk i is ended: the device does not wait for the host between two steps.  NOT
         # `value` (whose steps are synchronous calls, as in every round): what a loop that double-buffers its batches gets.
         if args.mode == 'kmer-table':
-            bcalls = [(finder.ctx, d[0].data_ptr(), d[1].data_ptr(), args.reads, d[2], k, step, rec_offset, psi_amd.ALL | uni, stream) for d in dev]
+            bcalls = [(finder.ctx, d[0].data_ptr(), d[1].data_ptr(), args.reads, d[2], k, step, rec_offset,
+                       psi_amd.ALL | uni | (0 if args.ordered else psi_amd.ANY_ORDER), stream) for d in dev]
             dh, nh = C.c_void_p(), C.c_uint64()
 
             def pipelined(n_steps):

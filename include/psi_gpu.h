@@ -372,6 +372,13 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k);
                                    are packed; a chunk for which it does not hold is answered again the general way (same
                                    records, a little later).  psi::Records sets it for chunks of equal-length reads. */
 
+#define PSIGPU_ANY_ORDER 16u    /* raw records (no PSIGPU_SORT_UNIQUE: ignored with it) may come out in ANY order, as the
+                                   reference's callback stream does (its order is unspecified: seed_finder.hpp:1724-1732 walks
+                                   an index, not the reads).  Without the flag the default mode hands the records out seed by
+                                   seed in read order, which costs its one kernel a look-back over the tiles in front of every
+                                   tile (~0.06 ms per 7 M seeds); with it a tile takes its output range with one atomic add:
+                                   same records, blocks of 1024 seeds in the order they finished.  Other query modes ignore it. */
+
 /* One chunk of psikt's loop: get_seeds + index_reads + seeds_all (src/psikt.cpp:195-204).
  * `bases`/`read_off` are HOST buffers (read i = bases[read_off[i] .. read_off[i+1])),
  * `step` is psikt's -d (0 = k), `rec_offset` the number of reads consumed before this

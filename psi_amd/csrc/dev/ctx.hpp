@@ -1,0 +1,396 @@
+// the context, process-wide pools, uploads and their checksums -- part of the one translation unit device.hip (included there, in order; not a header of its own).
+struct psigpu_ctx {
+  int device = 0;
+  std::string err;
+  // graph
+  bool have_graph = false;
+  uint64_t n_nodes = 0;
+  std::vector<uint32_t> node_len;   // label length per node (host): a loaded index's loci are checked against it
+  DevBuf nodes, lite, node_id, lab2, labn, edge_to;
+  // index
+  bool have_index = false;
+  bool fm_ok = true;               // rank blocks present: FM search possible (false: k-mer table mode only)
+  uint32_t index_k = 0, sa_rate = 0, context = 0, n_paths = 0;
+  uint64_t n_loci = 0;
+  // One PART of the index on the device: a complete FM index over a group of paths (an index is one part
+  // unless its text would pass the 32-bit row limit).  The FM modes and MEM mode search every part; the
+  // k-mer table tabulates them together.
+  struct FmPart {
+    DevBuf blocks, samples, exc_row, exc_sa, ftab, text4, seg, seg_dir, seg_rank;      // (exc_row: + the super-block counts)
+    DevBuf saloc;                    // (node rank, offset) per SA row (sa_rate 1, when memory is plentiful)
+    DevBuf sarec;                    // per-row records for seed length sarec_k (sa_rate 1, interval table, text resident)
+    DevBuf ftabx;                    // interval table with the first row's record in its entries (FtabX), for seed length ftabx_k
+    uint64_t text_len = 0, n_exc = 0, n_segs = 0;
+    uint64_t C[4] = { 0, 0, 0, 0 };
+    uint32_t ftab_len = 0, exc_shift = EXC_SUPER_SHIFT, sarec_k = 0, ftabx_k = 0;
+    bool have_text4 = false, have_saloc = false;
+    void release()
+    {
+      for (DevBuf* b : { &blocks, &samples, &exc_row, &exc_sa, &ftab, &text4, &seg, &seg_dir, &seg_rank, &saloc, &sarec, &ftabx }) b->release();
+      text_len = n_exc = n_segs = 0; ftab_len = sarec_k = ftabx_k = 0; have_text4 = have_saloc = false;
+    }
+  };
+  std::vector<std::unique_ptr<FmPart>> parts;      // parts[0] always exists
+  FmPart& p0() const { return *parts[0]; }
+  bool rows_tried = false;         // build_row_records has run for this index (the records exist, or do not fit / apply)
+  bool id_affine = false;          // external node id = rank + id_base
+  uint64_t id_base = 0;
+  DevBuf loci;
+  uint32_t gocc_thr = 0;
+  uint32_t tune = 0;               // PSIGPU_TUNE_* measurement switches (psigpu_set_tuning)
+  bool kt_dedup = false;           // the k-mer table was built without a gocc threshold: one entry per graph position
+  // locus k-mer table (built on first use for the index's seed length)
+  uint32_t query_mode = PSIGPU_MODE_KMER_TABLE, walk_cap = 0;
+  bool lkt_ready = false, lkt_failed = false;
+  bool kt_ready = false;           // the table also holds the path k-mers (KmerSlot), K1 is one probe
+  DevBuf kt_ht, kt_ext, kt_onpos;
+  uint64_t kt_ht_size = 0, kt_n_path_kmers = 0, kt_n_ext = 0;
+  uint32_t lkt_k = 0;
+  DevBuf lkt_ht, lkt_ent, lkt_res;
+  // traverse mode, k > 12: the loci's 12-base prefix walks (k_traverse's pfx_roots), made once per index
+  DevBuf pfx_roots;
+  uint64_t pfx_n = 0;
+  bool pfx_ready = false, pfx_failed = false;
+  float pfx_build_ms = 0.f;
+  uint64_t lkt_ht_size = 0, lkt_n_ent = 0, lkt_n_res = 0, lkt_n_walks = 0;
+  float lkt_build_ms = 0.f;
+  std::string lkt_note;
+  DevBuf w_seedout, w_seedres, w_iv_tiles_off, w_defer, w_hit_a, w_hit_seed;
+  DevBuf w_tilestate;              // k_kmer_step's look-back words, one per tile (a word carries the serial of the call that wrote it)
+  const void* tilestate_clean = nullptr;      // the allocation that was last zeroed whole
+  bool opt_no_fused = false;       // A/B, tests: the default step as three kernels (k_seed_pack, k_kmer_probe, k_kmer_emit)
+  // per-call workspace (grow-only)
+  DevBuf in_bases;                 // host entry, reads in pinned memory: the chunk's reads (transfers queued ahead of the compute loop)
+  DevBuf in_mask;                  // ... packed reads: their "not ACGT" bits
+  DevBuf w_bases, w_read_off, w_cnt, w_tiles, w_seed_off, w_seed_key, w_seed_info,
+      w_seed_next, w_ht, w_pfx, w_pfx12, w_iv_lo, w_iv_cnt, w_iv_aux, w_hit_off, w_iv_tiles,
+      w_chunks, w_chunk_fill, w_chunk_off, w_chunk_tiles, w_hits, w_spill_a, w_spill_b, w_ctr, w_total,
+      w_sb_cnt, w_sb_off, w_sb_tiles, w_sb_key,      // the partition of a chunk's seeds (k_sb_*): counts, offsets, (k-mer, seed) records
+      w_seed_wide, w_seed_pfx;                                  // two-word seeds: the k-mers themselves, their first 14 bases
+  uint64_t hits_cap_hint = 0, chunks_cap_hint = 0;
+  uint64_t spill_cap = 1u << 22;   // traverser spill queue entries (grows when a chunk overflows it)
+  void* h_pinned = nullptr;        // pinned host mirror of the counters + counts, written by k_publish
+  void* h_pinned_dev = nullptr;    // the same memory as the device addresses it
+  hipEvent_t ev[12];
+  bool have_events = false;
+  psigpu_counters last{};
+  uint64_t last_max_read_len = 0;  // longest read of the last run_pipeline call
+  // sort-unique on the device (PSIGPU_SORT_UNIQUE)
+  uint64_t max_node_len = 0;
+  DevBuf ids_sorted;               // node ids in increasing order (only when they are not rank + id_base)
+  HitSorter sorter;
+  int grouped_state = 0;           // last run_pipeline: 0 groups not looked at, 1 each seed's hits ordered in place and that
+                                   // makes the array sorted and duplicate-free, 2 it does not
+  DevBuf w_sorted[2], w_count;
+  // host entry point: sub-batches of a chunk pipelined through two slots (H2D | kernels | D2H)
+  struct Slot {
+    DevBuf bases, off, mask;                     // (mask: packed reads, the sub-batch's "not ACGT" bits)
+    void* h_stage = nullptr; size_t h_cap = 0;   // pinned staging: rebased read offsets, and the bases of pageable callers
+    void* h_stage_dev = nullptr;                 // the same memory as the device addresses it
+    hipEvent_t in_ready = nullptr, out_done = nullptr;
+    DevBuf d_wire;                               // 16-byte wire records of the slot's sub-batch (k_hits_wire16)
+    void* h_wire = nullptr; size_t h_wire_cap = 0;   // pinned: where they land on the host, before they are widened
+  } slot[2];
+  DevBuf w_hits_alt;
+  hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+  // the pipeline's transfers, each direction on a copy engine of its own (see pipeline_init)
+  struct EngineCopy {
+    bool ok = false;
+    int n_sig = 0;                               // signals taken from the process-wide pool: sig_in[0..IN_RING-1], then sig_out[0..1]
+    static constexpr int IN_RING = 8;            // transfers of reads that may be queued ahead of the compute loop
+    hsa_agent_t gpu{}, cpu{};
+    uint32_t eng_in = 0, eng_out = 0;            // hsa_amd_sdma_engine_id_t bits
+    hsa_signal_t sig_in[IN_RING]{}, sig_out[2]{};      // 1 while the transfer is in flight (two-slot path: sig_in[0..1])
+    hsa_signal_t sig_fast[3]{};                        // ... the transfers out of the lookahead path's three slots
+  } ec;
+  double hits_per_read_hint = 0.0;
+  bool trace_call = false;         // the host-entry call in progress runs under PSIGPU_TRACE
+  // host entry, default mode: two sub-batches in flight (the kernels of sub-batch i + 1 are queued before the host waits
+  // for sub-batch i).  Set by a run_pipeline call that went through the default mode's five kernels alone; per in-flight
+  // sub-batch a hit buffer, a mapped block for its counters and an event.
+  uint32_t fast_k = 0, fast_flags = 0;
+  bool fast_on = false, fast_off = false;
+  static constexpr int N_FAST = 3;     // (two in the queue + the one whose records are on their way out)
+  struct FastSlot {
+    DevBuf hits, off, wire;
+    void* h = nullptr; void* h_dev = nullptr;
+    void* h_wire = nullptr; size_t h_wire_cap = 0;
+    hipEvent_t begin = nullptr, done = nullptr;
+  } fast[N_FAST];
+  bool opt_no_lookahead = false;
+  uint64_t lookahead_fallbacks = 0;
+  // what the graph and the index left on the device, with a checksum of every array taken when it was loaded
+  // (psigpu_verify_resident: has anything of it changed since?)
+  struct Resident { std::string name; const DevBuf* buf; const void* at; uint64_t bytes; uint64_t sum; };
+  std::vector<Resident> resident;
+  // device-resident entry, two chunks in flight (psigpu_find_seeds_device_begin / _end): what was begun and not ended yet,
+  // oldest first.  A chunk that could be queued (the default mode's kernels alone: enqueue_default) sits in a FastSlot;
+  // any other chunk is answered by the synchronous entry when its turn to be ended comes.
+  struct DevPending {
+    bool queued = false;
+    const char* d_bases = nullptr; const uint64_t* d_mask = nullptr; bool packed = false; const uint64_t* d_off = nullptr;
+    uint64_t nr = 0, nb = 0, rec_offset = 0; uint32_t k = 0, step = 0, flags = 0; void* stream = nullptr;
+    unsigned long long serial = 0; bool uniform = false; uint64_t cap = 0; int slot = 0;
+  } dpend[2];
+  int dp_head = 0, dp_count = 0;
+  uint64_t dp_seq = 0;
+  void* dp_stream = nullptr;       // the stream of the chunks in flight (one stream for all of them: the workspace is shared)
+  std::vector<void*> retired;      // hit buffers outgrown by a _begin while a caller may still read them: freed by the next _end
+  void* stager = nullptr;          // the host entry's helper thread for pageable reads (struct Worker)
+  void* widener = nullptr;         // the host entry's widening threads (struct Widener, made by its first call)
+  // psigpu_set_option
+  uint64_t opt_sub_bytes = 0;
+  bool opt_no_ahead = false, opt_no_engine_copy = false;
+  uint32_t opt_wire = 0;           // 0: the narrowest wire record that fits; 8 / 16 / 32: nothing narrower
+  uint32_t opt_wire8_roff_cap = 0; // test hook: at most this many read-offset bits in an 8-byte record
+  bool opt_no_pfx_roots = false;   // traverse mode from the loci themselves (A/B, tests)
+  bool opt_res16 = false;          // 16 bytes of probe results per seed (A/B, tests)
+  uint64_t opt_expected_calls = 0; // PSIGPU_MODE_AUTO: chunks the caller expects to ask (0: unknown)
+  uint64_t opt_expected_seeds = 0; // ... and seeds over all of them
+  bool auto_mode = false, auto_resolved = false;
+  uint32_t wire_used = 0;          // bytes per wire record the last run_pipeline call left in its wire buffer (0: none)
+  unsigned long long serial = 0;   // run_pipeline calls so far: every call's counter block carries its number
+  uint64_t uniform_refuted = 0;    // calls that claimed PSIGPU_UNIFORM_READS for reads that were not (answered again the general way)
+  uint64_t stale_handbacks = 0;    // counter blocks that came back with another call's number (psigpu_counters.stale_handbacks)
+  bool wire8_overflowed = false;   // a sub-batch's records did not fit 8 bytes: the context stays with 16 from then on
+};
+
+static uint32_t bits_for(uint64_t max_value)      // bits needed to hold 0..max_value (at least 1)
+{
+  uint32_t b = 1;
+  while (b < 64 && (max_value >> b)) ++b;
+  return b;
+}
+
+static thread_local std::string g_create_err;
+
+// The host entry's HSA objects live as long as the process: one reference on the runtime (HIP holds its own), and the
+// completion signals of the engine copies are handed from context to context instead of being destroyed with one --
+// ROCr may still be retiring a copy on its own thread when the waiter that saw the signal reach 0 is already
+// tearing the context down (a finder closed right after its last chunk, under load: silent SIGSEGVs and
+// "double free or corruption" in one of every ~8 fuzz processes sharing a box, none since).
+namespace {
+struct HsaGlobals {
+  std::mutex mu;
+  bool tried = false, up = false;
+  std::vector<hsa_signal_t> idle;
+  bool init()
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!tried) { tried = true; up = hsa_init() == HSA_STATUS_SUCCESS; }
+    return up;
+  }
+  bool take(hsa_signal_t* sg)
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!idle.empty()) { *sg = idle.back(); idle.pop_back(); hsa_signal_store_relaxed(*sg, 0); return true; }
+    }
+    return hsa_signal_create(0, 0, nullptr, sg) == HSA_STATUS_SUCCESS;
+  }
+  void give(hsa_signal_t sg) { std::lock_guard<std::mutex> lk(mu); idle.push_back(sg); }
+};
+HsaGlobals g_hsa;
+}  // namespace
+
+// Pinned host buffers for returned hits are recycled process-wide: hipHostMalloc of a few
+// hundred MB costs tens of milliseconds, a chunk loop would pay it every call.
+namespace {
+struct PinnedPool {
+  std::mutex mu;
+  std::vector<std::pair<void*, size_t>> free_list, live;
+  void* get(size_t bytes)
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < free_list.size(); ++i)
+      if (free_list[i].second >= bytes) {
+        auto b = free_list[i];
+        free_list.erase(free_list.begin() + i);
+        live.push_back(b);
+        return b.first;
+      }
+    void* p = nullptr;
+    size_t want = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocMapped) != hipSuccess) return nullptr;
+    live.emplace_back(p, want);
+    return p;
+  }
+  void put(void* p)
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < live.size(); ++i)
+      if (live[i].first == p) {
+        free_list.push_back(live[i]);
+        live.erase(live.begin() + i);
+        // keep at most two idle buffers
+        while (free_list.size() > 2) { (void)hipHostFree(free_list.front().first); free_list.erase(free_list.begin()); }
+        return;
+      }
+    (void)hipHostFree(p);
+  }
+};
+PinnedPool g_pinned;
+}  // namespace
+
+#define HIPCHK(ctx, call)                                                                    \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+      return PSIGPU_ERR_DEVICE;                                                              \
+    }                                                                                        \
+  } while (0)
+
+// A large array of ordinary (pageable) host memory to the device: hipMemcpy stages such a copy on one thread
+// (6-10 GB/s: a whole-genome index, 45 GB, took 7 of the 11 s of psigpu_load_index); here a few threads copy
+// 32-MiB pieces into two pinned buffers while the previous piece is on its way.
+static void copy_on_threads(char* dst, const char* src, size_t n)
+{
+  const unsigned hw = std::thread::hardware_concurrency();
+  const unsigned parts = (unsigned)std::min<size_t>(std::min<unsigned>(8, hw ? hw : 1), std::max<size_t>(1, n / (2u << 20)));
+  if (parts <= 1) { memcpy(dst, src, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n / parts + 63) & ~(size_t)63;
+  for (unsigned t = 1; t < parts; ++t) {
+    const size_t a = std::min(n, t * per), b = std::min(n, (t + 1) * per);
+    th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
+  }
+  memcpy(dst, src, std::min(n, per));
+  for (auto& t : th) t.join();
+}
+
+static int upload_large(psigpu_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+  constexpr size_t PIECE = 32u << 20;
+  struct Stage {
+    void* buf[2] = { nullptr, nullptr };
+    hipEvent_t done[2] = { nullptr, nullptr };
+    hipStream_t s = nullptr;
+    ~Stage()
+    {
+      if (s) (void)hipStreamSynchronize(s);       // (an error path may leave a piece in flight)
+      for (int i = 0; i < 2; ++i) { if (buf[i]) (void)hipHostFree(buf[i]); if (done[i]) (void)hipEventDestroy(done[i]); }
+      if (s) (void)hipStreamDestroy(s);
+    }
+  } st;
+  bool ok = hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && ok; ++i)
+    ok = hipHostMalloc(&st.buf[i], PIECE, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&st.done[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {                                        // no pinned memory to spare: the plain copy
+    (void)hipGetLastError();
+    HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return PSIGPU_OK;
+  }
+  size_t piece = 0;
+  for (size_t off = 0; off < bytes; off += PIECE, ++piece) {
+    const size_t len = std::min(PIECE, bytes - off);
+    const int i = (int)(piece & 1);
+    if (piece >= 2) HIPCHK(ctx, hipEventSynchronize(st.done[i]));
+    copy_on_threads((char*)st.buf[i], (const char*)src + off, len);
+    HIPCHK(ctx, hipMemcpyAsync((char*)dst + off, st.buf[i], len, hipMemcpyHostToDevice, st.s));
+    HIPCHK(ctx, hipEventRecord(st.done[i], st.s));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(st.s));
+  return PSIGPU_OK;
+}
+
+// A/B switches of the load campaigns (read per call: a campaign sets them for its own finders).
+// PSIGPU_AB_LOAD_HOLE=1 brings back what the loaders did before round 5: pads filled on the null stream with nobody waiting,
+// no device synchronisation when a loader returns, no read-back of checksums (which happened to order the fills).
+// PSIGPU_AB_NO_PAD_ZERO=1 leaves the pads as allocated (with PSIGPU_POISON: a known byte) -- does any answer depend on them?
+static bool ab_load_hole() { return getenv("PSIGPU_AB_LOAD_HOLE") != nullptr; }
+static bool ab_no_pad_zero() { return getenv("PSIGPU_AB_NO_PAD_ZERO") != nullptr; }
+// every loader ends here: whatever it queued on any stream (fills, table kernels) has run when the caller gets control back
+static int loader_fence(psigpu_ctx* ctx)
+{
+  if (ab_load_hole()) return PSIGPU_OK;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { ctx->err = std::string("hipDeviceSynchronize (end of a loader): ") + hipGetErrorString(e); return PSIGPU_ERR_DEVICE; }
+  return PSIGPU_OK;
+}
+
+// ---- what the device holds of the graph and the index, checked against what was put there ------------------------
+// Three wrong answers of the load campaigns have in common the data a freshly loaded finder reads, not a
+// kernel.  Every array the loaders put on the device leaves a 64-bit checksum behind (a grid-stride kernel: 9 GB in a few
+// milliseconds); psigpu_verify_resident recomputes them -- "has anything the finder reads changed since it was loaded?" --
+// and with PSIGPU_VERIFY_UPLOAD=1 every upload is also checked against the same sum over its HOST source (one pass of
+// the CPU over the array: campaigns only).
+__device__ __host__ inline uint64_t resident_mix(uint64_t w, uint64_t i)
+{
+  uint64_t x = w + 0x9E3779B97F4A7C15ull * (i + 1);
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
+  return x;
+}
+__global__ void __launch_bounds__(256) k_checksum(const uint64_t* __restrict__ p, uint64_t n_words, unsigned long long* __restrict__ out)
+{
+  uint64_t acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) acc += resident_mix(p[i], i);
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+  if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+}
+static int device_checksum(psigpu_ctx* ctx, const void* d, uint64_t bytes, uint64_t* sum)
+{
+  *sum = 0;
+  const uint64_t n_words = bytes / 8;                 // (a tail of fewer than eight bytes is left out on both sides)
+  if (n_words == 0) return PSIGPU_OK;
+  TmpBuf acc;
+  HIPCHK(ctx, acc.alloc(8));
+  HIPCHK(ctx, hipMemset(acc.p, 0, 8));
+  const unsigned grid = (unsigned)std::min<uint64_t>((n_words + 255) / 256, 256 * 16);
+  k_checksum<<<grid, 256>>>(reinterpret_cast<const uint64_t*>(d), n_words, acc.as<unsigned long long>());
+  HIPCHK(ctx, hipMemcpy(sum, acc.p, 8, hipMemcpyDeviceToHost));
+  return PSIGPU_OK;
+}
+static uint64_t host_checksum(const void* h, uint64_t bytes)
+{
+  const uint64_t n_words = bytes / 8;
+  std::atomic<uint64_t> acc{ 0 };
+  const char* c = static_cast<const char*>(h);
+  parallel_for(n_words, 1u << 20, [&](uint64_t i0, uint64_t i1) {
+    uint64_t a = 0;
+    for (uint64_t i = i0; i < i1; ++i) { uint64_t w; memcpy(&w, c + 8 * i, 8); a += resident_mix(w, i); }
+    acc.fetch_add(a, std::memory_order_relaxed);
+  });
+  return acc.load();
+}
+// record (and, on request, verify against the host source) what was just put at `at` (inside b)
+static int resident_note(psigpu_ctx* ctx, const char* name, const DevBuf& b, const void* at, const void* host_src, uint64_t bytes)
+{
+  const bool env_verify = getenv("PSIGPU_VERIFY_UPLOAD") != nullptr;      // (read per load: a campaign switches it on for its own finders)
+  uint64_t sum = 0;
+  int st = device_checksum(ctx, at, bytes, &sum);
+  if (st != PSIGPU_OK) return st;
+  if (env_verify && host_src && sum != host_checksum(host_src, bytes)) {
+    fprintf(stderr, "[psigpu] PSIGPU_VERIFY_UPLOAD: %s (%llu bytes) is not on the device what it is on the host\n", name, (unsigned long long)bytes);
+    ctx->err = std::string("upload of ") + name + " failed verification";
+    return PSIGPU_ERR_DEVICE;
+  }
+  for (auto& r : ctx->resident)
+    if (r.buf == &b && r.at == at) { r.name = name; r.bytes = bytes; r.sum = sum; return PSIGPU_OK; }
+  ctx->resident.push_back(psigpu_ctx::Resident{ name, &b, at, bytes, sum });
+  return PSIGPU_OK;
+}
+static void resident_forget(psigpu_ctx* ctx, const DevBuf& b)
+{
+  auto& v = ctx->resident;
+  v.erase(std::remove_if(v.begin(), v.end(), [&](const psigpu_ctx::Resident& r) { return r.buf == &b; }), v.end());
+}
+
+template <typename T>
+static int upload(psigpu_ctx* ctx, DevBuf& b, const T* src, uint64_t n, uint64_t pad_elems = 0, const char* name = nullptr)
+{
+  if (name) resident_forget(ctx, b);
+  HIPCHK(ctx, b.ensure((n + pad_elems) * sizeof(T) + 16));
+  if (n * sizeof(T) >= (64u << 20)) { int st = upload_large(ctx, b.p, src, n * sizeof(T)); if (st != PSIGPU_OK) return st; }
+  else
+  if (n) HIPCHK(ctx, hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  if (pad_elems && !ab_no_pad_zero()) {
+    // hipMemset on the null stream returns before the fill has run, and the query kernels run on non-blocking streams that
+    // do not order against the null stream: the host waits for the fill here (round-4 review: the loaders' ordering hole)
+    HIPCHK(ctx, hipMemsetAsync((char*)b.p + n * sizeof(T), 0, pad_elems * sizeof(T), nullptr));
+    if (!ab_load_hole()) HIPCHK(ctx, hipStreamSynchronize(nullptr));
+  }
+  if (name && n && !ab_load_hole()) return resident_note(ctx, name, b, b.p, src, n * sizeof(T));
+  return PSIGPU_OK;
+}
+

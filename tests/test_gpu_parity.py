@@ -675,6 +675,65 @@ def test_properties_at_scale():
 
 
 @pytest.mark.parametrize('query_mode', ['kmer-table'], indirect=True)
+def _independent_windows(sg, px, finder, k, n_windows, wlen, lo_pos, hi_pos, seed=7, reads_per_window=300):
+    """A checker that takes NOTHING from the product (round-4 review: every oracle run fed paths, trims, loci and the
+    suffix array of the finder under test, so a locus the product fails to detect was missing on both sides).  On
+    `n_windows` random windows of `wlen` backbone bases: the window's subgraph as a brute-force Graph; its starting loci by
+    the brute-force DEFINITION (oracle/brute.py uncovered_loci: every k-walk that is not a run of the path -- the intent of
+    seed_finder.hpp:1481-1541, pinned by test_seedfinder.cpp:98-163 in tests/test_oracle_golden.py); the oracle's path
+    index over the window with its OWN suffix array (ext_sa = None); reads drawn from the window.  Compared, away from
+    the window's cut ends: (a) the product's loci inside the window with the definition's, (b) the product's records for
+    those reads -- the finder over the WHOLE graph -- with the oracle's over the window."""
+    import oracle
+    from oracle import brute
+    rng = np.random.default_rng(seed)
+    snv_pos = np.flatnonzero(sg.alt)
+    lab = lambda pos: int(pos) + int(np.searchsorted(snv_pos, pos, side='left'))           # noqa: E731  label coordinate of a backbone position
+    lo = sg.label_off.astype(np.int64)
+    eo = sg.edge_off.astype(np.int64)
+    ln, lc = px.loci
+    path = px.paths()[0].astype(np.int64)
+    margin = 64
+    n_loci_checked = n_hits_checked = 0
+    for w0 in rng.integers(lo_pos, hi_pos - wlen, size=n_windows):
+        w0 = int(w0)
+        v0 = int(np.searchsorted(sg.label_off, np.uint64(lab(w0)), side='left'))
+        v1 = int(np.searchsorted(sg.label_off, np.uint64(lab(w0 + wlen)), side='left'))
+        labels = bytes(sg.labels[int(lo[v0]):int(lo[v1])]).decode()
+        bg = brute.Graph()
+        for v in range(v0, v1):
+            bg.add_node(int(sg.node_id[v]), labels[int(lo[v] - lo[v0]):int(lo[v + 1] - lo[v0])])
+        for v in range(v0, v1):
+            bg.out[int(sg.node_id[v])] = [int(sg.node_id[t]) for t in sg.edge_to[eo[v]:eo[v + 1]].tolist() if v0 <= t < v1]
+        sub_path = path[(path >= v0) & (path < v1)]
+        # (a) the loci
+        want_loci = brute.uncovered_loci(bg, [[int(sg.node_id[r]) for r in sub_path]], k)
+        id_lo, id_hi = int(sg.node_id[v0 + margin]), int(sg.node_id[v1 - margin])
+        want_in = [(v, o) for v, o in want_loci if id_lo <= v < id_hi]
+        a, b = np.searchsorted(ln, [v0 + margin, v1 - margin])
+        got_in = [(int(sg.node_id[v]), int(o)) for v, o in zip(ln[a:b].tolist(), lc[a:b].tolist())]
+        assert got_in == want_in, 'starting loci differ from the brute-force definition in the window at %d' % w0
+        n_loci_checked += len(want_in)
+        # (b) the records: reads from inside the window, each SNV's allele at random
+        start = rng.integers(w0 + 2500, w0 + wlen - 2700, size=reads_per_window)      # (inside the margins: 64 nodes of <= 32 bases)
+        idx = start[:, None] + np.arange(150)[None, :]
+        r, al = sg.backbone[idx], sg.alt[idx]
+        wb = np.ascontiguousarray(np.where((al != 0) & (rng.random(size=idx.shape) < 0.5), al, r).reshape(-1))
+        woff = np.arange(reads_per_window + 1, dtype=np.uint64) * np.uint64(150)
+        og = oracle.OracleGraph.from_brute(bg)
+        pidx = oracle.OraclePathIndex(og, [(sub_path - v0).tolist()])                 # (its own suffix array)
+        rank = {v: i for i, v in enumerate(bg.ids)}
+        o_ln = np.array([rank[v] for v, _ in want_loci], np.uint32)
+        o_lo = np.array([o for _, o in want_loci], np.uint32)
+        want = oracle.sort_unique(oracle.seeds_all(og, pidx, bytes(wb), woff, k, k, o_ln, o_lo, threads=4))
+        got = psi_amd.sort_unique(finder.seeds_all((wb, woff), step=k))
+        inner = lambda h: h[(h[:, 0] >= np.uint64(id_lo)) & (h[:, 0] < np.uint64(id_hi))]      # noqa: E731
+        got, want = inner(got), inner(want)
+        assert len(want) >= reads_per_window * 7 and _eq(got, want), 'records differ from the independent oracle in the window at %d' % w0
+        n_hits_checked += len(want)
+    return n_loci_checked, n_hits_checked
+
+
 def test_query_modes_agree_at_full_size(query_mode):
     """BASELINE.json configs[1] at full size (51 Mbp, 1.1 M SNVs, 1 M x 150 bp reads, k = 21): the
     three query modes return the same 7.0 M sort-unique records, every seed is found where it was sampled."""
@@ -707,6 +766,14 @@ def test_query_modes_agree_at_full_size(query_mode):
                                                threads=oracle.lib().orc_max_threads()))
     want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
     assert _eq(res['kmer-table'], want)
+    # ... and a checker that takes nothing from the product: 20 random 50-kbp windows, loci by the brute-force definition,
+    # the oracle's own suffix array (once per run of the suite: the modes agree, asserted above)
+    if query_mode == 'kmer-table':
+        f = psi_amd.SeedFinder(g, k)
+        f.set_path_index(px)
+        n_l, n_h = _independent_windows(sg, px, f, k, 20, 50_000, sg.n_block + 1000, 51_000_000 - 1000)
+        f.close()
+        assert n_l > 20 * 15_000 and n_h > 20 * 300 * 7 - 200
 
 
 @pytest.mark.parametrize('query_mode', ['kmer-table'], indirect=True)
@@ -783,6 +850,9 @@ def test_config2_whole_genome(query_mode):
     got, want = psi_amd.sort_unique(inner(got)), inner(want)
     assert len(want) >= n_win * 7
     assert _eq(got, want)
+    # ---- and the checker that takes nothing from the product (20 random 50-kbp windows of the 3.1 Gbp) ------------------
+    n_l, n_h = _independent_windows(sg, px, f, k, 20, 50_000, sg.n_block + 1000, L - 1000)
+    assert n_l > 20 * 15_000 and n_h > 20 * 300 * 7 - 200
     f.close()
 
 
@@ -2030,3 +2100,100 @@ def test_resident_arrays_keep_their_checksums():
         f.close()
     finally:
         os.environ.pop('PSIGPU_VERIFY_UPLOAD', None)
+
+
+@pytest.mark.parametrize('k,step', [(21, 1), (21, 21), (12, 3), (31, 2)])
+def test_one_kernel_step_equals_the_three_kernel_step(query_mode, k, step):
+    """k_kmer_step (round 5: seeding, table probe and emission of a tile of seeds in one kernel, output offsets by a decoupled
+    look-back over the tiles) returns the RAW records of k_seed_pack -> k_kmer_probe -> k_kmer_emit in the same order:
+    equal-length reads with and without the claim, ragged reads with N / lower case / short / empty reads, packed words,
+    more tiles than one look-back window holds (> 64 tiles of 1024 seeds), a hit buffer that overflows (the call again with
+    room), sort-unique on the device, the device-resident entry with two chunks in flight, the host entry in sub-batches."""
+    import torch
+    if query_mode != 'kmer-table':
+        pytest.skip('the one-kernel step is the default mode without a traverser pass')
+    g, reads = _x_case()
+    f1 = psi_amd.SeedFinder(g, k)
+    f1.create_path_index(2, rng_seed=5)
+    f3 = psi_amd.SeedFinder(g, k)
+    f3.set_option('no_fused', 1)
+    f3.set_path_index(f1.pindex)
+    equal = [r[:100] for r in reads if len(r) >= 100]
+    ragged = _ragged_reads(reads[:600], k)
+    many = equal * (1 if step > 1 else 1)
+    cases = [(equal, psi_amd.ALL | psi_amd.UNIFORM_READS), (equal, psi_amd.ALL), (ragged, psi_amd.ALL), (ragged[:7], psi_amd.ALL),
+             (equal, psi_amd.ON_PATHS), (ragged, psi_amd.OFF_PATHS | psi_amd.UNIFORM_READS), (many, psi_amd.ALL | psi_amd.SORT_UNIQUE)]
+    for rs, flags in cases:
+        bases, off = psi_amd.pack_reads(rs)
+        d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        got, want = [], []
+        for f, out in ((f1, got), (f3, want)):
+            ptr, n = f.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, rec_offset=77, flags=flags)
+            out.append(f.copy_hits(ptr, n))
+            out.append(f.counters())
+        assert _eq(got[0], want[0]), (len(rs), flags)                 # raw records, same order
+        assert got[1]['fused_step'] == 1 and want[1]['fused_step'] == 0
+        for key in ('n_seeds', 'n_seeds_valid', 'n_seeds_on_path', 'n_hits_on_path', 'n_hits_off_path', 'n_hits'):
+            assert got[1][key] == want[1][key], key
+        # packed words through the same kernel
+        pr = psi_amd.PackedReads(bases, off)
+        d_w, d_m = torch.from_numpy(pr.words.view(np.int64)).cuda(), torch.from_numpy(pr._mask_store.view(np.int64)).cuda()
+        ptr, n = f1.seeds_all_device_packed(d_w.data_ptr(), d_m.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, rec_offset=77, flags=flags)
+        assert _eq(f1.copy_hits(ptr, n), want[0])
+    if step == 1:
+        assert got[1]['n_seeds'] > 64 * 1024                         # (the look-back moved its window)
+    # PSIGPU_ANY_ORDER: the same raw records (as a multiset), tiles of 1024 seeds in the order they finished; with
+    # PSIGPU_SORT_UNIQUE the flag is ignored
+    rows = lambda h: h[np.lexsort(h.T[::-1])]                        # noqa: E731
+    for rs, flags in cases[:3]:
+        bases, off = psi_amd.pack_reads(rs)
+        d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        ptr, n = f1.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, rec_offset=77, flags=flags)
+        ordered = f1.copy_hits(ptr, n)
+        for _ in range(3):
+            ptr, n = f1.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, rec_offset=77, flags=flags | psi_amd.ANY_ORDER)
+            anyo = f1.copy_hits(ptr, n)
+            assert f1.counters()['n_hits'] == len(ordered)
+            assert _eq(rows(anyo), rows(ordered))
+        ptr, n = f1.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, rec_offset=77, flags=flags | psi_amd.SORT_UNIQUE)
+        su = f1.copy_hits(ptr, n)
+        ptr, n = f1.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, rec_offset=77,
+                                     flags=flags | psi_amd.SORT_UNIQUE | psi_amd.ANY_ORDER)
+        assert _eq(f1.copy_hits(ptr, n), su)
+        # (the three-kernel step has one order only)
+        ptr, n = f3.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(rs), len(bases), step=step, rec_offset=77, flags=flags | psi_amd.ANY_ORDER)
+        assert _eq(f3.copy_hits(ptr, n), ordered)
+    # the hit buffer overflows (a fresh context has no hint; many hits per seed at k = 12): the call is made again with room
+    f1b = psi_amd.SeedFinder(g, k)
+    f1b.set_path_index(f1.pindex)
+    lots = equal * 3
+    a = f1b.seeds_all(lots, step=step)
+    b = f3.seeds_all(lots, step=step)
+    assert _eq(a, b)
+    # the host entry, cut into sub-batches, sorted on the device; and two chunks in flight
+    os.environ['PSIGPU_SUB_BYTES'] = '20000'
+    try:
+        assert _eq(f1.seeds_all(ragged, step=step, sort_unique=True), f3.seeds_all(ragged, step=step, sort_unique=True))
+        pb = psi_amd.pinned_copy(psi_amd.pack_reads(equal)[0]), psi_amd.pinned_copy(psi_amd.pack_reads(equal)[1])
+        for _ in range(2):
+            assert _eq(f1.seeds_all((pb[0].array, pb[1].array), step=step, sort_unique=True), f3.seeds_all(equal, step=step, sort_unique=True))
+    finally:
+        os.environ.pop('PSIGPU_SUB_BYTES')
+    bases, off = psi_amd.pack_reads(equal)
+    d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    ptr, n = f3.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(equal), len(bases), step=step, flags=psi_amd.ALL | psi_amd.UNIFORM_READS)
+    w = f3.copy_hits(ptr, n)
+    f1.seeds_all_device(d_b.data_ptr(), d_o.data_ptr(), len(equal), len(bases), step=step, flags=psi_amd.ALL | psi_amd.UNIFORM_READS)
+    for _ in range(2):
+        f1.seeds_all_device_begin(d_b.data_ptr(), d_o.data_ptr(), len(equal), len(bases), step=step, flags=psi_amd.ALL | psi_amd.UNIFORM_READS)
+    for _ in range(2):
+        ptr, n = f1.seeds_all_device_end()
+        assert _eq(f1.copy_hits(ptr, n), w)
+        assert f1.counters()['fused_step'] == 1
+    for _ in range(2):
+        f1.seeds_all_device_begin(d_b.data_ptr(), d_o.data_ptr(), len(equal), len(bases), step=step,
+                                  flags=psi_amd.ALL | psi_amd.UNIFORM_READS | psi_amd.ANY_ORDER)
+    for _ in range(2):
+        ptr, n = f1.seeds_all_device_end()
+        assert _eq(rows(f1.copy_hits(ptr, n)), rows(w))
+    f1.close(); f1b.close(); f3.close()

@@ -10,6 +10,8 @@ for i in $(seq 0 $((N-1))); do
   pids+=($!)
 done
 rc=0
-for p in "${pids[@]}"; do wait $p || rc=1; done
+# (exit codes: 0 finished its seeds, 124 ran until the timeout -- both fine; 1 a mismatch or an exception; 134 / 139 a fatal signal)
+i=0
+for p in "${pids[@]}"; do wait $p; e=$?; echo "EXIT p$i $e"; if [ $e -ne 0 ] && [ $e -ne 124 ]; then rc=1; fi; i=$((i+1)); done
 for i in $(seq 0 $((N-1))); do echo "== p$i"; grep -v "^seed" gpurun_out/fuzz_${TAG:-r}_p$i.log | tail -n 70; grep "^seed" gpurun_out/fuzz_${TAG:-r}_p$i.log | tail -n 1; done
 exit $rc

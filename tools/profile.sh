@@ -46,6 +46,9 @@ import json
 calls={}
 for k,c,v,n in rows:
     if k.startswith("void k_seed_pack") or k.startswith("k_seed_pack"): calls[c]=n
+# (the default step is one kernel since round 5: a step = one k_kmer_step dispatch)
+for k,c,v,n in rows:
+    if c not in calls and (k.startswith("void k_kmer_step") or k.startswith("k_kmer_step")): calls[c]=n
 tr={}
 for k,c,v,n in rows:
     if c in ("FETCH_SIZE","WRITE_SIZE"):
