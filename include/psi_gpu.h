@@ -409,8 +409,11 @@ int psigpu_find_seeds_packed(psigpu_ctx* ctx, const uint64_t* packed, const uint
                              psigpu_hits* out);
 /* ASCII bases [first, first + n) of a chunk -> their bits in packed / n_mask (arrays for the whole chunk, zeroed by the
  * caller or filled front to back: the words that [first, first + n) touches only partly are or-ed into).  Any byte that
- * is not one of ACGTacgt sets its mask bit.  Returns the number of non-ACGT bases in the range.  Host only, no GPU needed;
- * ranges that do not share a 64-base block may be packed by different threads at once. */
+ * is not one of ACGTacgt sets its mask bit.  Returns the number of non-ACGT bases in the range.  n_mask may be NULL only
+ * for a caller that looks at that count: such a base is then packed as A, and a chunk packed that way and handed to
+ * psigpu_find_seeds_packed with n_mask = NULL yields seeds ACROSS it -- not what psigpu_find_seeds does with an N -- so a
+ * non-zero count without a mask array means "pack again with one".  Host only, no GPU needed; ranges that do not share a
+ * 64-base block may be packed by different threads at once (32 bases per step where the host has AVX2 + BMI2). */
 uint64_t psigpu_pack_reads(const char* bases, uint64_t first, uint64_t n, uint64_t* packed, uint64_t* n_mask);
 
 /* MEM mode -- SeedFinder::seeds_on_paths( sequence, callback ) -> find_mems

@@ -966,3 +966,45 @@ def test_bench_line_is_small():
     # the LF kernel's algorithmic bytes count one rank block per LF step: no series prices itself above the peak
     c = {'n_seeds_valid': 7_000_000, 'n_lf_steps': 7_000_000 * 21, 'n_rows_verified': 0}
     assert bench.algorithmic_bytes('k_fm_search', c, 21, 1, 0) == 64.0 * 7_000_000 * 21
+
+
+# ---------------------------------------------------------------------------------------
+def test_pack_reads_words_and_mask():
+    """psigpu_pack_reads (host side of psigpu_find_seeds_packed; the vector loop where the host has AVX2 + BMI2, the SWAR loop
+    and the per-base ends elsewhere): words and "not ACGT" bits against a numpy statement of the layout -- base i in bits
+    63 - 2 (i % 32), 62 - 2 (i % 32) of word i / 32, its mask bit i % 64 of word i / 64 -- from aligned and unaligned starts,
+    upper and lower case, N and other letters.  With no mask array a base that is not ACGT is packed as A and only COUNTED:
+    the count is the caller's one sign (round-4 advisor), checked here."""
+    import ctypes as C
+    L = psi_amd.lib()
+    rng = np.random.default_rng(3)
+    n = 200_003
+    alphabet = np.frombuffer(b'ACGTacgtNnRY-', np.uint8)
+    b = alphabet[rng.choice(len(alphabet), size=n, p=[.2, .2, .2, .2, .04, .04, .04, .04, .01, .01, .005, .005, .01])]
+    code = np.full(256, 255, np.uint8)
+    for ch, v in zip(b'ACGTacgt', [0, 1, 2, 3, 0, 1, 2, 3]):
+        code[ch] = v
+
+    def expect(first, cnt):
+        c = code[b[first:first + cnt]]
+        at = np.arange(first, first + cnt, dtype=np.uint64)
+        words = np.zeros((first + cnt + 31) // 32 + 2, np.uint64)
+        mask = np.zeros((first + cnt + 63) // 64 + 2, np.uint64)
+        good = c != 255
+        np.bitwise_or.at(words, (at[good] >> np.uint64(5)).astype(np.int64),
+                         c[good].astype(np.uint64) << (np.uint64(62) - np.uint64(2) * (at[good] & np.uint64(31))))
+        np.bitwise_or.at(mask, (at[~good] >> np.uint64(6)).astype(np.int64), np.uint64(1) << (at[~good] & np.uint64(63)))
+        return words, mask, int((~good).sum())
+
+    for first, cnt in ((0, n), (0, 64), (5, 1000), (31, 64), (32, 31), (7, 33), (0, 95), (64, 4096), (1, 1), (63, 130_000)):
+        words, mask = np.zeros((first + cnt + 31) // 32 + 2, np.uint64), np.zeros((first + cnt + 63) // 64 + 2, np.uint64)
+        bad = L.psigpu_pack_reads(b[first:].ctypes.data_as(C.c_void_p), first, cnt, psi_amd._ptr(words), psi_amd._ptr(mask))
+        ew, em, eb = expect(first, cnt)
+        assert bad == eb and (words == ew).all() and (mask == em).all(), (first, cnt)
+        # no mask array: the same words, the count still says that the chunk needs one
+        words2 = np.zeros_like(words)
+        assert L.psigpu_pack_reads(b[first:].ctypes.data_as(C.c_void_p), first, cnt, psi_amd._ptr(words2), None) == eb
+        assert (words2 == ew).all()
+    clean = np.frombuffer(b'ACGT', np.uint8)[rng.integers(0, 4, size=4097)]
+    words = np.zeros(4097 // 32 + 3, np.uint64)
+    assert L.psigpu_pack_reads(clean.ctypes.data_as(C.c_void_p), 0, len(clean), psi_amd._ptr(words), None) == 0
