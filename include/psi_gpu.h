@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSIGPU_ABI_VERSION 6
+#define PSIGPU_ABI_VERSION 7
 #define PSIGPU_MAX_SEED_LEN 63u   /* psikt takes any -l (src/psikt.cpp:327); seeds are 2-bit packed into one 64-bit word up
                                     to 31 bases and into two words from 32 to 63 */
 #define PSIGPU_MAX_TABLE_SEED_LEN 31u   /* the tabulating query modes (k-mer table, locus table) hold one-word k-mers: longer
@@ -415,6 +415,19 @@ int psigpu_find_seeds_packed(psigpu_ctx* ctx, const uint64_t* packed, const uint
  * non-zero count without a mask array means "pack again with one".  Host only, no GPU needed; ranges that do not share a
  * 64-base block may be packed by different threads at once (32 bases per step where the host has AVX2 + BMI2). */
 uint64_t psigpu_pack_reads(const char* bases, uint64_t first, uint64_t n, uint64_t* packed, uint64_t* n_mask);
+
+/* Seed::gocc (seed.hpp:45, "genome occurrence count") of the on-path phase: how often each seed's k-mer occurs in the indexed
+ * path text -- count_occurrences( fst_itr ) of kmer_exact_matches (index_iter.hpp:842-843), what _add_occurrences hands to
+ * every hit of the seed (index_iter.hpp:743, :674).  counts[s] for seed s of the chunk, reads in order and a read's seeds in
+ * offset order (offsets 0, step, 2 step ... as psigpu_find_seeds takes them; n_counts must be their number); 0 for a seed
+ * with an N and for an index without paths; the gocc threshold is NOT applied (it is a filter on this very number).  The
+ * counts come from the FM index (k_fm_search: the size of the seed's suffix-array interval, over all parts of the index),
+ * whatever the query mode: needs an index view with rank blocks.  The 32-byte records of psigpu_find_seeds* do not carry
+ * the field (psikt does not write it: src/psikt.cpp:176-179); the header API's callbacks get it from here
+ * (psi_amd/include/psi/seed_finder.hpp).  The off-path phase's gocc is the number of READ positions with the k-mer
+ * (traverser_bfs.hpp:103-108: length( saPositions ) of the reads index): a count over the chunk's seeds, made by the caller. */
+int psigpu_count_occurrences(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off, uint64_t n_reads, uint32_t k,
+                             uint32_t step, uint32_t* counts, uint64_t n_counts);
 
 /* MEM mode -- SeedFinder::seeds_on_paths( sequence, callback ) -> find_mems
  * (seed_finder.hpp:1459-1479, index_iter.hpp:854-906): per read, from `start` the pattern grows

@@ -141,6 +141,7 @@ ABI = [
     ('psigpu_find_seeds_packed', C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                            C.c_uint32, C.POINTER(Hits)]),
     ('psigpu_pack_reads', C.c_uint64, [_P, C.c_uint64, C.c_uint64, _P, _P]),
+    ('psigpu_count_occurrences', C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.c_uint64]),
     ('psigpu_find_seeds_device_packed', C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                                   C.c_uint64, C.c_uint32, _P, C.POINTER(_P), _U64P]),
     ('psigpu_set_option', C.c_int, [_P, C.c_char_p, C.c_uint64]),
@@ -688,6 +689,22 @@ class SeedFinder:
 
     def seeds_off_paths(self, reads, step: int = 0, rec_offset: int = 0):
         return self._find(reads, step, rec_offset, OFF_PATHS)
+
+    def count_occurrences(self, reads, step: int = 0) -> np.ndarray:
+        """Seed::gocc of the on-path phase (psigpu_count_occurrences): per seed of the chunk -- reads in order, a read's seeds
+        in offset order -- the number of occurrences of its k-mer in the indexed path text (index_iter.hpp:842-843)."""
+        if isinstance(reads, tuple):
+            bases, off = reads
+        else:
+            bases, off = pack_reads(reads)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        k, st = self.seed_len, step or self.seed_len
+        lens = (off[1:] - off[:-1]).astype(np.int64)
+        n = int(np.where(lens >= k, (lens - k) // st + 1, 0).sum())
+        out = np.zeros(n, np.uint32)
+        self._chk(lib().psigpu_count_occurrences(self.ctx, _ptr(bases), _ptr(off), len(off) - 1, k, st, _ptr(out), n))
+        return out
 
     def find_mems(self, reads, max_mem: int = 0, rec_offset: int = 0) -> np.ndarray:
         """SeedFinder::seeds_on_paths( sequence, callback ) for every read (reference

@@ -49,6 +49,8 @@ struct psigpu_ctx {
   DevBuf lkt_ht, lkt_ent, lkt_res;
   // traverse mode, k > 12: the loci's 12-base prefix walks (k_traverse's pfx_roots), made once per index
   DevBuf pfx_roots;
+  DevBuf w_pfx_surv;               // ... those of them that pass a chunk's prefix maps (k_pfx_filter -> k_traverse)
+  uint32_t pfx_depth = 0;          // bases of a prefix walk: min(k, 14) -- the depth of the chunk's long prefix map
   uint64_t pfx_n = 0;
   bool pfx_ready = false, pfx_failed = false;
   float pfx_build_ms = 0.f;

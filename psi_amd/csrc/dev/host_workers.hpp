@@ -106,6 +106,10 @@ struct Widener {
   std::atomic<bool> stop{ false };              // the session is abandoned (error path): leave it
   std::vector<std::thread> th;
   std::function<void(int)> wait_copy;           // blocks until the slot's device-to-host transfer is complete
+  // PSIGPU_TRACE=2 (timeline of the two-in-flight path): when job j's transfer was seen complete / its last slice widened,
+  // milliseconds on the caller's clock
+  double* tl_copy = nullptr; double* tl_wide = nullptr; double tl_base = 0;
+  static double tl_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   unsigned T = 0;
   std::mutex mu;
   std::condition_variable cv;
@@ -165,7 +169,7 @@ struct Widener {
     for (size_t j = 0; j < n_jobs; ++j) {
       while (posted.load(std::memory_order_acquire) <= j) { if (stop.load()) return; std::this_thread::yield(); }
       const Job job = jobs[j];
-      if (t == 0) { if (job.n) wait_copy(job.slot); ready.store(j + 1, std::memory_order_release); }
+      if (t == 0) { if (job.n) wait_copy(job.slot); if (tl_copy) tl_copy[j] = tl_now() - tl_base; ready.store(j + 1, std::memory_order_release); }
       else while (ready.load(std::memory_order_acquire) <= j) { if (stop.load()) return; std::this_thread::yield(); }
       const uint64_t a = job.n * t / T, b = job.n * (t + 1) / T;
       if (job.fmt.bytes == 8) {
@@ -187,7 +191,7 @@ struct Widener {
         }
       }
       __builtin_ia32_sfence();                   // the streaming stores above, before the slice is declared done
-      parts[j].fetch_add(1, std::memory_order_acq_rel);
+      if (parts[j].fetch_add(1, std::memory_order_acq_rel) + 1 == T && tl_wide) tl_wide[j] = tl_now() - tl_base;
     }
   }
   ~Widener()

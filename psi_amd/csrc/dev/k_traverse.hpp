@@ -116,6 +116,50 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
   }
 }
 
+// The prefix walks of the starting loci against the chunk's prefix maps: a stream (16 bytes per walk in, the few that pass
+// out).  The 12-mer map is 2 MiB (L2), the long one 32 MiB and only asked for walks the short one lets pass.  A wave
+// collects what passes in LDS and appends it with one atomic per ~200 walks (one per round of 64 would be 400 k atomics
+// on one address: 11 ns each).  The order of the survivors is whatever the waves make it; the traverser's records have
+// no order either.
+constexpr uint32_t PF_BUF = 256;
+__global__ void __launch_bounds__(256)
+k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, const uint32_t* __restrict__ pfx12, const uint32_t* __restrict__ pfx_bits,
+             uint32_t depth, uint4* __restrict__ out, unsigned long long* n_out)
+{
+  __shared__ uint4 buf[4][PF_BUF];
+  const uint32_t lane = lane_id(), wib = threadIdx.x >> 6;
+  const uint32_t sh12 = 2 * (depth - PFX_SHORT);
+  uint32_t held = 0;                              // wave-uniform: walks in this wave's buffer
+  auto flush = [&]() {
+    unsigned long long at = 0;
+    if (lane == 0) at = atomicAdd(n_out, (unsigned long long)held);
+    at = __shfl(at, 0);
+    for (uint32_t i = lane; i < held; i += 64) out[at + i] = buf[wib][i];
+    held = 0;
+    __builtin_amdgcn_wave_barrier();
+  };
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t base = (uint64_t)blockIdx.x * 256 + wib * 64; base < n; base += stride) {
+    const uint64_t i = base + lane;
+    uint4 e = make_uint4(0, 0, 0, 0);
+    bool keep = false;
+    if (i < n) {
+      e = roots[i];
+      const uint32_t p12 = e.x >> sh12;
+      keep = (pfx12[p12 >> 5] >> (p12 & 31)) & 1u;
+      if (keep) keep = (pfx_bits[e.x >> 5] >> (e.x & 31)) & 1u;
+    }
+    const uint64_t km = __ballot(keep);
+    if (km) {
+      if (keep) buf[wib][held + (uint32_t)__popcll(km & lanemask_lt())] = e;
+      held += (uint32_t)__popcll(km);
+      __builtin_amdgcn_wave_barrier();
+      if (held > PF_BUF - 64) flush();
+    }
+  }
+  if (held) flush();
+}
+
 template <bool ENUM, typename KEY = uint64_t>
 __global__ void __launch_bounds__(64)
 k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node rank, offset) */,
@@ -123,13 +167,14 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
            const TravItemT<KEY>* __restrict__ spill_in, uint64_t n_spill_in,
            TravItemT<KEY>* __restrict__ spill_out, uint64_t spill_cap,
            uint32_t k, uint64_t rec_offset, psigpu_hit* __restrict__ chunks, uint32_t* __restrict__ chunk_fill,
-           uint32_t cap_chunks, uint64_t n_nodes, DevCounters* ctr, EnumOut eo, const uint4* __restrict__ pfx_roots = nullptr)
+           uint32_t cap_chunks, uint64_t n_nodes, DevCounters* ctr, EnumOut eo, const uint4* __restrict__ pfx_roots = nullptr,
+           const unsigned long long* __restrict__ n_roots_dev = nullptr /* pfx_roots: how many there are (k_pfx_filter's count) */)
 {
-  // pfx_roots (round 4, query time, k > 12): the roots are not the loci but their PREFIX WALKS, enumerated once per index
-  // (ensure_pfx_roots): (12-mer, node, offset in the node's record, locus) -- where a walk from the locus stands after 12
-  // bases.  What every chunk did for every locus -- load the locus, load its node record, hop to the next node for the rest
-  // of the 12 bases -- is then a coalesced stream of 16-byte records, checked against the chunk's 12-mer map (L2-resident)
-  // while it is staged: only the third or so of the walks the map lets pass ever enters the walking loop.
+  // pfx_roots (query time, k > 12): the roots are not the loci but their PREFIX WALKS, enumerated once per index
+  // (ensure_pfx_roots): (prefix, node, offset in the node's record, locus) -- where a walk from the locus stands after
+  // min(k, 14) bases -- and of those only the ones that pass the chunk's two prefix maps (k_pfx_filter, round 5: a streaming
+  // kernel; in round 4 this kernel staged all of them and tested the 12-mer map itself, one memory latency per 64 roots
+  // and wave, and walked the survivors to 14 bases through the graph).  Every lane starts on a walk that matters.
   typedef TravItemT<KEY> TravItem;
   typedef DoneItemT<KEY> DoneItem;
   static_assert(!ENUM || sizeof(KEY) == 8, "the tables are made for one-word seeds");
@@ -144,7 +189,12 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   // roots: either fresh loci (spill_in == nullptr) or spilled partial walks
   const bool from_spill = spill_in != nullptr;
   const bool from_pfx = !ENUM && !from_spill && pfx_roots != nullptr;      // (n_loci then counts prefix walks)
-  const uint64_t n_roots = from_spill ? n_spill_in : n_loci;
+  uint64_t n_roots = from_spill ? n_spill_in : n_loci;
+  if (from_pfx && n_roots_dev) {
+    // the roots were counted on the device: this launch's share of them (whole rounds of 64)
+    n_roots = min((uint64_t)*n_roots_dev, n_loci);
+    loci_per_wave = (uint32_t)(((n_roots + gridDim.x - 1) / gridDim.x + 63) / 64 * 64);
+  }
   uint64_t cursor = (uint64_t)blockIdx.x * loci_per_wave;     // next root NOT yet requested from memory
   const uint64_t cend = min(n_roots, cursor + loci_per_wave);
   uint32_t top = 0, ndone = 0;            // wave-uniform
@@ -165,9 +215,8 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
       uint64_t rix = cursor + lane;
       if (from_spill) { pf = spill_in[rix]; pf_off = 0; }
       else if (from_pfx) {
-        const uint4 e = pfx_roots[rix];       // 12-mer, node, offset, locus
-        pf.kmer = (KEY)e.x | ((KEY)1 << (2 * PFX_SHORT)); pf.node = e.y; pf.locus = e.w; pf_off = e.z;
-        if (tb.pfx12) pf_keep = (tb.pfx12[e.x >> 5] >> (e.x & 31)) & 1u;
+        const uint4 e = pfx_roots[rix];       // prefix of tb.pfx_len bases, node, offset, locus (both prefix maps passed)
+        pf.kmer = (KEY)e.x | ((KEY)1 << (2 * tb.pfx_len)); pf.node = e.y; pf.locus = e.w; pf_off = e.z;
       }
       else { uint2 lc = loci[rix]; pf.kmer = 1; pf.node = lc.x; pf.locus = (uint32_t)rix; pf_off = lc.y; }
     }

@@ -105,6 +105,7 @@ struct DevCounters {
   PaddedCounter serial;          // the call's serial number, stored by the kernel that zeroes the counters: what comes back to the
                                  // host must carry the serial of THIS call (a stale hand-back is detected, not believed)
   PaddedCounter dbg0, dbg1;      // diagnostics (builds with -DTRAV_STATS)
+  PaddedCounter n_pfx_surv;      // k_pfx_filter: prefix walks of the starting loci that pass the chunk's prefix maps (k_traverse's roots)
   PaddedCounter ticket;          // k_kmer_step: the next tile to hand out (workgroups take tiles in the order they start)
   StripedCounter n_hits_on_s;    // ... its on-path hits, added per workgroup (the host adds them to n_hits_on)
   __host__ unsigned long long hits_on() const { return n_hits_on.v + n_hits_on_s.total(); }

@@ -307,10 +307,15 @@ int run( Options const& o, Logger& log )
     finder.set_expected_work( calls, seeds );
   }
   /* the first chunk of reads is parsed (into page-locked memory) while the index is loaded or made */
-  auto chunk = finder.create_readrecord();
+  /* two chunk buffers: while the device answers one chunk the next is parsed and packed into the other (round 5; the
+   * reference's loop loads, seeds, loads: src/psikt.cpp:190-208 -- parsing 1 M reads costs several device calls) */
+  auto chunk_a = finder.create_readrecord();
+  auto chunk_b = finder.create_readrecord();
+  auto* chunk_p = &chunk_a;
+  auto* next_p = &chunk_b;
   std::future< bool > first_chunk;
   if ( !o.indexonly )
-    first_chunk = std::async( std::launch::async, [ & ] { return readRecords( chunk, reads_iss, o.chunk_size ); } );
+    first_chunk = std::async( std::launch::async, [ & ] { return readRecords( chunk_a, reads_iss, o.chunk_size ); } );
   log.info( "Looking for an existing path index..." );
   auto t0 = std::chrono::steady_clock::now();
   if ( finder.load_path_index( o.pindex_path, o.context, o.step_size, o.dindex_min_ris, o.dindex_max_ris ) ) {
@@ -362,12 +367,21 @@ int run( Options const& o, Logger& log )
   log.info( "Finding seeds..." );
   auto t_all = std::chrono::steady_clock::now();
   double t_device = 0;
+  std::future< bool > next_chunk;      /* the chunk being read into *next_p while the device is busy */
   while ( true ) {
     log.info( "Loading a read chunk..." );
     auto t_load = std::chrono::steady_clock::now();
-    if ( !( first_chunk.valid() ? first_chunk.get() : readRecords( chunk, reads_iss, o.chunk_size ) ) ) break;
+    bool have;
+    if ( first_chunk.valid() ) have = first_chunk.get();
+    else if ( next_chunk.valid() ) { have = next_chunk.get(); std::swap( chunk_p, next_p ); }
+    else have = readRecords( *chunk_p, reads_iss, o.chunk_size );
+    if ( !have ) break;
+    auto& chunk = *chunk_p;
     log.info( "Fetched " + std::to_string( chunk.size() ) + " reads with total length of " +
               std::to_string( chunk.length_sum() ) + "bp in " + std::to_string( seconds_since( t_load ) ) + " s." );
+    /* (the reader is this thread's again only after the get() above: one thread at a time on the stream) */
+    if ( o.chunk_size != 0 )
+      next_chunk = std::async( std::launch::async, [ &, np = next_p ] { return readRecords( *np, reads_iss, o.chunk_size ); } );
     finder.get_seeds( seeds, chunk, o.distance );
     auto seeds_index = finder.index_reads( seeds );
     log.info( "Finding all seeds..." );

@@ -15,10 +15,12 @@
 #ifndef PSI_AMD_SEED_FINDER_HPP__
 #define PSI_AMD_SEED_FINDER_HPP__
 
+#include <cctype>
 #include <cstdint>
 #include <functional>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -332,17 +334,57 @@ namespace psi {
       return hits;
     }
 
+    /** The hits of one phase through the callback, with Seed::gocc as the reference sets it: on paths the number of
+     *  occurrences of the seed's k-mer in the path text (index_iter.hpp:743 -- length( occurrences1 ), from
+     *  psigpu_count_occurrences), off paths the number of read positions of the chunk that hold the k-mer
+     *  (traverser_bfs.hpp:107 -- length( saPositions ) of the reads index, counted here over the chunk's seeds).  Both
+     *  phases asked for at once: on paths first, then off paths, as seeds_all does (reference :1724-1732). */
     void run( SeedsRecord const& seeds, unsigned int flags, callback_type const& callback ) const
     {
+      if ( ( flags & PSIGPU_ALL ) == PSIGPU_ALL ) {
+        run( seeds, ( flags & ~PSIGPU_ALL ) | PSIGPU_ON_PATHS, callback );
+        run( seeds, ( flags & ~PSIGPU_ALL ) | PSIGPU_OFF_PATHS, callback );
+        return;
+      }
       psigpu_hits hits = find( seeds, flags );
+      if ( hits.n == 0 ) { psigpu_free_hits( &hits ); return; }
+      Records const& c = *seeds.chunk;
+      std::uint64_t const k = seeds.seed_len, d = seeds.distance;
+      /* first seed of every read (offsets 0, d, 2d ... while i < len - k + 1: sequence.hpp:1711-1714) */
+      std::vector< std::uint64_t > first( c.size() + 1, 0 );
+      for ( std::size_t r = 0; r < c.size(); ++r ) {
+        std::uint64_t const len = c.offsets[ r + 1 ] - c.offsets[ r ];
+        first[ r + 1 ] = first[ r ] + ( len >= k ? ( len - k ) / d + 1 : 0 );
+      }
+      std::vector< std::uint32_t > gocc( first.back(), 0 );
+      try {
+        if ( flags & PSIGPU_ON_PATHS ) {
+          if ( !gocc.empty() )
+            check( psigpu_count_occurrences( ctx, c.bases.data(), c.offsets.data(), c.size(), seeds.seed_len, seeds.distance,
+                                             gocc.data(), gocc.size() ) );
+        } else {
+          std::unordered_map< std::string, std::uint32_t > occ;
+          occ.reserve( gocc.size() * 2 );
+          auto kmer = [ & ]( std::size_t r, std::uint64_t j ) {
+            std::string s( c.bases.data() + c.offsets[ r ] + j * d, k );
+            for ( auto& ch : s ) ch = static_cast< char >( std::toupper( static_cast< unsigned char >( ch ) ) );
+            return s;
+          };
+          for ( std::size_t r = 0; r < c.size(); ++r )
+            for ( std::uint64_t j = 0; j < first[ r + 1 ] - first[ r ]; ++j ) ++occ[ kmer( r, j ) ];
+          for ( std::size_t r = 0; r < c.size(); ++r )
+            for ( std::uint64_t j = 0; j < first[ r + 1 ] - first[ r ]; ++j ) gocc[ first[ r ] + j ] = occ[ kmer( r, j ) ];
+        }
+      } catch ( ... ) { psigpu_free_hits( &hits ); throw; }
       output_type h{};
       h.match_len = seeds.seed_len;
-      h.gocc = 0;
       for ( std::uint64_t i = 0; i < hits.n; ++i ) {
         h.node_id = hits.data[ i ].node_id;
         h.node_offset = hits.data[ i ].node_offset;
         h.read_id = hits.data[ i ].read_id;
         h.read_offset = hits.data[ i ].read_offset;
+        std::uint64_t const r = h.read_id - c.get_record_offset();
+        h.gocc = gocc[ first[ r ] + h.read_offset / d ];
         callback( h );
       }
       psigpu_free_hits( &hits );

@@ -2197,3 +2197,72 @@ def test_one_kernel_step_equals_the_three_kernel_step(query_mode, k, step):
         ptr, n = f1.seeds_all_device_end()
         assert _eq(rows(f1.copy_hits(ptr, n)), rows(w))
     f1.close(); f1b.close(); f3.close()
+
+
+@pytest.mark.parametrize('k,step,npaths', [(21, 7, 2), (12, 1, 3), (31, 31, 1)])
+def test_header_api_callbacks_carry_gocc(query_mode, tmp_path, k, step, npaths):
+    """psi::SeedFinder::seeds_all with one callback per phase (reference seed_finder.hpp:1734-1743) through the C++ shim: the
+    records of both phases are the brute-force hit set, and every record carries Seed::gocc as the reference sets it -- on
+    paths the number of occurrences of the seed's k-mer in the indexed path text (index_iter.hpp:743, counted here on the
+    path sequences themselves, overlapping occurrences, not across paths), off paths the number of read positions of the
+    chunk that hold the k-mer (traverser_bfs.hpp:107).  psigpu_count_occurrences against the same count, seed by seed."""
+    import subprocess
+    from oracle import brute
+    if query_mode != 'kmer-table':
+        pytest.skip('the shim drives the default mode')
+    exe = str(tmp_path / 'seedfinder_api')
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'psi_amd', 'include'),
+                           os.path.join(ROOT, 'tests', 'cpp', 'seedfinder_api.cpp'), '-o', exe,
+                           '-L' + os.path.join(ROOT, 'psi_amd'), '-lpsi_gpu', '-lz', '-Wl,-rpath,' + os.path.join(ROOT, 'psi_amd')])
+    reads = brute.read_seqs(os.path.join(REF, 'reads_n1000l100e0i0.seq'))[:300]
+    reads = [r.upper() for r in reads] + [reads[0].upper(), reads[1][:60].upper()]           # (repeated k-mers among the chunk's seeds)
+    rf = tmp_path / 'reads.seq'
+    rf.write_text('\n'.join(reads) + '\n')
+    out = subprocess.check_output([exe, os.path.join(REF, 'x.gfa'), str(rf), str(k), str(npaths), str(step)]).decode().split('\n')
+    paths = [l.split(' ', 1)[1] for l in out if l.startswith('pathseq ')]
+    assert len(paths) == npaths
+    recs = [l.split() for l in out if l.startswith('on ') or l.startswith('off ')]
+    assert recs and all(int(r[5]) == k for r in recs)
+
+    def occurrences(text, pat):
+        n, at = 0, text.find(pat)
+        while at >= 0:
+            n, at = n + 1, text.find(pat, at + 1)
+        return n
+    in_reads = {}
+    for r in reads:
+        for j in range(0, len(r) - k + 1, step):
+            in_reads[r[j:j + k]] = in_reads.get(r[j:j + k], 0) + 1
+    on_cache = {}
+    n_on = n_off = 0
+    for phase, node, noff, rid, roff, _, gocc in recs:
+        km = reads[int(rid)][int(roff):int(roff) + k]
+        if phase == 'on':
+            if km not in on_cache:
+                on_cache[km] = sum(occurrences(p, km) for p in paths)
+            assert int(gocc) == on_cache[km] and on_cache[km] >= 1, (phase, node, noff, rid, roff, gocc)
+            n_on += 1
+        else:
+            assert int(gocc) == in_reads[km], (phase, node, noff, rid, roff, gocc)
+            n_off += 1
+    assert n_on and n_off
+    g = brute.parse_gfa(os.path.join(REF, 'x.gfa'))
+    want = brute.hit_set(g, reads, k, step)
+    got = sorted({(int(r[1]), int(r[2]), int(r[3]), int(r[4])) for r in recs})
+    assert got == want
+    # the count itself, seed by seed, through the C ABI (a finder over the same graph picks the same paths: same seed)
+    f = psi_amd.SeedFinder(_graph('x.gfa'), k)
+    f.create_path_index(npaths, rng_seed=0)
+    texts = []
+    gb = g
+    for p in f.pindex.paths():
+        texts.append(''.join(gb.seq[gb.ids[r]] for r in p.tolist()))
+    cnt = f.count_occurrences(reads, step=step)
+    at = 0
+    for r in reads:
+        for j in range(0, len(r) - k + 1, step):
+            km = r[j:j + k]
+            assert cnt[at] == (0 if 'N' in km else sum(occurrences(t, km) for t in texts)), (at, km)
+            at += 1
+    assert at == len(cnt)
+    f.close()

@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(L, name), name + ' is declared in include/psi_gpu.h but not exported'
     bound = {n for n, _, _ in psi_amd.ABI}
     assert declared == bound
-    assert L.psigpu_abi_version() == 6
+    assert L.psigpu_abi_version() == 7
 
 
 def test_no_gpu_means_loud_failure(ref_data):
@@ -45,6 +45,7 @@ def test_no_gpu_means_loud_failure(ref_data):
     assert L.psigpu_find_seeds_device_packed_begin(None, None, None, None, 0, 0, 10, 0, 0, psi_amd.ALL, None) == 1
     assert L.psigpu_find_seeds_device_end(None, C.byref(p), C.byref(n)) == 1
     assert L.psigpu_verify_resident(None, C.byref(n32), None, 0) == 1
+    assert L.psigpu_count_occurrences(None, None, None, 0, 10, 0, None, 0) == 1
 
 
 # ---------------------------------------------------------------------------------------

@@ -77,6 +77,10 @@ f.set_option('no_lookahead', 0)
 print(json.dumps({'label': 'alternated, 100 calls each', 'two_in_flight_median_ms': float(np.median(ab[0])), 'two_in_flight_min_ms': min(ab[0]),
                   'one_at_a_time_median_ms': float(np.median(ab[1])), 'one_at_a_time_min_ms': min(ab[1])}), flush=True)
 if os.environ.get('E2E_TRACE'):
-    os.environ['PSIGPU_TRACE'] = '1'
-    L.psigpu_find_seeds_packed(*calls[0]); L.psigpu_free_hits(C.byref(hits))
+    # PSIGPU_TRACE=2: the timeline of the default (two sub-batches in flight) path; =1: the synchronous loop's
+    for tr in ('2', '2', '1'):
+        os.environ['PSIGPU_TRACE'] = tr
+        t = time.perf_counter()
+        L.psigpu_find_seeds_packed(*calls[0]); L.psigpu_free_hits(C.byref(hits))
+        print('traced call (PSIGPU_TRACE=%s): %.3f ms' % (tr, (time.perf_counter() - t) * 1e3), file=sys.stderr, flush=True)
     del os.environ['PSIGPU_TRACE']
