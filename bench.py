@@ -1203,6 +1203,22 @@ def main():
                                  'note': 'steady state is the metric (index load excluded, SURVEY 8d); a finder that answers fewer '
                                          'chunks than this is better off in traverse mode: psigpu_set_query_mode( PSIGPU_MODE_AUTO )'}
 
+        # ---- psikt as a process on this configuration (tools/psikt_config1.py on the GPU box -> profiles/): the chunk loop a
+        # drop-in user runs (src/psikt.cpp:190-208), wall clock, beside the library calls above.  A recorded run, named as such.
+        pw_path = os.path.join(ROOT, 'profiles', '%s_psikt_config1.json' % PROFILE_ROUND)
+        if os.path.exists(pw_path) and args.reads == 1_000_000 and k == 21:
+            try:
+                pj = json.load(open(pw_path))
+                best = pj['runs'].get('index from file, 2nd run') or pj['runs'].get('patched, 2nd run') or {}
+                first = pj['runs'].get('patched (default)') or {}
+                out['psikt_wall'] = {'source': 'profiles/%s_psikt_config1.json (recorded run of tools/psikt_config1.py: 1 M-read FASTQ, GFA graph, '
+                                               'psikt -l 21 -n 1 -c 0)' % PROFILE_ROUND,
+                                     'find_seeds_s': best.get('find_s'), 'device_s': best.get('device_s'), 'load_reads_s': best.get('load_reads_s'),
+                                     'process_wall_s_index_from_file': best.get('wall_s'), 'process_wall_s_first_run': first.get('wall_s'),
+                                     'index_s_first_run': first.get('index_s'), 'hits': best.get('hits')}
+            except Exception as ex:
+                log('psikt wall record not readable (%s)' % ex)
+
         # ---- CPU baseline + parity gate -------------------------------------------------------------
         if args.cpu_reads != 0:
             import oracle

@@ -165,6 +165,32 @@ def main():
                             print(' again: product', g2.shape, 'oracle', w2.shape, 'oracle on one thread', w1.shape,
                                   '| first product run == second:', bool(gg.shape == g2.shape and (gg == g2).all()),
                                   '| first oracle run == one-thread run:', bool(wg.shape == w1.shape and (wg == w1).all()), flush=True)
+                            # (round 5) which INPUT of the side that is wrong has changed?  The oracle takes the graph arrays made above,
+                            # the reads, and paths / trims / loci from the finder's HOST index object; the product took the same loci
+                            # onto the device when the finder was made.
+                            arrays2 = (np.array(g.ids), np.cumsum([0] + [len(g.seq[v]) for v in g.ids]),
+                                       np.frombuffer(''.join(g.seq[v] for v in g.ids).encode(), np.uint8),
+                                       np.cumsum([0] + [len(g.out[v]) for v in g.ids]),
+                                       np.array([rank[t] for v in g.ids for t in g.out[v]], dtype=np.uint64))
+                            print(' graph arrays unchanged:', [bool(np.array_equal(np.asarray(a), np.asarray(b))) for a, b in zip(arrays, arrays2)], flush=True)
+                            pxh = psi_amd.PathIndex.build(pg, k, npaths, **dict(bargs, device=None))
+                            l1, l2 = px.loci, pxh.loci
+                            same = bool(np.array_equal(l1[0], l2[0]) and np.array_equal(l1[1], l2[1]))
+                            print(' loci of the index object == loci of a fresh host build:', same, len(l1[0]), len(l2[0]), flush=True)
+                            if not same and len(l1[0]) == len(l2[0]):
+                                d = np.flatnonzero((l1[0] != l2[0]) | (l1[1] != l2[1]))
+                                print('  differing loci (index, object, fresh):', [(int(i), (int(l1[0][i]), int(l1[1][i])), (int(l2[0][i]), int(l2[1][i]))) for i in d[:8]], flush=True)
+                            print(' paths of the index object == fresh:', [a.tolist() == b.tolist() for a, b in zip(px.paths(), pxh.paths())],
+                                  'trims', px.trims() == pxh.trims(), flush=True)
+                            if npaths == 0:
+                                print(' (no paths: both sides should equal the brute-force set) product == brute:', bool(gg.shape == want.shape and (gg == want).all()),
+                                      '| oracle == brute:', bool(wg.shape == want.shape and (wg == want).all()), flush=True)
+                            f9 = psi_amd.SeedFinder(pg, k, mode=mode, walk_cap=cap)
+                            f9.set_path_index(pxh)
+                            w9 = T._oracle_hits(arrays2, f9, rb, ro, k, step, gocc=thr)
+                            f9.set_gocc_threshold(thr)
+                            g9 = psi_amd.sort_unique(f9.seeds_all(reads, step=step))
+                            print(' with the fresh index and fresh arrays: product', g9.shape, 'oracle', w9.shape, flush=True)
                             sys.exit(1)
                         n_cases += 1
                     if cap == 0:
