@@ -221,7 +221,7 @@ def slim_line(out, full_path=None):
     line['config'] = {'workload': wl if len(wl) <= 420 else wl[:417] + '...'}
     for k_ in ('reads_per_gpu', 'read_len', 'k', 'seed_step', 'indexed_paths', 'nodes', 'text_len', 'starting_loci', 'sa_rate',
                'query_mode', 'seeds_per_step_per_gpu', 'hits_per_step_per_gpu', 'locus_kmers', 'path_kmers', 'table_build_ms',
-               'index_build_s', 'index_built_on', 'parallelism', 'whole_genome', 'record_order'):
+               'index_build_s', 'index_built_on', 'parallelism', 'whole_genome', 'record_order', 'shared_index_cached', 'shared_index_dir'):
         if k_ in cfg:
             line['config'][k_] = cfg[k_]
     rf = out.get('roofline') or {}

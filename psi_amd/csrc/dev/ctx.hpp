@@ -102,6 +102,8 @@ struct psigpu_ctx {
     static constexpr int IN_RING = 8;            // transfers of reads that may be queued ahead of the compute loop
     hsa_agent_t gpu{}, cpu{};
     uint32_t eng_in = 0, eng_out = 0;            // hsa_amd_sdma_engine_id_t bits
+    uint32_t eng_out2 = 0;                       // a second engine for the records' way out (0: none to spare): one engine moved
+                                                 // 34-37 GB/s of them beside the reads coming in, the link carries ~50 (round 5)
     hsa_signal_t sig_in[IN_RING]{}, sig_out[2]{};      // 1 while the transfer is in flight (two-slot path: sig_in[0..1])
     hsa_signal_t sig_fast[3]{};                        // ... the transfers out of the lookahead path's three slots
   } ec;
@@ -145,6 +147,9 @@ struct psigpu_ctx {
   bool opt_no_ahead = false, opt_no_engine_copy = false;
   uint32_t opt_wire = 0;           // 0: the narrowest wire record that fits; 8 / 16 / 32: nothing narrower
   uint32_t opt_wire8_roff_cap = 0; // test hook: at most this many read-offset bits in an 8-byte record
+  bool opt_no_numa = false;        // host entry: the library's threads anywhere (A/B; read when they are made)
+  bool opt_one_out_engine = false; // host entry: the records out on ONE copy engine (A/B; read when the pipeline is made)
+  uint32_t opt_widen_threads = 0;  // host entry: threads that widen the wire records (0: min(8, cores / 4)); read when the first call makes them
   bool opt_no_pfx_roots = false;   // traverse mode from the loci themselves (A/B, tests)
   bool opt_res16 = false;          // 16 bytes of probe results per seed (A/B, tests)
   uint64_t opt_expected_calls = 0; // PSIGPU_MODE_AUTO: chunks the caller expects to ask (0: unknown)

@@ -89,6 +89,48 @@ struct Worker {
   }
 };
 
+// The CPUs of the NUMA node the device hangs off (/sys/bus/pci/devices/<bdf>/numa_node, .../node<N>/cpulist): the
+// library's own threads -- they read what the copy engine just wrote into pinned memory next to the device and write the
+// caller's records -- stay there (round 5: the boxes have two nodes and a thread that lands on the far one does both
+// across the socket link).  Nothing is bound when anything about this cannot be read.
+struct NodeCpus {
+  cpu_set_t set; bool ok = false;
+  static NodeCpus of_device(int device)
+  {
+    NodeCpus nc; CPU_ZERO(&nc.set);
+    char bdf[64] = { 0 };
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return nc; }
+    for (char* c = bdf; *c; ++c) *c = (char)tolower((unsigned char)*c);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE* f = fopen(path, "r");
+    int node = -1;
+    if (f) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return nc;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return nc;
+    char list[1024] = { 0 };
+    const bool got = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!got) return nc;
+    cpu_set_t allowed; CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return nc;
+    int n = 0;
+    for (char* p = list; *p && *p != '\n';) {
+      char* e = nullptr;
+      long a = strtol(p, &e, 10), b = a;
+      if (e == p) break;
+      if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); if (e == p) break; }
+      for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, &nc.set); ++n; }
+      p = *e == ',' ? e + 1 : e;
+    }
+    nc.ok = n >= 2;
+    return nc;
+  }
+  void bind_this_thread() const { if (ok) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set); }
+};
+
 struct Widener {
   struct Job { const void* src; psigpu_hit* dst; uint64_t n, id_base, rec_base; int slot; WireFmt fmt; };
   // The threads live as long as the context (round 4: a call used to start and join up to eight threads of its own,
@@ -150,8 +192,17 @@ struct Widener {
     for (; checked < upto; ++checked)
       while (parts[checked].load(std::memory_order_acquire) < T) std::this_thread::yield();
   }
+  // the same question without waiting (the host entry's loop asks it while it has other things to look at)
+  bool finished(size_t upto)
+  {
+    for (; checked < upto; ++checked)
+      if (parts[checked].load(std::memory_order_acquire) < T) return false;
+    return true;
+  }
+  NodeCpus near;                                // where the threads run (set before the first begin())
   void loop(unsigned t)
   {
+    near.bind_this_thread();
     uint64_t seen = 0;
     for (;;) {
       {

@@ -61,8 +61,8 @@ k_pfx_compact(const ulonglong2* __restrict__ chunks, const uint32_t* __restrict_
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const ulonglong2 r = chunks[(uint64_t)c * CHUNK + i];
     out[dst0 + i] = make_uint4((uint32_t)r.x, (uint32_t)(r.x >> 32), (uint32_t)(r.y >> 32), (uint32_t)r.y);
-    keys[dst0 + i] = (uint32_t)r.y;
-    vals[dst0 + i] = (uint32_t)(dst0 + i);
+    keys[dst0 + i] = (uint32_t)r.x;              // ordered by the PREFIX (round 5; by locus in round 4): k_pfx_filter then reads the
+    vals[dst0 + i] = (uint32_t)(dst0 + i);       // chunk's prefix maps front to back instead of at 34 M random words per chunk
   }
 }
 

@@ -121,14 +121,20 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
 // collects what passes in LDS and appends it with one atomic per ~200 walks (one per round of 64 would be 400 k atomics
 // on one address: 11 ns each).  The order of the survivors is whatever the waves make it; the traverser's records have
 // no order either.
-constexpr uint32_t PF_BUF = 256;
+constexpr uint32_t PF_BUF = 512, PF_R = 4;
 __global__ void __launch_bounds__(256)
 k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, const uint32_t* __restrict__ pfx12, const uint32_t* __restrict__ pfx_bits,
              uint32_t depth, uint4* __restrict__ out, unsigned long long* n_out)
 {
+  // A wave owns a CONTIGUOUS range of the walks -- they come ordered by prefix, so its look-ups walk through the two maps
+  // front to back -- and takes it PF_R rounds of 64 at a time: the loads of all rounds are issued before the first is
+  // looked at (walk, 12-mer word, long-map word are three latencies in a row).
   __shared__ uint4 buf[4][PF_BUF];
   const uint32_t lane = lane_id(), wib = threadIdx.x >> 6;
   const uint32_t sh12 = 2 * (depth - PFX_SHORT);
+  const uint64_t n_waves = (uint64_t)gridDim.x * 4, wave = (uint64_t)blockIdx.x * 4 + wib;
+  const uint64_t per_wave = ((n + n_waves - 1) / n_waves + 63) / 64 * 64;
+  const uint64_t w0 = min(n, wave * per_wave), w1 = min(n, w0 + per_wave);
   uint32_t held = 0;                              // wave-uniform: walks in this wave's buffer
   auto flush = [&]() {
     unsigned long long at = 0;
@@ -138,23 +144,37 @@ k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, const uint32_t* __rest
     held = 0;
     __builtin_amdgcn_wave_barrier();
   };
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  for (uint64_t base = (uint64_t)blockIdx.x * 256 + wib * 64; base < n; base += stride) {
-    const uint64_t i = base + lane;
-    uint4 e = make_uint4(0, 0, 0, 0);
-    bool keep = false;
-    if (i < n) {
-      e = roots[i];
-      const uint32_t p12 = e.x >> sh12;
-      keep = (pfx12[p12 >> 5] >> (p12 & 31)) & 1u;
-      if (keep) keep = (pfx_bits[e.x >> 5] >> (e.x & 31)) & 1u;
+  for (uint64_t base = w0; base < w1; base += 64 * PF_R) {
+    uint4 e[PF_R];
+    uint32_t w12[PF_R], w14[PF_R];
+    bool in[PF_R];
+#pragma unroll
+    for (uint32_t r = 0; r < PF_R; ++r) {
+      const uint64_t i = base + 64 * r + lane;
+      in[r] = i < w1;
+      e[r] = roots[in[r] ? i : w1 - 1];           // (a lane past the end repeats the last walk and drops the answer)
     }
-    const uint64_t km = __ballot(keep);
-    if (km) {
-      if (keep) buf[wib][held + (uint32_t)__popcll(km & lanemask_lt())] = e;
-      held += (uint32_t)__popcll(km);
-      __builtin_amdgcn_wave_barrier();
-      if (held > PF_BUF - 64) flush();
+#pragma unroll
+    for (uint32_t r = 0; r < PF_R; ++r) { const uint32_t p12 = e[r].x >> sh12; w12[r] = pfx12[p12 >> 5]; }
+    // (the long map only for walks the short one lets pass -- two thirds do not, and theirs would be random words of a 32-MiB
+    // map -- but with no branch around the load: the others fetch word 0, one line for the whole wave)
+    bool pass[PF_R];
+#pragma unroll
+    for (uint32_t r = 0; r < PF_R; ++r) {
+      const uint32_t p12 = e[r].x >> sh12;
+      pass[r] = in[r] && ((w12[r] >> (p12 & 31)) & 1u);
+      w14[r] = pfx_bits[pass[r] ? e[r].x >> 5 : 0u];
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < PF_R; ++r) {
+      const bool keep = pass[r] && ((w14[r] >> (e[r].x & 31)) & 1u);
+      const uint64_t km = __ballot(keep);
+      if (km) {
+        if (keep) buf[wib][held + (uint32_t)__popcll(km & lanemask_lt())] = e[r];
+        held += (uint32_t)__popcll(km);
+        __builtin_amdgcn_wave_barrier();
+        if (held > PF_BUF - 64) flush();
+      }
     }
   }
   if (held) flush();
@@ -195,7 +215,8 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
     n_roots = min((uint64_t)*n_roots_dev, n_loci);
     loci_per_wave = (uint32_t)(((n_roots + gridDim.x - 1) / gridDim.x + 63) / 64 * 64);
   }
-  uint64_t cursor = (uint64_t)blockIdx.x * loci_per_wave;     // next root NOT yet requested from memory
+  uint64_t cursor = min(n_roots, (uint64_t)blockIdx.x * loci_per_wave);     // next root NOT yet requested from memory (a launch sized
+                                                                            // for more roots than the device counted: nothing for this wave)
   const uint64_t cend = min(n_roots, cursor + loci_per_wave);
   uint32_t top = 0, ndone = 0;            // wave-uniform
   uint32_t rb_pos = 0, rb_cnt = 0;        // wave-uniform: staged roots [rb_pos, rb_cnt) are unread
@@ -226,8 +247,8 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   // graphs whose ranks follow the topology, as vg's do) so are the nodes the walks hop to: stage
   // that rank window in LDS once, coalesced; anything outside is read from memory.
   uint32_t wb = 0, win_n = 0;             // first rank / size of the window (none for spill launches)
-  if (!from_spill && cursor < cend) {
-    wb = from_pfx ? pfx_roots[cursor].y : loci[cursor].x;
+  if (!from_spill && !from_pfx && cursor < cend) {      // (prefix walks come ordered by prefix: their nodes are anywhere)
+    wb = loci[cursor].x;
     win_n = TRAV_WIN;
     for (uint32_t i = lane; i < TRAV_WIN; i += 64) {
       NodeLite z = { 0, NIL, LITE_SLOW };

@@ -34,7 +34,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <cctype>
 #include <execinfo.h>
+#include <pthread.h>
+#include <sched.h>
 #include <memory>
 #include <signal.h>
 #include <sys/syscall.h>

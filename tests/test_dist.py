@@ -87,14 +87,18 @@ def test_bench_two_ranks_whole_genome_path_at_reduced_size(tmp_path):
     import json
     env = {'PSI_BENCH_BACKEND': 'gloo', 'PSI_BENCH_SHARE_DIR': str(tmp_path)}
     cmd = [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--wg', 'force',
-           '--wg-backbone', '3000000', '--wg-snvs', '60000', '--wg-nblock', '200000', '--wg-reads', '20000']
+           '--wg-backbone', '3000000', '--wg-snvs', '60000', '--wg-nblock', '200000', '--wg-reads', '20000',
+           '--full-out', str(tmp_path / 'full.json')]
     for cached in (False, True):
         p = _run_two_ranks(cmd, env)
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
         lines = [l for l in p.stdout.split('\n') if l.startswith('{')]
-        assert len(lines) == 1
-        j = json.loads(lines[0])
-        assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
+        assert len(lines) == 1 and len(lines[0]) < 6100           # (the line the driver parses: small, round 5)
+        line = json.loads(lines[0])
+        assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['roofline'] and 'cpu_baseline' in line
+        assert line['config']['whole_genome'] is True and line['multi_gpu']['n_ranks'] == 2 and line['value_end_to_end'] > 0
+        j = json.load(open(tmp_path / 'full.json'))               # ... and the full report beside it
+        assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] == pytest.approx(line['value'], rel=1e-4)
         c = j['config']
         assert c['whole_genome'] is True and 'configs[3]' in c['workload'] and c['shared_index_cached'] is cached
         assert c['seeds_per_step_per_gpu'] == 140000 and c['reads_per_gpu'] == 20000

@@ -751,7 +751,8 @@ def test_query_modes_agree_at_full_size(query_mode):
         c = f.counters()
         assert c['n_seeds'] == 7_000_000
         assert (c['n_path_kmers'] > 0) == (mode != 'locus-table')      # (traverse mode: the paths' k-mers, not the loci's)
-        assert (c['n_loci_traversed'] > 0) == (mode == 'traverse')
+        # (a walk cap of 1 leaves nearly every locus -- any that is uncovered has a second walk -- to the traverser in the table modes too)
+        assert (c['n_loci_traversed'] > 0) == (mode == 'traverse' or query_mode.endswith('cap1'))
         f.close()
     assert _eq(res['kmer-table'], res['traverse']) and _eq(res['locus-table'], res['traverse'])
     hits = res['traverse']

@@ -18,6 +18,12 @@ sg = synth.snv_graph(51_000_000, 1_100_000, n_block=11_000_000, seed=11)
 g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path])
 px = psi_amd.PathIndex.build(g, 21, 1, rng_seed=1, device=0)
 f = psi_amd.SeedFinder(g, 21, device=0)
+if os.environ.get('E2E_NO_NUMA'):
+    f.set_option('no_numa', 1)
+if os.environ.get('E2E_ONE_OUT_ENGINE'):
+    f.set_option('one_out_engine', 1)
+if os.environ.get('E2E_WIDEN_THREADS'):
+    f.set_option('widen_threads', int(os.environ['E2E_WIDEN_THREADS']))
 f.set_path_index(px)
 f.prepare()
 batches = [synth.sim_reads_snv(sg, 1_000_000, 150, seed=13 + 100 * b) for b in range(2)]
@@ -48,11 +54,11 @@ def run(label, reps=15):
     print(json.dumps(r), flush=True)
 
 
-for mb in (4, 8, 16, 32, 64, 160):
+for mb in (() if os.environ.get('E2E_QUICK') else (4, 8, 16, 32, 64, 160)):
     f.set_option('sub_bytes', mb << 20)
     run('sub %d Mi bases' % mb)
 f.set_option('sub_bytes', 0)
-for w in (16, 32):
+for w in (() if os.environ.get('E2E_QUICK') else (16, 32)):
     f.set_option('wire', w)
     run('wire %d' % w)
 f.set_option('wire', 0)
