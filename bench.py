@@ -355,7 +355,11 @@ def wg_decide(args, world):
                 avail = int(ln.split()[1]) * 1024
     except OSError:
         pass
-    tag = 'psi_bench_wg_%d_%d_%d_k%d_p%d' % (plan['backbone'], plan['snvs'], plan['nblock'], args.k, args.paths)
+    # (everything that changes the exported arrays is in the name: a later run with another --sa-rate / --ftab / builder, or of
+    # another round's layout, must not map an older directory -- round-4 advisor.  The directory is kept so that the
+    # driver's N = 2, 4, 8 runs build it once; its path and size are logged when it is made.)
+    tag = 'psi_bench_wg_abi%d_%d_%d_%d_k%d_p%d_s%d_f%d_%s' % (7, plan['backbone'], plan['snvs'], plan['nblock'], args.k, args.paths,
+                                                            args.sa_rate, args.ftab, 'host' if args.host_build else 'dev')
     where = None
     for base in [os.environ.get('PSI_BENCH_SHARE_DIR'), '/dev/shm', os.environ.get('TMPDIR'), '/tmp']:
         if not base or not os.path.isdir(base):
@@ -406,6 +410,11 @@ def wg_build_and_export(plan, args, local_rank):
     t0 = time.time()
     shared.export_views(plan['dir'], g, px, extra={'n_block': n_block, 'index_build_s': t['index_build_s'], 'graph_s': t['graph_s']})
     t['export_s'] = time.time() - t0
+    try:
+        size = sum(os.path.getsize(os.path.join(plan['dir'], f)) for f in os.listdir(plan['dir']))
+        log('shared index written to %s (%.1f GB, kept for the next run of this workload: remove it by hand when done)' % (plan['dir'], size / 1e9))
+    except OSError:
+        pass
     del px, g
     import gc
     gc.collect()

@@ -121,7 +121,7 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
 // collects what passes in LDS and appends it with one atomic per ~200 walks (one per round of 64 would be 400 k atomics
 // on one address: 11 ns each).  The order of the survivors is whatever the waves make it; the traverser's records have
 // no order either.
-constexpr uint32_t PF_BUF = 512, PF_R = 4;
+constexpr uint32_t PF_BUF = 256, PF_R = 8;      // (16 KB of LDS per workgroup: eight workgroups per CU; eight rounds per latency chain)
 __global__ void __launch_bounds__(256)
 k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, const uint32_t* __restrict__ pfx12, const uint32_t* __restrict__ pfx_bits,
              uint32_t depth, uint4* __restrict__ out, unsigned long long* n_out)
@@ -154,6 +154,10 @@ k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, const uint32_t* __rest
       in[r] = i < w1;
       e[r] = roots[in[r] ? i : w1 - 1];           // (a lane past the end repeats the last walk and drops the answer)
     }
+    // (whole 16-byte loads: left alone the compiler fetches the prefix word now and the other three words later, behind the
+    // branch that keeps a walk -- one more memory latency per round, eight in a row per iteration: 0.37 ms for this kernel)
+#pragma unroll
+    for (uint32_t r = 0; r < PF_R; ++r) keep_whole(e[r]);
 #pragma unroll
     for (uint32_t r = 0; r < PF_R; ++r) { const uint32_t p12 = e[r].x >> sh12; w12[r] = pfx12[p12 >> 5]; }
     // (the long map only for walks the short one lets pass -- two thirds do not, and theirs would be random words of a 32-MiB
@@ -170,18 +174,18 @@ k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, const uint32_t* __rest
       const bool keep = pass[r] && ((w14[r] >> (e[r].x & 31)) & 1u);
       const uint64_t km = __ballot(keep);
       if (km) {
+        if (held + (uint32_t)__popcll(km) > PF_BUF) flush();
         if (keep) buf[wib][held + (uint32_t)__popcll(km & lanemask_lt())] = e[r];
         held += (uint32_t)__popcll(km);
         __builtin_amdgcn_wave_barrier();
-        if (held > PF_BUF - 64) flush();
       }
     }
   }
   if (held) flush();
 }
 
-template <bool ENUM, typename KEY = uint64_t>
-__global__ void __launch_bounds__(64)
+template <bool ENUM, typename KEY = uint64_t, bool WINDOW = true>      // (WINDOW false: roots that are not in node order -- the filtered
+__global__ void __launch_bounds__(64)                                 // prefix walks; 4 KB of LDS less per wave = 30 waves per CU, not 17)
 k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node rank, offset) */,
            uint64_t n_loci, uint32_t loci_per_wave,
            const TravItemT<KEY>* __restrict__ spill_in, uint64_t n_spill_in,
@@ -202,7 +206,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   __shared__ DoneItem doneq[DONE_CAP];
   __shared__ TravItem rootbuf[64];        // staged roots and their start offsets
   __shared__ uint32_t rootoff[64];
-  __shared__ NodeLite window[TRAV_WIN];   // node records of the ranks this wave's loci start in
+  __shared__ NodeLite window[WINDOW ? TRAV_WIN : 1];   // node records of the ranks this wave's loci start in
   ChunkWriter cw = { chunks, chunk_fill, cap_chunks, NIL, 0 };
   PairWriter pw = { NIL, 0 };
   const uint32_t lane = lane_id();
@@ -247,7 +251,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   // graphs whose ranks follow the topology, as vg's do) so are the nodes the walks hop to: stage
   // that rank window in LDS once, coalesced; anything outside is read from memory.
   uint32_t wb = 0, win_n = 0;             // first rank / size of the window (none for spill launches)
-  if (!from_spill && !from_pfx && cursor < cend) {      // (prefix walks come ordered by prefix: their nodes are anywhere)
+  if (WINDOW && !from_spill && !from_pfx && cursor < cend) {      // (prefix walks come ordered by prefix: their nodes are anywhere)
     wb = loci[cursor].x;
     win_n = TRAV_WIN;
     for (uint32_t i = lane; i < TRAV_WIN; i += 64) {
@@ -296,7 +300,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
     if (have) {
       uint32_t widx = it.node - wb;                                     // wraps above the window
       uint4 nlw;                                                        // (one 16-byte read from either place)
-      if (widx < win_n) nlw = *reinterpret_cast<const uint4*>(&window[widx]); else nlw = *reinterpret_cast<const uint4*>(&g.lite[it.node]);
+      if (WINDOW && widx < win_n) nlw = *reinterpret_cast<const uint4*>(&window[widx]); else nlw = *reinterpret_cast<const uint4*>(&g.lite[it.node]);
       keep_whole(nlw);
       NodeLite nl = { (uint64_t)nlw.x | ((uint64_t)nlw.y << 32), nlw.z, nlw.w };
       uint32_t depth = hibit(it.kmer) >> 1;

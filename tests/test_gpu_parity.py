@@ -12,6 +12,7 @@ from psi_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 REF = os.path.join(GOLDEN, 'ref_data')
 
@@ -1592,7 +1593,20 @@ def test_host_entry_with_two_sub_batches_in_flight(query_mode):
     rp = (psi_amd.pinned_copy(rag), psi_amd.pinned_copy(roff))
     w2 = f.seeds_all((rag, roff), step=k, sort_unique=True)
     assert _eq(f.seeds_all((rp[0].array, rp[1].array), step=k, sort_unique=True, uniform=True), w2)
+    f_px = f.pindex
     f.close()
+    # the host-side arrangement of round 5 switched off piece by piece (options read when the pipeline / its threads are made):
+    # the records out on one copy engine, the library's threads wherever the scheduler puts them, three widening threads
+    for opts in ((('one_out_engine', 1),), (('no_numa', 1), ('widen_threads', 3)), (('sub_bytes', 3_000_000),)):
+        f = psi_amd.SeedFinder(g, k)
+        f.set_path_index(f_px)
+        f.set_option('sub_bytes', 60_000)
+        for n_, v_ in opts:
+            f.set_option(n_, v_)
+        for _ in range(2):
+            assert _eq(f.seeds_all(src, step=k, rec_offset=11, sort_unique=True), want)
+            assert _eq(f.seeds_all_packed(pk, step=k, rec_offset=11, sort_unique=True), want)
+        f.close()
     # duplicates (four full copies of each path): ordering a seed's hits in place is not enough -> the general sort
     f = psi_amd.SeedFinder(g, k, mode='locus-table')
     f.create_path_index(4, rng_seed=2)
@@ -2200,7 +2214,7 @@ def test_one_kernel_step_equals_the_three_kernel_step(query_mode, k, step):
     f1.close(); f1b.close(); f3.close()
 
 
-@pytest.mark.parametrize('k,step,npaths', [(21, 7, 2), (12, 1, 3), (31, 31, 1)])
+@pytest.mark.parametrize('k,step,npaths', [(21, 7, 2), (12, 1, 3), (31, 31, 1), (40, 13, 2)])
 def test_header_api_callbacks_carry_gocc(query_mode, tmp_path, k, step, npaths):
     """psi::SeedFinder::seeds_all with one callback per phase (reference seed_finder.hpp:1734-1743) through the C++ shim: the
     records of both phases are the brute-force hit set, and every record carries Seed::gocc as the reference sets it -- on
