@@ -54,6 +54,28 @@ def main():
                          device=rng.choice([None, 0]), patched=patched,
                          context=rng.choice([0, k, k + 1, k + 7]) if patched else 0)
             px = psi_amd.PathIndex.build(pg, k, npaths, **bargs)
+            # (round 5) canaries: what the HOST holds of this index and of the inputs, as it is now -- compared again after every
+            # finder run below.  The oracle-side disagreements of rounds 4-5 say that something a loaded process holds in host
+            # memory changes under it; if it does, what the new bytes look like says who wrote them.
+            canary = {'loci_node': px.loci[0], 'loci_off': px.loci[1], 'paths': [p.copy() for p in px.paths()],
+                      'labels': np.frombuffer(labels, np.uint8).copy(), 'edge_to': np.array(edge_to, dtype=np.uint64),
+                      'reads': np.frombuffer(''.join(reads).encode(), np.uint8).copy()}
+
+            def check_canaries(where):
+                now = {'loci_node': px.loci[0], 'loci_off': px.loci[1], 'paths': [p for p in px.paths()],
+                       'labels': np.frombuffer(labels, np.uint8), 'edge_to': np.array(edge_to, dtype=np.uint64),
+                       'reads': np.frombuffer(''.join(reads).encode(), np.uint8)}
+                for name, was in canary.items():
+                    cur = now[name]
+                    pairs = list(zip(was, cur)) if name == 'paths' else [(was, cur)]
+                    for a_, b_ in pairs:
+                        if a_.shape != b_.shape or not np.array_equal(a_, b_):
+                            d = np.flatnonzero(a_ != b_) if a_.shape == b_.shape else np.zeros(0, np.int64)
+                            print('HOST CANARY CHANGED', seed, where, name, 'shape', a_.shape, b_.shape, 'first differing indices', d[:12].tolist(),
+                                  'was', a_[d[:12]].tolist() if len(d) else None, 'is', b_[d[:12]].tolist() if len(d) else None,
+                                  'bytes around the first (is):', b_.view(np.uint8)[max(0, int(d[0]) * b_.itemsize - 32):int(d[0]) * b_.itemsize + 64].tobytes().hex() if len(d) else None,
+                                  flush=True)
+                            sys.exit(1)
             # starting loci = brute-force definition over the trimmed paths (acyclic graphs only: the
             # brute force lists walks, the product's candidate sets handle repeats on their own)
             paths_ids = [[g.ids[r] for r in p] for p in px.paths()]
@@ -226,6 +248,7 @@ def main():
                             sys.exit(1)
                         f2.close()
                     f.close()
+                    check_canaries('after mode %s cap %d' % (mode, cap))
                     n_cases += 1
         if (seed - first) % 25 == 24:
             print('.. through seed %d, %d finder runs' % (seed, n_cases), flush=True)
