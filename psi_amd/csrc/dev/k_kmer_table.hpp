@@ -353,15 +353,31 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
   const uint64_t s0 = wave * per_wave, s1 = min(n_seeds, s0 + per_wave);
   uint64_t wsum = 0, osum = 0;
   uint32_t n_live = 0;
-  for (uint64_t base = s0; base < s1; base += 64) {
-    const uint64_t seed = base + lane;
-    if (seed >= s1) continue;
-    const uint64_t key = seed_key[seed];
-    uint4 res = make_uint4(0, 0, 0, 0);
-    if (key != KEY_INVALID) {
-      const uint64_t h = kt_home(key, kt.n_slots);
-      res = kt_resolve(kt, key, h, load16(kt.ht + h), want_on, want_off, gocc_thr);
+  // (KP_R rounds per iteration, round 5: the keys of all rounds, then their slots, each group in one block -- k_kmer_step's
+  // lesson; one round at a time this kernel had one probe per lane in flight)
+  constexpr uint32_t KP_R = 4;
+  for (uint64_t base0 = s0; base0 < s1; base0 += 64 * KP_R) {
+    uint64_t keys[KP_R], hs[KP_R];
+    uint4 vs[KP_R];
+#pragma unroll
+    for (uint32_t rr = 0; rr < KP_R; ++rr) {
+      const uint64_t sd = base0 + 64 * rr + lane;
+      keys[rr] = seed_key[sd < s1 ? sd : s0];
     }
+#pragma unroll
+    for (uint32_t rr = 0; rr < KP_R; ++rr) {
+      if (base0 + 64 * rr + lane >= s1) keys[rr] = KEY_INVALID;
+      hs[rr] = keys[rr] != KEY_INVALID ? kt_home(keys[rr], kt.n_slots) : 0ull;      // (a seed with an N loads slot 0: no branch between the loads)
+      vs[rr] = *reinterpret_cast<const uint4*>(kt.ht + hs[rr]);
+    }
+#pragma unroll
+    for (uint32_t rr = 0; rr < KP_R; ++rr) {
+    const uint64_t seed = base0 + 64 * rr + lane;
+    if (seed >= s1) continue;
+    const uint64_t key = keys[rr];
+    keep_whole(vs[rr]);
+    uint4 res = make_uint4(0, 0, 0, 0);
+    if (key != KEY_INVALID) res = kt_resolve(kt, key, hs[rr], vs[rr], want_on, want_off, gocc_thr);
     if constexpr (R8) {
       uint64_t r8 = (uint64_t)res.x;
       if (res.z & RES_EXT) r8 |= R8_EXT;
@@ -372,6 +388,7 @@ k_kmer_probe(KmerTableView kt, const uint64_t* __restrict__ seed_key, const uint
     const uint32_t con = res.z & RES_CNT, coff = res.w & ~RES_INLINE;
     wsum += con; osum += coff;
     n_live += con != 0;
+    }
   }
   for (int d = 32; d > 0; d >>= 1) {
     wsum += __shfl_down(wsum, d); osum += __shfl_down(osum, d); n_live += __shfl_down(n_live, d);
@@ -485,74 +502,115 @@ k_fm_search_direct(FMView fm, const FtabX* __restrict__ ftabx, LktView lk, const
   const uint64_t wmask = rem ? (1ull << (2 * rem)) - 1ull : 0ull;
   uint32_t n_live = 0, n_rows = 0;
   uint64_t wsum = 0, osum = 0;
-  for (uint64_t base = s0; base < s1; base += 64) {
-    const uint64_t seed = base + lane;
-    const bool in = seed < s1;
-    const uint64_t key = in ? seed_key[seed] : KEY_INVALID;
-    const bool valid = key != KEY_INVALID;
-    TableSlot sl = { KEY_INVALID, 0, 0 };
-    uint64_t h = 0;
-    const bool probing = lk.ht != nullptr && valid;
-    if (probing) { h = lkt_home(key, lk.n_slots); sl = lk.ht[h]; }
-    uint32_t l = 0, r = 0;
-    SaRec first = { 0, 0, 0 };                  // row l's record, when the interval table carries it
-    if (valid) {
-      if (ftabx) {
-        const uint4* e = reinterpret_cast<const uint4*>(ftabx + (key & qmask));
-        const uint4 a = e[0], b = e[1];           // (one sector)
-        l = a.x; r = a.y; first.node = a.z; first.noff = a.w; first.ctx = (uint64_t)b.x | ((uint64_t)b.y << 32);
-      } else { uint2 iv = fm.ftab[key & qmask]; l = iv.x; r = iv.y; }
-    }
-    uint32_t cnt = r > l ? r - l : 0u, aux = 0, on_node = 0, on_noff = 0;
-    const bool deferred = rem != 0 && cnt > VERIFY_ROWS;
-    if (rem != 0 && cnt != 0 && !deferred) {
-      // the rem bases in front of each row against the head of the seed, rows four at a time; the
-      // first matching row's record also gives K2 the hit itself
-      const uint64_t want = key >> (2 * q);
-      uint32_t mask = 0;
-      for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {
-        SaRec c[4];
+  // FD_R rounds of 64 seeds per iteration (round 5): the keys of all rounds, then their interval-table entries and table
+  // probes, then the second rows' records are each issued together -- one round at a time the kernel spent a memory
+  // latency per load and round (key -> entry -> row), with one seed per lane in flight.
+  constexpr uint32_t FD_R = 4;
+  const bool have_lk = lk.ht != nullptr;
+  for (uint64_t base = s0; base < s1; base += 64 * FD_R) {
+    uint64_t key[FD_R];
+    bool in[FD_R];
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-          c[j] = SaRec{ 0, 0, 0 };
-          if (t0 + j < cnt) {
-            if (ftabx && t0 + j == 0) { c[j] = first; continue; }
-            uint4 v = *reinterpret_cast<const uint4*>(&fm.sarec[l + t0 + j]);
-            c[j].node = v.x; c[j].noff = v.y; c[j].ctx = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    for (uint32_t rr = 0; rr < FD_R; ++rr) {
+      const uint64_t seed = base + 64 * rr + lane;
+      in[rr] = seed < s1;
+      key[rr] = seed_key[in[rr] ? seed : s0];      // (a lane past the end reads the wave's first key and drops the answer)
+    }
+#pragma unroll
+    for (uint32_t rr = 0; rr < FD_R; ++rr) if (!in[rr]) key[rr] = KEY_INVALID;
+    uint64_t h[FD_R];
+    uint4 slw[FD_R], ea[FD_R];
+    uint2 eb[FD_R];
+    // (no branch around a load, not even a wave-uniform one: a block that ends behind a load ends in a wait for it.  A finder
+    // without a locus table probes the key array instead, and drops what it gets)
+    const uint4* const lk_base = have_lk ? reinterpret_cast<const uint4*>(lk.ht) : reinterpret_cast<const uint4*>(seed_key);
+    const char* const ft_base = ftabx ? reinterpret_cast<const char*>(ftabx) : reinterpret_cast<const char*>(fm.ftab);
+    const uint32_t ft_shift = ftabx ? 5u : 3u;      // 32-byte entries with the first row's record, or 8-byte intervals
+#pragma unroll
+    for (uint32_t rr = 0; rr < FD_R; ++rr) {
+      const bool valid = key[rr] != KEY_INVALID;
+      h[rr] = (have_lk && valid) ? lkt_home(key[rr], lk.n_slots) : 0ull;
+      slw[rr] = lk_base[h[rr]];
+      const char* e = ft_base + ((valid ? (key[rr] & qmask) : 0ull) << ft_shift);
+      __builtin_memcpy(&ea[rr], e, 16);             // l, r, first row's node and offset (or l, r and the next entry's)
+      __builtin_memcpy(&eb[rr], e + 16, 8);         // its context (or the entry after that: dropped)
+    }
+#pragma unroll
+    for (uint32_t rr = 0; rr < FD_R; ++rr) {
+      if (!have_lk) slw[rr] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
+      if (!ftabx) { ea[rr].z = ea[rr].w = 0; eb[rr] = make_uint2(0, 0); }
+    }
+    // the second row of every interval that has one (1.45 rows on average): its record, before any round is looked at
+    uint4 row1[FD_R];
+#pragma unroll
+    for (uint32_t rr = 0; rr < FD_R; ++rr) {
+      const bool valid = key[rr] != KEY_INVALID;
+      const uint32_t l_ = ea[rr].x, r_ = ea[rr].y;
+      const uint32_t cnt_ = (valid && r_ > l_) ? r_ - l_ : 0u;
+      const bool want1 = rem != 0 && cnt_ >= 2 && cnt_ <= VERIFY_ROWS;
+      row1[rr] = *reinterpret_cast<const uint4*>(&fm.sarec[want1 ? l_ + 1 : 0u]);
+    }
+#pragma unroll
+    for (uint32_t rr = 0; rr < FD_R; ++rr) {
+      const uint64_t seed = base + 64 * rr + lane;
+      const bool valid = key[rr] != KEY_INVALID;
+      const uint32_t l = valid ? ea[rr].x : 0u, r = valid ? ea[rr].y : 0u;
+      SaRec first = { ea[rr].z, ea[rr].w, (uint64_t)eb[rr].x | ((uint64_t)eb[rr].y << 32) };      // row l's record, when the interval table carries it
+      uint32_t cnt = r > l ? r - l : 0u, aux = 0, on_node = 0, on_noff = 0;
+      const bool deferred = rem != 0 && cnt > VERIFY_ROWS;
+      if (rem != 0 && cnt != 0 && !deferred) {
+        // the rem bases in front of each row against the head of the seed, rows four at a time; the
+        // first matching row's record also gives K2 the hit itself
+        const uint64_t want = key[rr] >> (2 * q);
+        uint32_t mask = 0;
+        for (uint32_t t0 = 0; t0 < cnt; t0 += 4) {
+          SaRec c[4];
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) {
+            c[j] = SaRec{ 0, 0, 0 };
+            if (t0 + j < cnt) {
+              if (ftabx && t0 + j == 0) { c[j] = first; continue; }
+              uint4 v = row1[rr];
+              if (t0 + j != 1) v = *reinterpret_cast<const uint4*>(&fm.sarec[l + t0 + j]);
+              c[j].node = v.x; c[j].noff = v.y; c[j].ctx = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            }
           }
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j)
+            if (t0 + j < cnt && (c[j].ctx >> 58) >= rem && (c[j].ctx & wmask) == want) {
+              if (mask == 0) { on_node = c[j].node; on_noff = c[j].noff; aux = AUX_RESOLVED; }
+              mask |= 1u << (t0 + j);
+            }
         }
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j)
-          if (t0 + j < cnt && (c[j].ctx >> 58) >= rem && (c[j].ctx & wmask) == want) {
-            if (mask == 0) { on_node = c[j].node; on_noff = c[j].noff; aux = AUX_RESOLVED; }
-            mask |= 1u << (t0 + j);
-          }
+        n_rows += cnt;
+        cnt = (uint32_t)__popc(mask);
+        aux |= (rem << 8) | mask;
       }
-      n_rows += cnt;
-      cnt = (uint32_t)__popc(mask);
-      aux |= (rem << 8) | mask;
-    }
-    // the locus k-mer table: the first probe is back by now; collisions are rare
-    uint32_t ofirst = 0, ocnt = 0, onoff = 0;
-    if (probing) lkt_resolve(lk, key, h, sl, ofirst, ocnt, onoff);
-    const bool keep = !deferred && cnt != 0 && cnt <= gocc_thr;
-    if (in) {
-      so.iv_lo[seed] = l;
-      so.iv_cnt[seed] = keep ? cnt : 0u;
-      so.iv_aux[seed] = aux;
-      so.on_node[seed] = on_node;
-      so.on_noff[seed] = on_noff;
-      if (lk.ht != nullptr) { so.off_first[seed] = ofirst; so.off_cnt[seed] = ocnt; so.off_noff[seed] = onoff; }
-      n_live += keep;
-      wsum += keep ? cnt : 0u;
-      osum += ocnt & ~OFF_INLINE;
-    }
-    uint64_t dm = __ballot(deferred);
-    if (dm) {
-      unsigned long long at = 0;
-      if (lane == 0) at = atomicAdd(&ctr->n_defer.v, (unsigned long long)__popcll(dm));
-      at = __shfl(at, 0);
-      if (deferred) defer[at + __popcll(dm & lanemask_lt())] = (uint32_t)seed;
+      // the locus k-mer table: the first probe is back by now; collisions are rare
+      uint32_t ofirst = 0, ocnt = 0, onoff = 0;
+      if (have_lk && valid) {
+        const TableSlot sl = { (unsigned long long)slw[rr].x | ((unsigned long long)slw[rr].y << 32), slw[rr].z, slw[rr].w };
+        lkt_resolve(lk, key[rr], h[rr], sl, ofirst, ocnt, onoff);
+      }
+      const bool keep = !deferred && cnt != 0 && cnt <= gocc_thr;
+      if (in[rr]) {
+        so.iv_lo[seed] = l;
+        so.iv_cnt[seed] = keep ? cnt : 0u;
+        so.iv_aux[seed] = aux;
+        so.on_node[seed] = on_node;
+        so.on_noff[seed] = on_noff;
+        if (have_lk) { so.off_first[seed] = ofirst; so.off_cnt[seed] = ocnt; so.off_noff[seed] = onoff; }
+        n_live += keep;
+        wsum += keep ? cnt : 0u;
+        osum += ocnt & ~OFF_INLINE;
+      }
+      uint64_t dm = __ballot(deferred);
+      if (dm) {
+        unsigned long long at = 0;
+        if (lane == 0) at = atomicAdd(&ctr->n_defer.v, (unsigned long long)__popcll(dm));
+        at = __shfl(at, 0);
+        if (deferred) defer[at + __popcll(dm & lanemask_lt())] = (uint32_t)seed;
+      }
     }
   }
   for (int d = 32; d > 0; d >>= 1) {

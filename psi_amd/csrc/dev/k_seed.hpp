@@ -330,9 +330,16 @@ k_seed_pack(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
       const uint64_t abs0 = ro[j] + st[j];
       fast[j] = in[j] && abs0 + 8ull * nw <= n_bases;
 #pragma unroll
-      for (uint32_t w = 0; w < NW; ++w) {
-        x[j][w] = 0;
-        if (fast[j] && w < nw) __builtin_memcpy(&x[j][w], bases + abs0 + 8 * w, 8);
+      for (uint32_t w = 0; w < NW; ++w) x[j][w] = 0;
+      // (all words of the seed in ONE block, from addresses pulled back inside the buffer where the seed ends near its end --
+      // such a seed takes the byte loop below: a load per branch was a memory latency per word, round 5)
+      if (n_bases >= 8) {
+#pragma unroll
+        for (uint32_t w = 0; w < NW; ++w) {
+          uint64_t a = (in[j] ? abs0 : 0ull) + 8 * w;
+          a = a + 8 <= n_bases ? a : n_bases - 8;
+          __builtin_memcpy(&x[j][w], bases + a, 8);
+        }
       }
     }
 #pragma unroll
