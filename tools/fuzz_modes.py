@@ -159,6 +159,24 @@ def main():
                                 print(' index rebuilt on', dev, o, '| loci equal to the first:', same_loci, '| result:',
                                       'ok' if (r4.shape == want.shape and (r4 == want).all()) else 'WRONG', flush=True)
                                 f4.close()
+                        # (round 5, after campaign b: wrong in every variant above) what all those finders share is the HOST graph
+                        # object: is what it holds still what it was made from?  and does a second object made from the same
+                        # Python data answer right?
+                        up = np.frombuffer(labels.upper(), np.uint8)
+                        print(' graph object unchanged: labels', bool(np.array_equal(pg.labels, up)),
+                              'label_off', bool(np.array_equal(pg.label_off, label_off)), 'edge_off', bool(np.array_equal(pg.edge_off, edge_off)),
+                              'edge_to', bool(np.array_equal(pg.edge_to, np.array(edge_to, dtype=np.uint32))), flush=True)
+                        if not np.array_equal(pg.labels, up):
+                            d = np.flatnonzero(pg.labels != up)
+                            print('  labels differ at', d[:16].tolist(), 'is', bytes(pg.labels[d[:16]]), 'was', bytes(up[d[:16]]), flush=True)
+                        pg2 = psi_amd.Graph.from_csr(g.ids, label_off, labels, edge_off, edge_to, paths=[[rank[v] for v in g.paths[0][1]]])
+                        px3 = psi_amd.PathIndex.build(pg2, k, npaths, **dict(bargs, device=None))
+                        f7 = psi_amd.SeedFinder(pg2, k, mode=mode, walk_cap=cap)
+                        f7.set_path_index(px3)
+                        r7 = psi_amd.sort_unique(f7.seeds_all(reads, step=step))
+                        print(' a second graph object from the same data:', 'ok' if (r7.shape == want.shape and (r7 == want).all()) else 'WRONG', flush=True)
+                        want2 = np.array(brute.hit_set(g, [r.upper() for r in reads], k, step), dtype=np.uint64).reshape(-1, 4)
+                        print(' the brute-force set computed again == the first:', bool(want2.shape == want.shape and (want2 == want).all()), flush=True)
                         f5 = psi_amd.SeedFinder(pg, k, mode=mode, walk_cap=cap)
                         f5.set_option('no_pfx_roots', 1)
                         f5.set_path_index(px)
