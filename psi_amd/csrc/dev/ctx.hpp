@@ -77,6 +77,7 @@ struct psigpu_ctx {
   bool have_events = false;
   psigpu_counters last{};
   uint64_t last_max_read_len = 0;  // longest read of the last run_pipeline call
+  uint64_t longest_read_seen = 0;  // ... of all calls so far (the packed wire records are sized with it: a hint, checked on the device)
   // sort-unique on the device (PSIGPU_SORT_UNIQUE)
   uint64_t max_node_len = 0;
   DevBuf ids_sorted;               // node ids in increasing order (only when they are not rank + id_base)
@@ -145,7 +146,7 @@ struct psigpu_ctx {
   // psigpu_set_option
   uint64_t opt_sub_bytes = 0;
   bool opt_no_ahead = false, opt_no_engine_copy = false;
-  uint32_t opt_wire = 0;           // 0: the narrowest wire record that fits; 8 / 16 / 32: nothing narrower
+  uint32_t opt_wire = 0;           // 0: the narrowest wire record that fits; 5 / 6 / 7 / 8 / 16 / 32: nothing narrower
   uint32_t opt_wire8_roff_cap = 0; // test hook: at most this many read-offset bits in an 8-byte record
   bool opt_no_numa = false;        // host entry: the library's threads anywhere (A/B; read when they are made)
   bool opt_one_out_engine = false; // host entry: the records out on ONE copy engine (A/B; read when the pipeline is made)
@@ -160,6 +161,7 @@ struct psigpu_ctx {
   uint64_t uniform_refuted = 0;    // calls that claimed PSIGPU_UNIFORM_READS for reads that were not (answered again the general way)
   uint64_t stale_handbacks = 0;    // counter blocks that came back with another call's number (psigpu_counters.stale_handbacks)
   bool wire8_overflowed = false;   // a sub-batch's records did not fit 8 bytes: the context stays with 16 from then on
+  uint32_t wirep_floor = 5;        // packed wire records (5-7 bytes): none narrower than this (a sub-batch whose records did not fit raised it; 8: none)
 };
 
 static uint32_t bits_for(uint64_t max_value)      // bits needed to hold 0..max_value (at least 1)

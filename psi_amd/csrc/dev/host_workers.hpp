@@ -223,7 +223,28 @@ struct Widener {
       if (t == 0) { if (job.n) wait_copy(job.slot); if (tl_copy) tl_copy[j] = tl_now() - tl_base; ready.store(j + 1, std::memory_order_release); }
       else while (ready.load(std::memory_order_acquire) <= j) { if (stop.load()) return; std::this_thread::yield(); }
       const uint64_t a = job.n * t / T, b = job.n * (t + 1) / T;
-      if (job.fmt.bytes == 8) {
+      if (job.fmt.bytes && job.fmt.bytes < 8) {
+        // packed records (k_hits_wirep): blocks of WP_BLOCK, each behind the read id of its first record
+        const char* src = static_cast<const char*>(job.src);
+        const uint32_t B = job.fmt.bytes, nb = job.fmt.noff_bits, vb = job.fmt.node_bits, rb = job.fmt.roff_bits;
+        const uint64_t nm = (1ull << nb) - 1, vm = (1ull << vb) - 1, rm = (1ull << rb) - 1, km = (1ull << (8 * B)) - 1;
+        const uint64_t stride = wirep_block_stride(B), div = job.fmt.roff_div;
+        for (uint64_t i = a; i < b;) {
+          const uint64_t blk = i / WP_BLOCK, e = std::min<uint64_t>(b, (blk + 1) * WP_BLOCK);
+          const char* p = src + blk * stride;
+          uint64_t first; memcpy(&first, p, 8);
+          const uint64_t rid0 = job.rec_base + (first & 0xFFFFFFFFull);
+          p += 8 + (i % WP_BLOCK) * B;
+          for (; i < e; ++i, p += B) {
+            uint64_t key; memcpy(&key, p, 8);         // (the landing buffer has room behind the last record)
+            key &= km;
+            const uint64_t noff = key & nm; key >>= nb;
+            const uint64_t node = key & vm; key >>= vb;
+            const uint64_t roff = (key & rm) * div; key >>= rb;
+            store_hit(job.dst + i, job.id_base + node, noff, rid0 + key, roff);
+          }
+        }
+      } else if (job.fmt.bytes == 8) {
         const uint64_t* src = static_cast<const uint64_t*>(job.src);
         const uint32_t nb = job.fmt.noff_bits, vb = job.fmt.node_bits, rb = job.fmt.roff_bits;
         const uint64_t nm = (1ull << nb) - 1, vm = (1ull << vb) - 1, rm = (1ull << rb) - 1;

@@ -10,6 +10,8 @@
 // call's or ignored and nothing needs a fence.  The records come out in seed order exactly as k_kmer_emit writes them
 // (emit_round: the transposed stores, the spread of a seed with many hits over the wave).
 // The general (not equal-length) reads locate their read as k_seed_pack does, from the scanned seed offsets.
+// Traverse mode runs the same kernel over the table of the PATHS' k-mers and has it leave the seeds' k-mers and (read, offset)
+// behind for the chunk's seed table and the traverser.
 // ------------------------------------------------------------------------------------
 #ifndef KS_ROUNDS
 #define KS_ROUNDS 4
@@ -27,7 +29,9 @@ k_kmer_step(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
             KmerTableView kt, MapView mv, const LocusEnt* __restrict__ ent, bool want_on, bool want_off, uint32_t gocc_thr,
             uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap, uint64_t* tile_state, uint32_t serial22,
             DevCounters* ctr, uint32_t opts /* 2: no look-back (timing experiment, wrong records);
-                                               4: PSIGPU_ANY_ORDER -- the tile's output range by one atomic add */)
+                                               4: PSIGPU_ANY_ORDER -- the tile's output range by one atomic add */,
+            uint64_t* __restrict__ seed_key_out = nullptr, uint2* __restrict__ seed_info_out = nullptr /* traverse mode: the seeds'
+                                               k-mers and (read, offset) for the chunk's seed table and the traverser behind this kernel */)
 {
   __shared__ uint32_t s_tile;
   __shared__ uint32_t s_cnt[KS_R * 4];
@@ -179,6 +183,11 @@ k_kmer_step(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
     }
   }
 
+  if (seed_key_out) {
+#pragma unroll
+    for (int r = 0; r < KS_R; ++r)
+      if (have[r]) { seed_key_out[sd[r]] = key[r]; seed_info_out[sd[r]] = si[r]; }
+  }
   // ---- one probe per seed: every round's first load in flight before the first is looked at ----------------------------
   uint64_t h[KS_R];
   uint4 v[KS_R];

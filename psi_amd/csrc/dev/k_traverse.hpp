@@ -117,33 +117,23 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
 }
 
 // The prefix walks of the starting loci against the chunk's prefix maps: a stream (16 bytes per walk in, the few that pass
-// out).  The 12-mer map is 2 MiB (L2), the long one 32 MiB and only asked for walks the short one lets pass.  A wave
-// collects what passes in LDS and appends it with one atomic per ~200 walks (one per round of 64 would be 400 k atomics
-// on one address: 11 ns each).  The order of the survivors is whatever the waves make it; the traverser's records have
-// no order either.
-constexpr uint32_t PF_BUF = 256, PF_R = 8;      // (16 KB of LDS per workgroup: eight workgroups per CU; eight rounds per latency chain)
+// out).  The 12-mer map is 2 MiB (L2), the long one 32 MiB and only asked for walks the short one lets pass.  A wave owns
+// a contiguous range of the walks and writes what passes to the START OF THE SAME RANGE of `out`, its count to seg_cnt[wave]:
+// wave w of the traverser takes segment w.  (Until round 5 the survivors were appended to one array through one counter:
+// 24 576 waves x at least one atomic on one address, ~11 ns each = 0.27 of the kernel's 0.34 ms.)
+constexpr uint32_t PF_R = 8;                     // eight rounds of 64 walks per latency chain
 __global__ void __launch_bounds__(256)
-k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, const uint32_t* __restrict__ pfx12, const uint32_t* __restrict__ pfx_bits,
-             uint32_t depth, uint4* __restrict__ out, unsigned long long* n_out)
+k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, uint32_t per_wave, const uint32_t* __restrict__ pfx12,
+             const uint32_t* __restrict__ pfx_bits, uint32_t depth, uint4* __restrict__ out, uint32_t* __restrict__ seg_cnt)
 {
-  // A wave owns a CONTIGUOUS range of the walks -- they come ordered by prefix, so its look-ups walk through the two maps
-  // front to back -- and takes it PF_R rounds of 64 at a time: the loads of all rounds are issued before the first is
-  // looked at (walk, 12-mer word, long-map word are three latencies in a row).
-  __shared__ uint4 buf[4][PF_BUF];
+  // The walks come ordered by prefix, so a wave's look-ups walk through the two maps front to back; it takes them PF_R
+  // rounds of 64 at a time: the loads of all rounds are issued before the first is looked at (walk, 12-mer word, long-map
+  // word are three latencies in a row).
   const uint32_t lane = lane_id(), wib = threadIdx.x >> 6;
   const uint32_t sh12 = 2 * (depth - PFX_SHORT);
-  const uint64_t n_waves = (uint64_t)gridDim.x * 4, wave = (uint64_t)blockIdx.x * 4 + wib;
-  const uint64_t per_wave = ((n + n_waves - 1) / n_waves + 63) / 64 * 64;
+  const uint64_t wave = (uint64_t)blockIdx.x * 4 + wib;
   const uint64_t w0 = min(n, wave * per_wave), w1 = min(n, w0 + per_wave);
-  uint32_t held = 0;                              // wave-uniform: walks in this wave's buffer
-  auto flush = [&]() {
-    unsigned long long at = 0;
-    if (lane == 0) at = atomicAdd(n_out, (unsigned long long)held);
-    at = __shfl(at, 0);
-    for (uint32_t i = lane; i < held; i += 64) out[at + i] = buf[wib][i];
-    held = 0;
-    __builtin_amdgcn_wave_barrier();
-  };
+  uint32_t held = 0;                              // wave-uniform: walks of this wave that passed
   for (uint64_t base = w0; base < w1; base += 64 * PF_R) {
     uint4 e[PF_R];
     uint32_t w12[PF_R], w14[PF_R];
@@ -155,7 +145,7 @@ k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, const uint32_t* __rest
       e[r] = roots[in[r] ? i : w1 - 1];           // (a lane past the end repeats the last walk and drops the answer)
     }
     // (whole 16-byte loads: left alone the compiler fetches the prefix word now and the other three words later, behind the
-    // branch that keeps a walk -- one more memory latency per round, eight in a row per iteration: 0.37 ms for this kernel)
+    // branch that keeps a walk -- one more memory latency per round, eight in a row per iteration)
 #pragma unroll
     for (uint32_t r = 0; r < PF_R; ++r) keep_whole(e[r]);
 #pragma unroll
@@ -173,15 +163,11 @@ k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, const uint32_t* __rest
     for (uint32_t r = 0; r < PF_R; ++r) {
       const bool keep = pass[r] && ((w14[r] >> (e[r].x & 31)) & 1u);
       const uint64_t km = __ballot(keep);
-      if (km) {
-        if (held + (uint32_t)__popcll(km) > PF_BUF) flush();
-        if (keep) buf[wib][held + (uint32_t)__popcll(km & lanemask_lt())] = e[r];
-        held += (uint32_t)__popcll(km);
-        __builtin_amdgcn_wave_barrier();
-      }
+      if (keep) out[w0 + held + (uint32_t)__popcll(km & lanemask_lt())] = e[r];
+      held += (uint32_t)__popcll(km);
     }
   }
-  if (held) flush();
+  if (lane == 0) seg_cnt[wave] = held;
 }
 
 template <bool ENUM, typename KEY = uint64_t, bool WINDOW = true>      // (WINDOW false: roots that are not in node order -- the filtered
@@ -192,7 +178,8 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
            TravItemT<KEY>* __restrict__ spill_out, uint64_t spill_cap,
            uint32_t k, uint64_t rec_offset, psigpu_hit* __restrict__ chunks, uint32_t* __restrict__ chunk_fill,
            uint32_t cap_chunks, uint64_t n_nodes, DevCounters* ctr, EnumOut eo, const uint4* __restrict__ pfx_roots = nullptr,
-           const unsigned long long* __restrict__ n_roots_dev = nullptr /* pfx_roots: how many there are (k_pfx_filter's count) */)
+           const uint32_t* __restrict__ seg_cnt = nullptr /* pfx_roots in segments of loci_per_wave, the first seg_cnt[wave] of each
+                                                             filled (k_pfx_filter): wave w takes segment w */)
 {
   // pfx_roots (query time, k > 12): the roots are not the loci but their PREFIX WALKS, enumerated once per index
   // (ensure_pfx_roots): (prefix, node, offset in the node's record, locus) -- where a walk from the locus stands after
@@ -214,14 +201,8 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   const bool from_spill = spill_in != nullptr;
   const bool from_pfx = !ENUM && !from_spill && pfx_roots != nullptr;      // (n_loci then counts prefix walks)
   uint64_t n_roots = from_spill ? n_spill_in : n_loci;
-  if (from_pfx && n_roots_dev) {
-    // the roots were counted on the device: this launch's share of them (whole rounds of 64)
-    n_roots = min((uint64_t)*n_roots_dev, n_loci);
-    loci_per_wave = (uint32_t)(((n_roots + gridDim.x - 1) / gridDim.x + 63) / 64 * 64);
-  }
-  uint64_t cursor = min(n_roots, (uint64_t)blockIdx.x * loci_per_wave);     // next root NOT yet requested from memory (a launch sized
-                                                                            // for more roots than the device counted: nothing for this wave)
-  const uint64_t cend = min(n_roots, cursor + loci_per_wave);
+  uint64_t cursor = min(n_roots, (uint64_t)blockIdx.x * loci_per_wave);     // next root NOT yet requested from memory
+  const uint64_t cend = (from_pfx && seg_cnt) ? cursor + seg_cnt[blockIdx.x] : min(n_roots, cursor + loci_per_wave);
   uint32_t top = 0, ndone = 0;            // wave-uniform
   uint32_t rb_pos = 0, rb_cnt = 0;        // wave-uniform: staged roots [rb_pos, rb_cnt) are unread
   uint32_t kpaths = 0;

@@ -1641,10 +1641,11 @@ def test_packed_device_entry_equals_ascii():
 
 @pytest.mark.parametrize('pinned', [False, True])
 def test_wire_record_formats_agree(pinned):
-    """The records cross the device-to-host link as 8-byte keys (round 4), 16-byte records (round 3) or as they are
-    (32 bytes): same records, same order.  An 8-byte key whose read-offset field is too narrow for a read of the
+    """The records cross the device-to-host link as packed records of 5 to 7 bytes (round 5: read id relative to the
+    block of 256 records, read offset in seed distances), 8-byte keys (round 4), 16-byte records (round 3) or as they
+    are (32 bytes): same records, same order.  An 8-byte key whose read-offset field is too narrow for a read of the
     sub-batch (forced here through the test hook) is detected on the device and the sub-batch goes out as 16-byte
-    records instead."""
+    records instead; so is a packed record sized for shorter reads than the chunk holds."""
     g, reads = _x_case()
     k, step = 21, 5
     ragged = _ragged_reads(reads[:300], k)
@@ -1659,7 +1660,7 @@ def test_wire_record_formats_agree(pinned):
     assert f.counters()['wire_bytes_per_hit'] == 32
     for sub in (1 << 30, 700):
         f.set_option('sub_bytes', sub)
-        for wire, expect in ((0, 8), (8, 8), (16, 16), (32, 32)):
+        for wire, expect in ((0, 5), (6, 6), (7, 7), (8, 8), (16, 16), (32, 32)):
             f.set_option('wire', wire)
             assert _eq(psi_amd.sort_unique(f.seeds_all(src, step=step, rec_offset=9)), want_raw), (sub, wire)
             assert f.counters()['wire_bytes_per_hit'] == expect
@@ -1673,9 +1674,30 @@ def test_wire_record_formats_agree(pinned):
         assert _eq(psi_amd.sort_unique(f.seeds_all(src, step=step, rec_offset=9)), want_raw)
         f.set_option('wire8_roff_bits', 0)
         assert _eq(f.seeds_all(src, step=step, rec_offset=9, sort_unique=True), want)
-        assert f.counters()['wire_bytes_per_hit'] == 8
+        assert f.counters()['wire_bytes_per_hit'] == 5
     with pytest.raises(psi_amd.PsiGpuError):
         f.set_option('no_such_option', 1)
+    short = [r[:k + 2] for r in reads[:40]]
+    long_ = [''.join(reads[i:i + 16]) for i in range(0, 320, 16)]
+    f.set_option('wire', 32)
+    want_long = f.seeds_all(long_, step=step, sort_unique=True)
+    f_px = f.pindex
+    f.close()
+    # packed records are sized by the longest read the context has seen: a chunk of short reads, then one whose reads are
+    # sixteen times as long -- its offsets do not fit, the kernel says so, the sub-batch goes out as 16-byte records and the
+    # context goes on with one byte more per record
+    f = psi_amd.SeedFinder(g, k)
+    f.set_path_index(f_px)
+    f.seeds_all(short, step=step, sort_unique=True)                  # (the first chunk of a context: nothing known yet, 8-byte keys)
+    assert f.counters()['wire_bytes_per_hit'] == 8
+    f.seeds_all(short, step=step, sort_unique=True)
+    assert f.counters()['wire_bytes_per_hit'] == 5
+    f.seeds_all(short, step=step, sort_unique=True)
+    assert _eq(f.seeds_all(long_, step=step, sort_unique=True), want_long)
+    assert f.counters()['wire_bytes_per_hit'] == 16
+    assert _eq(f.seeds_all(long_, step=step, sort_unique=True), want_long)
+    assert f.counters()['wire_bytes_per_hit'] == 6
+    # a seed distance the offsets are no multiples of cannot happen through seeds_all; records out of read order cannot either
     f.close()
 
 

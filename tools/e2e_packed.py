@@ -82,6 +82,22 @@ for i in range(240):
 f.set_option('no_lookahead', 0)
 print(json.dumps({'label': 'alternated, 100 calls each', 'two_in_flight_median_ms': float(np.median(ab[0])), 'two_in_flight_min_ms': min(ab[0]),
                   'one_at_a_time_median_ms': float(np.median(ab[1])), 'one_at_a_time_min_ms': min(ab[1])}), flush=True)
+# the wire formats alternated the same way: packed records (5-7 bytes, round 5) against 8-byte keys
+abw = {0: [], 8: []}
+for i in range(240):
+    w = 8 if i & 1 else 0
+    f.set_option('wire', w)
+    t = time.perf_counter()
+    assert L.psigpu_find_seeds_packed(*calls[(i >> 1) % 2]) == 0
+    L.psigpu_free_hits(C.byref(hits))
+    if i >= 40:
+        abw[w].append((time.perf_counter() - t) * 1e3)
+    if i in (238, 239):
+        print(json.dumps({'label': 'wire option %d' % w, 'wire_bytes_per_hit': int(f.counters()['wire_bytes_per_hit']),
+                          'lookahead_fallbacks': int(f.counters()['lookahead_fallbacks'])}), flush=True)
+f.set_option('wire', 0)
+print(json.dumps({'label': 'wire formats alternated, 100 calls each', 'packed_median_ms': float(np.median(abw[0])), 'packed_min_ms': min(abw[0]),
+                  'keys8_median_ms': float(np.median(abw[8])), 'keys8_min_ms': min(abw[8])}), flush=True)
 if os.environ.get('E2E_TRACE'):
     # PSIGPU_TRACE=2: the timeline of the default (two sub-batches in flight) path; =1: the synchronous loop's
     for tr in ('2', '2', '1'):
