@@ -117,32 +117,35 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
 }
 
 // The prefix walks of the starting loci against the chunk's prefix maps: a stream (16 bytes per walk in, the few that pass
-// out).  The 12-mer map is 2 MiB (L2), the long one 32 MiB and only asked for walks the short one lets pass.  A wave owns
-// a contiguous range of the walks and writes what passes to the START OF THE SAME RANGE of `out`, its count to seg_cnt[wave]:
-// wave w of the traverser takes segment w.  (Until round 5 the survivors were appended to one array through one counter:
+// out).  The 12-mer map is 2 MiB (L2), the long one 32 MiB and only asked for walks the short one lets pass.  A wave writes
+// what passes of the walks it looked at to a segment of `out` of its own, its count to seg_cnt[wave]: wave w of the
+// traverser takes segment w.  (Until round 5 the survivors were appended to one array through one counter:
 // 24 576 waves x at least one atomic on one address, ~11 ns each = 0.27 of the kernel's 0.34 ms.)
-constexpr uint32_t PF_R = 8;                     // eight rounds of 64 walks per latency chain
+constexpr uint32_t PF_R = 8;                     // eight rounds of 64 walks per wave and latency chain
+constexpr uint32_t PF_CHUNK = 4 * 64 * PF_R;     // walks a workgroup takes at a time
 __global__ void __launch_bounds__(256)
 k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, uint32_t per_wave, const uint32_t* __restrict__ pfx12,
              const uint32_t* __restrict__ pfx_bits, uint32_t depth, uint4* __restrict__ out, uint32_t* __restrict__ seg_cnt)
 {
-  // The walks come ordered by prefix, so a wave's look-ups walk through the two maps front to back; it takes them PF_R
-  // rounds of 64 at a time: the loads of all rounds are issued before the first is looked at (walk, 12-mer word, long-map
-  // word are three latencies in a row).
+  // The workgroups sweep the walks as one front -- workgroup b takes chunks b, b + grid, b + 2 grid ... of PF_CHUNK walks, its
+  // four waves interleaved round by round -- so that what is in flight at any time is one contiguous window of memory (a wave
+  // with a 12-KB range of its own, 24 576 ranges open at once, ran at 1.6 TB/s).  The walks come ordered by prefix, so a
+  // round's look-ups are neighbours in the two maps.  The loads of all PF_R rounds are issued before the first is looked
+  // at (walk, 12-mer word, long-map word are three latencies in a row).  Output: segment `wave` of per_wave slots.
   const uint32_t lane = lane_id(), wib = threadIdx.x >> 6;
   const uint32_t sh12 = 2 * (depth - PFX_SHORT);
   const uint64_t wave = (uint64_t)blockIdx.x * 4 + wib;
-  const uint64_t w0 = min(n, wave * per_wave), w1 = min(n, w0 + per_wave);
+  uint4* __restrict__ mine = out + wave * per_wave;
   uint32_t held = 0;                              // wave-uniform: walks of this wave that passed
-  for (uint64_t base = w0; base < w1; base += 64 * PF_R) {
+  for (uint64_t base = (uint64_t)blockIdx.x * PF_CHUNK; base < n; base += (uint64_t)gridDim.x * PF_CHUNK) {
     uint4 e[PF_R];
     uint32_t w12[PF_R], w14[PF_R];
     bool in[PF_R];
 #pragma unroll
     for (uint32_t r = 0; r < PF_R; ++r) {
-      const uint64_t i = base + 64 * r + lane;
-      in[r] = i < w1;
-      e[r] = roots[in[r] ? i : w1 - 1];           // (a lane past the end repeats the last walk and drops the answer)
+      const uint64_t i = base + (uint64_t)(r * 4 + wib) * 64 + lane;
+      in[r] = i < n;
+      e[r] = roots[in[r] ? i : n - 1];            // (a lane past the end repeats the last walk and drops the answer)
     }
     // (whole 16-byte loads: left alone the compiler fetches the prefix word now and the other three words later, behind the
     // branch that keeps a walk -- one more memory latency per round, eight in a row per iteration)
@@ -163,7 +166,7 @@ k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, uint32_t per_wave, con
     for (uint32_t r = 0; r < PF_R; ++r) {
       const bool keep = pass[r] && ((w14[r] >> (e[r].x & 31)) & 1u);
       const uint64_t km = __ballot(keep);
-      if (keep) out[w0 + held + (uint32_t)__popcll(km & lanemask_lt())] = e[r];
+      if (keep) mine[held + (uint32_t)__popcll(km & lanemask_lt())] = e[r];
       held += (uint32_t)__popcll(km);
     }
   }
@@ -202,7 +205,7 @@ k_traverse(GraphView g, TableView tb, const uint2* __restrict__ loci /* (node ra
   const bool from_pfx = !ENUM && !from_spill && pfx_roots != nullptr;      // (n_loci then counts prefix walks)
   uint64_t n_roots = from_spill ? n_spill_in : n_loci;
   uint64_t cursor = min(n_roots, (uint64_t)blockIdx.x * loci_per_wave);     // next root NOT yet requested from memory
-  const uint64_t cend = (from_pfx && seg_cnt) ? cursor + seg_cnt[blockIdx.x] : min(n_roots, cursor + loci_per_wave);
+  const uint64_t cend = (from_pfx && seg_cnt) ? cursor + min(seg_cnt[blockIdx.x], loci_per_wave) : min(n_roots, cursor + loci_per_wave);
   uint32_t top = 0, ndone = 0;            // wave-uniform
   uint32_t rb_pos = 0, rb_cnt = 0;        // wave-uniform: staged roots [rb_pos, rb_cnt) are unread
   uint32_t kpaths = 0;
