@@ -150,7 +150,7 @@ struct psigpu_ctx {
   uint32_t opt_wire8_roff_cap = 0; // test hook: at most this many read-offset bits in an 8-byte record
   bool opt_no_numa = false;        // host entry: the library's threads anywhere (A/B; read when they are made)
   bool opt_one_out_engine = false; // host entry: the records out on ONE copy engine (A/B; read when the pipeline is made)
-  uint32_t opt_widen_threads = 0;  // host entry: threads that widen the wire records (0: min(8, cores / 4)); read when the first call makes them
+  uint32_t opt_widen_threads = 0;  // host entry: threads that widen the wire records (0: min(12, cores / 4)); read when the first call makes them
   bool opt_no_pfx_roots = false;   // traverse mode from the loci themselves (A/B, tests)
   bool opt_res16 = false;          // 16 bytes of probe results per seed (A/B, tests)
   uint64_t opt_expected_calls = 0; // PSIGPU_MODE_AUTO: chunks the caller expects to ask (0: unknown)

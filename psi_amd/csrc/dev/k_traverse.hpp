@@ -116,9 +116,8 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
   }
 }
 
-// The prefix walks of the starting loci against the chunk's prefix maps: a stream (16 bytes per walk in, the few that pass
-// out).  The 12-mer map is 2 MiB (L2), the long one 32 MiB and only asked for walks the short one lets pass.  A wave writes
-// what passes of the walks it looked at to a segment of `out` of its own, its count to seg_cnt[wave]: wave w of the
+// The prefix walks of the starting loci against the chunk's long prefix map (4^min(k,14) bits): a stream (16 bytes per walk
+// in, the few that pass out).  A wave writes what passes of the walks it looked at to a segment of `out` of its own, its count to seg_cnt[wave]: wave w of the
 // traverser takes segment w.  (Until round 5 the survivors were appended to one array through one counter:
 // 24 576 waves x at least one atomic on one address, ~11 ns each = 0.27 of the kernel's 0.34 ms.)
 constexpr uint32_t PF_R = 8;                     // eight rounds of 64 walks per wave and latency chain
@@ -130,16 +129,15 @@ k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, uint32_t per_wave, con
   // The workgroups sweep the walks as one front -- workgroup b takes chunks b, b + grid, b + 2 grid ... of PF_CHUNK walks, its
   // four waves interleaved round by round -- so that what is in flight at any time is one contiguous window of memory (a wave
   // with a 12-KB range of its own, 24 576 ranges open at once, ran at 1.6 TB/s).  The walks come ordered by prefix, so a
-  // round's look-ups are neighbours in the two maps.  The loads of all PF_R rounds are issued before the first is looked
-  // at (walk, 12-mer word, long-map word are three latencies in a row).  Output: segment `wave` of per_wave slots.
+  // round's look-ups are neighbours in the map.  The loads of all PF_R rounds are issued before the first is looked at
+  // (walk, then map word: two latencies in a row).  Output: segment `wave` of per_wave slots.
   const uint32_t lane = lane_id(), wib = threadIdx.x >> 6;
-  const uint32_t sh12 = 2 * (depth - PFX_SHORT);
   const uint64_t wave = (uint64_t)blockIdx.x * 4 + wib;
   uint4* __restrict__ mine = out + wave * per_wave;
   uint32_t held = 0;                              // wave-uniform: walks of this wave that passed
   for (uint64_t base = (uint64_t)blockIdx.x * PF_CHUNK; base < n; base += (uint64_t)gridDim.x * PF_CHUNK) {
     uint4 e[PF_R];
-    uint32_t w12[PF_R], w14[PF_R];
+    uint32_t w14[PF_R];
     bool in[PF_R];
 #pragma unroll
     for (uint32_t r = 0; r < PF_R; ++r) {
@@ -151,17 +149,15 @@ k_pfx_filter(const uint4* __restrict__ roots, uint64_t n, uint32_t per_wave, con
     // branch that keeps a walk -- one more memory latency per round, eight in a row per iteration)
 #pragma unroll
     for (uint32_t r = 0; r < PF_R; ++r) keep_whole(e[r]);
+    // The long map alone, for every walk: the walks are in prefix order, so the 64 look-ups of a round fall into two or
+    // three neighbouring sectors of it and the kernel reads the map once, front to back (32 MiB beside 282 MB of walks).
+    // Asking the 2-MiB 12-mer map first -- as the traverser did when the walks came in locus order and a look-up in the
+    // long map was a random sector -- was a third memory latency in the chain for nothing.
 #pragma unroll
-    for (uint32_t r = 0; r < PF_R; ++r) { const uint32_t p12 = e[r].x >> sh12; w12[r] = pfx12[p12 >> 5]; }
-    // (the long map only for walks the short one lets pass -- two thirds do not, and theirs would be random words of a 32-MiB
-    // map -- but with no branch around the load: the others fetch word 0, one line for the whole wave)
+    for (uint32_t r = 0; r < PF_R; ++r) w14[r] = pfx_bits[e[r].x >> 5];
     bool pass[PF_R];
 #pragma unroll
-    for (uint32_t r = 0; r < PF_R; ++r) {
-      const uint32_t p12 = e[r].x >> sh12;
-      pass[r] = in[r] && ((w12[r] >> (p12 & 31)) & 1u);
-      w14[r] = pfx_bits[pass[r] ? e[r].x >> 5 : 0u];
-    }
+    for (uint32_t r = 0; r < PF_R; ++r) pass[r] = in[r];
 #pragma unroll
     for (uint32_t r = 0; r < PF_R; ++r) {
       const bool keep = pass[r] && ((w14[r] >> (e[r].x & 31)) & 1u);
