@@ -7,6 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# a fatal signal inside the library leaves its native backtrace on stderr before pytest's fault handler prints the Python one
+# (round 5: one SIGSEGV inside a host index build, once, in a GPU run that had left nothing but the Python stack)
+os.environ.setdefault('PSIGPU_SEGV_TRACE', '1')
+
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 REF_DATA = os.path.join(GOLDEN, 'ref_data')
 
