@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "host.hpp"
+#include "loci_steps.hpp"
 
 namespace psigpu {
 namespace {
@@ -588,6 +589,60 @@ __global__ void k_loci_fill(LociGraph g, const unsigned long long* __restrict__ 
   loci_of_node(g, v, unc[v], out_n + first[v], out_o + first[v]);
 }
 
+// ------------------------------------------------------------------------------------
+// Starting loci of TRIMMED paths (psikt's default: patches), of more than 64 paths, of paths that visit a node
+// twice -- where one coverage bit per path does not do.  The host routine's own scheme (index.cpp
+// find_starting_loci / explore): a walk is covered while it is a run of consecutive STEPS of some path, a step
+// indexing bases [lo, hi) of its node; per node the candidate steps of a walk depend on its start offset only
+// through the distinct head offsets of the steps at the node.  One thread per node, explore() with an explicit
+// stack and the candidate lists in a per-thread pool.  A node whose lists do not fit the pool is counted in
+// `hard`; the caller then takes the host routine (same result either way; the fuzz campaigns build with
+// PSIGPU_BUILD_VERIFY=1, which compares the two).
+// ------------------------------------------------------------------------------------
+__global__ void k_steps_init(const uint32_t* __restrict__ step_node, const uint32_t* __restrict__ len, uint64_t total,
+                             uint32_t* __restrict__ lo, uint32_t* __restrict__ hi, uint8_t* __restrict__ last, uint32_t* __restrict__ cnt)
+{
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= total) return;
+  const uint32_t v = step_node[s];
+  lo[s] = 0; hi[s] = len[v]; last[s] = 0;
+  atomicAdd(&cnt[v], 1u);
+}
+__global__ void k_steps_ends(const uint64_t* __restrict__ first, uint64_t n_paths, const uint32_t* __restrict__ head,
+                             const uint32_t* __restrict__ tail, const uint32_t* __restrict__ step_node, const uint32_t* __restrict__ len,
+                             uint32_t* __restrict__ lo, uint32_t* __restrict__ hi, uint8_t* __restrict__ last)
+{
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_paths || first[p + 1] == first[p]) return;
+  const uint64_t s0 = first[p], s1 = first[p + 1] - 1;
+  if (head) lo[s0] = min(len[step_node[s0]], head[p]);
+  if (tail && tail[p]) hi[s1] = min(len[step_node[s1]], tail[p]);
+  last[s1] = 1;
+}
+__global__ void k_iota_u32(uint32_t* __restrict__ a, uint64_t n)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (uint32_t)i;
+}
+
+__global__ void k_steps_loci_count(StepGraph g, uint32_t* __restrict__ cnt, uint32_t* __restrict__ n_hard)
+{
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= g.n) return;
+  bool hard = false;
+  const uint32_t c = steps_loci_of_node(g, v, nullptr, nullptr, &hard);
+  cnt[v] = hard ? 0u : c;
+  if (hard) atomicAdd(n_hard, 1u);
+}
+__global__ void k_steps_loci_fill(StepGraph g, const uint32_t* __restrict__ first, const uint32_t* __restrict__ cnt,
+                                  uint32_t* __restrict__ out_n, uint32_t* __restrict__ out_o)
+{
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= g.n || cnt[v] == 0) return;
+  bool hard = false;
+  steps_loci_of_node(g, v, out_n + first[v], out_o + first[v], &hard);
+}
+
 }  // namespace
 
 int gpu_find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>& paths, uint32_t k, uint32_t step,
@@ -665,6 +720,113 @@ int gpu_find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_
                              d_out_n.as<uint32_t>(), d_out_o.as<uint32_t>());
     GB_CHK(download(loci_node.data(), d_out_n.p, (size_t)total * 4));
     GB_CHK(download(loci_off.data(), d_out_o.p, (size_t)total * 4));
+  }
+  GB_CHK(hipDeviceSynchronize());
+  return PSIGPU_OK;
+}
+
+// The same for any set of paths (trimmed, many, not simple): see steps_loci_of_node.  *n_hard_out != 0: some nodes were
+// left to the host -- the caller runs find_starting_loci() instead and the arrays here are to be ignored.
+int gpu_find_starting_loci_steps(const Graph& g, const std::vector<std::vector<uint32_t>>& paths,
+                                 const std::vector<uint32_t>& path_head, const std::vector<uint32_t>& path_tail,
+                                 uint32_t k, uint32_t step, int device, std::vector<uint32_t>& loci_node,
+                                 std::vector<uint32_t>& loci_off, uint64_t* n_hard_out, std::string* err)
+{
+  loci_node.clear();
+  loci_off.clear();
+  *n_hard_out = 0;
+  if (step == 0) step = 1;
+  const uint64_t n = g.n_nodes(), m = g.edge_to.size();
+  if (n == 0) return PSIGPU_OK;
+  std::vector<uint64_t> first(paths.size() + 1, 0);
+  for (size_t p = 0; p < paths.size(); ++p) first[p + 1] = first[p] + paths[p].size();
+  const uint64_t total = first[paths.size()];
+  if (total >= 0xFFFFFFF0ull || n >= 0xFFFFFFF0ull) { *n_hard_out = 1; return PSIGPU_OK; }      // (32-bit step numbers here: the host's job)
+  GB_CHK(hipSetDevice(device));
+  Buf d_label_off, d_edge_off, d_edge_to, d_len, d_reach_a, d_reach_b, d_child, d_flag, d_first, d_head, d_tail,
+      d_step_node, d_lo, d_hi, d_last, d_cnt, d_at_off, d_idx, d_keys_out, d_at, d_lcnt, d_lfirst, d_out_n, d_out_o, tmp;
+  size_t tmp_cap = 0;
+  GB_CHK(d_label_off.alloc((n + 1) * 8)); GB_CHK(d_edge_off.alloc((n + 1) * 8)); GB_CHK(d_edge_to.alloc((m + 1) * 4));
+  GB_CHK(hipMemcpy(d_label_off.p, g.label_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+  GB_CHK(hipMemcpy(d_edge_off.p, g.edge_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+  if (m) GB_CHK(hipMemcpy(d_edge_to.p, g.edge_to.data(), m * 4, hipMemcpyHostToDevice));
+  GB_CHK(d_len.alloc(n * 4)); GB_CHK(d_reach_a.alloc(n * 4)); GB_CHK(d_reach_b.alloc(n * 4)); GB_CHK(d_child.alloc(n * 4));
+  GB_CHK(d_flag.alloc(16));
+  const unsigned gn = grid_for(n);
+  k_loci_len<<<gn, 256>>>(d_label_off.as<uint64_t>(), n, k, d_len.as<uint32_t>(), d_reach_a.as<uint32_t>());
+  d_label_off.drop();
+  uint32_t* ra = d_reach_a.as<uint32_t>();
+  uint32_t* rb = d_reach_b.as<uint32_t>();
+  for (;;) {
+    GB_CHK(hipMemset(d_flag.p, 0, 4));
+    k_loci_reach<<<gn, 256>>>(d_edge_off.as<uint64_t>(), d_edge_to.as<uint32_t>(), d_len.as<uint32_t>(), n, k, ra, rb,
+                              d_child.as<uint32_t>(), d_flag.as<uint32_t>());
+    uint32_t changed = 0;
+    GB_CHK(hipMemcpy(&changed, d_flag.p, 4, hipMemcpyDeviceToHost));
+    std::swap(ra, rb);
+    if (!changed) break;
+  }
+  d_reach_a.drop(); d_reach_b.drop();
+  // the steps: the paths' node lists one after the other, the bases each step indexes, the steps at every node
+  GB_CHK(d_step_node.alloc((total + 1) * 4)); GB_CHK(d_lo.alloc((total + 1) * 4)); GB_CHK(d_hi.alloc((total + 1) * 4));
+  GB_CHK(d_last.alloc(total + 1)); GB_CHK(d_cnt.alloc((n + 1) * 4)); GB_CHK(d_at_off.alloc((n + 1) * 4));
+  {
+    // (one transfer: patches are millions of short paths)
+    std::vector<uint32_t> cat;
+    resize_populated(cat, total);
+    for (size_t p = 0; p < paths.size(); ++p)
+      if (!paths[p].empty()) memcpy(cat.data() + first[p], paths[p].data(), paths[p].size() * 4);
+    if (total) GB_CHK(hipMemcpy(d_step_node.p, cat.data(), total * 4, hipMemcpyHostToDevice));
+  }
+  GB_CHK(hipMemset(d_cnt.p, 0, (n + 1) * 4));
+  if (total) {
+    k_steps_init<<<grid_for(total), 256>>>(d_step_node.as<uint32_t>(), d_len.as<uint32_t>(), total, d_lo.as<uint32_t>(),
+                                           d_hi.as<uint32_t>(), d_last.as<uint8_t>(), d_cnt.as<uint32_t>());
+    GB_CHK(d_first.alloc(first.size() * 8));
+    GB_CHK(hipMemcpy(d_first.p, first.data(), first.size() * 8, hipMemcpyHostToDevice));
+    const bool have_head = path_head.size() >= paths.size(), have_tail = path_tail.size() >= paths.size();
+    if (have_head) { GB_CHK(d_head.alloc(paths.size() * 4)); GB_CHK(hipMemcpy(d_head.p, path_head.data(), paths.size() * 4, hipMemcpyHostToDevice)); }
+    if (have_tail) { GB_CHK(d_tail.alloc(paths.size() * 4)); GB_CHK(hipMemcpy(d_tail.p, path_tail.data(), paths.size() * 4, hipMemcpyHostToDevice)); }
+    k_steps_ends<<<grid_for(paths.size()), 256>>>(d_first.as<uint64_t>(), paths.size(), have_head ? d_head.as<uint32_t>() : nullptr,
+                                                  have_tail ? d_tail.as<uint32_t>() : nullptr, d_step_node.as<uint32_t>(),
+                                                  d_len.as<uint32_t>(), d_lo.as<uint32_t>(), d_hi.as<uint32_t>(), d_last.as<uint8_t>());
+  }
+  int st = scan_u32(d_cnt.as<uint32_t>(), d_at_off.as<uint32_t>(), n + 1, true, tmp, tmp_cap, err);
+  if (st != PSIGPU_OK) return st;
+  GB_CHK(d_at.alloc((total + 1) * 4));
+  if (total) {
+    // a stable sort of the step numbers by node: a node's steps come out ascending
+    GB_CHK(d_idx.alloc(total * 4)); GB_CHK(d_keys_out.alloc(total * 4));
+    k_iota_u32<<<grid_for(total), 256>>>(d_idx.as<uint32_t>(), total);
+    unsigned bits = 1;
+    while (bits < 32 && (1ull << bits) < n) ++bits;
+    st = sort_pairs<uint32_t>(d_step_node.as<uint32_t>(), d_keys_out.as<uint32_t>(), d_idx.as<uint32_t>(), d_at.as<uint32_t>(), total, bits,
+                              tmp, tmp_cap, err);
+    if (st != PSIGPU_OK) return st;
+    d_idx.drop(); d_keys_out.drop();
+  }
+  StepGraph sg = { d_edge_off.as<uint64_t>(), d_edge_to.as<uint32_t>(), d_len.as<uint32_t>(), d_child.as<uint32_t>(),
+                   d_step_node.as<uint32_t>(), d_lo.as<uint32_t>(), d_hi.as<uint32_t>(), d_last.as<uint8_t>(),
+                   d_at_off.as<uint32_t>(), d_at.as<uint32_t>(), n, k, step };
+  GB_CHK(d_lcnt.alloc((n + 1) * 4)); GB_CHK(d_lfirst.alloc((n + 1) * 4));
+  GB_CHK(hipMemset(d_flag.p, 0, 4));
+  k_steps_loci_count<<<grid_for(n), 256>>>(sg, d_lcnt.as<uint32_t>(), d_flag.as<uint32_t>());
+  uint32_t n_hard = 0;
+  GB_CHK(hipMemcpy(&n_hard, d_flag.p, 4, hipMemcpyDeviceToHost));
+  if (n_hard) { *n_hard_out = n_hard; return PSIGPU_OK; }
+  GB_CHK(hipMemset(d_lcnt.as<uint32_t>() + n, 0, 4));
+  st = scan_u32(d_lcnt.as<uint32_t>(), d_lfirst.as<uint32_t>(), n + 1, true, tmp, tmp_cap, err);
+  if (st != PSIGPU_OK) return st;
+  uint32_t total_loci = 0;
+  GB_CHK(hipMemcpy(&total_loci, d_lfirst.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
+  resize_populated(loci_node, total_loci);
+  resize_populated(loci_off, total_loci);
+  if (total_loci) {
+    GB_CHK(d_out_n.alloc((size_t)total_loci * 4)); GB_CHK(d_out_o.alloc((size_t)total_loci * 4));
+    k_steps_loci_fill<<<grid_for(n), 256>>>(sg, d_lfirst.as<uint32_t>(), d_lcnt.as<uint32_t>(), d_out_n.as<uint32_t>(),
+                                           d_out_o.as<uint32_t>());
+    GB_CHK(download(loci_node.data(), d_out_n.p, (size_t)total_loci * 4));
+    GB_CHK(download(loci_off.data(), d_out_o.p, (size_t)total_loci * 4));
   }
   GB_CHK(hipDeviceSynchronize());
   return PSIGPU_OK;

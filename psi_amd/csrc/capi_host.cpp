@@ -13,6 +13,7 @@
 #endif
 
 #include "host.hpp"
+#include "loci_steps.hpp"
 #include "sais.hpp"
 
 using namespace psigpu;
@@ -300,6 +301,72 @@ int psigpu_index_matches(const psigpu_index* h, const psigpu_graph* g, uint32_t 
 }
 
 uint32_t psigpu_index_locus_step(const psigpu_index* h) { return h ? h->x.locus_step : 0; }
+
+// Test hook (not part of include/psi_gpu.h): the starting loci of the index's paths by the routine the DEVICE runs for
+// trimmed / many / non-simple paths (loci_steps.hpp, build_gpu.hip k_steps_loci_*), run here on the host over structures
+// made the way the kernels make them.  Returns the number of loci (written to out_node / out_off while they fit `cap`),
+// -1 when a node is beyond the routine's per-thread pool (the device build then takes the host routine), -2 on bad arguments.
+int64_t psigpu_debug_loci_by_steps(const psigpu_graph* gh, const psigpu_index* h, uint32_t locus_step, uint32_t* out_node,
+                                   uint32_t* out_off, uint64_t cap)
+{
+  if (!gh || !h) return -2;
+  const Graph& g = gh->g;
+  const Index& x = h->x;
+  if (locus_step == 0) locus_step = 1;
+  const uint64_t n = g.n_nodes();
+  const uint32_t k = x.k;
+  std::vector<uint32_t> len(n), reach(n), child(n, 0);
+  for (uint64_t v = 0; v < n; ++v) { len[v] = (uint32_t)g.node_len((uint32_t)v); reach[v] = std::min<uint32_t>(k, len[v]); }
+  for (bool changed = true; changed;) {
+    changed = false;
+    for (uint64_t v = n; v-- > 0;) {
+      uint32_t best = 0;
+      for (uint64_t e = g.edge_off[v]; e < g.edge_off[v + 1]; ++e) best = std::max(best, reach[g.edge_to[e]]);
+      child[v] = best;
+      const uint32_t r = (uint32_t)std::min<uint64_t>(k, (uint64_t)len[v] + best);
+      if (r > reach[v]) { reach[v] = r; changed = true; }
+    }
+  }
+  std::vector<uint64_t> first(x.paths.size() + 1, 0);
+  for (size_t p = 0; p < x.paths.size(); ++p) first[p + 1] = first[p] + x.paths[p].size();
+  const uint64_t total = first.back();
+  std::vector<uint32_t> step_node(total + 1), lo(total + 1), hi(total + 1), at_off(n + 1, 0), at(total + 1);
+  std::vector<uint8_t> last(total + 1, 0);
+  for (size_t p = 0; p < x.paths.size(); ++p)
+    for (size_t i = 0; i < x.paths[p].size(); ++i) {
+      const uint64_t s = first[p] + i;
+      step_node[s] = x.paths[p][i]; lo[s] = 0; hi[s] = len[step_node[s]];
+    }
+  for (size_t p = 0; p < x.paths.size(); ++p) {
+    if (x.paths[p].empty()) continue;
+    const uint64_t s0 = first[p], s1 = first[p + 1] - 1;
+    if (x.path_head.size() >= x.paths.size()) lo[s0] = std::min(len[step_node[s0]], x.path_head[p]);
+    if (x.path_tail.size() >= x.paths.size() && x.path_tail[p]) hi[s1] = std::min(len[step_node[s1]], x.path_tail[p]);
+    last[s1] = 1;
+  }
+  for (uint64_t s = 0; s < total; ++s) ++at_off[step_node[s] + 1];
+  for (uint64_t v = 0; v < n; ++v) at_off[v + 1] += at_off[v];
+  {
+    std::vector<uint32_t> fill(at_off.begin(), at_off.end() - 1);
+    for (uint64_t s = 0; s < total; ++s) at[fill[step_node[s]]++] = (uint32_t)s;      // (in step order: ascending per node)
+  }
+  std::vector<uint64_t> edge_off(g.edge_off.begin(), g.edge_off.end());
+  StepGraph sg = { edge_off.data(), g.edge_to.data(), len.data(), child.data(), step_node.data(), lo.data(), hi.data(), last.data(),
+                   at_off.data(), at.data(), n, k, locus_step };
+  uint64_t count = 0;
+  std::vector<uint32_t> bn(1 << 16), bo(1 << 16);
+  for (uint64_t v = 0; v < n; ++v) {
+    bool hard = false;
+    const uint32_t c = steps_loci_of_node(sg, v, nullptr, nullptr, &hard);
+    if (hard) return -1;
+    if (c == 0) continue;
+    if (c > bn.size()) { bn.resize(c); bo.resize(c); }
+    steps_loci_of_node(sg, v, bn.data(), bo.data(), &hard);
+    for (uint32_t i = 0; i < c; ++i, ++count)
+      if (count < cap && out_node && out_off) { out_node[count] = bn[i]; out_off[count] = bo[i]; }
+  }
+  return (int64_t)count;
+}
 
 // The starting loci for another locus step, recomputed from the index's own paths and trims: nothing that
 // lies beside the index file is trusted for this (a `<prefix>_loci_e<E>l<K>` file carries no graph

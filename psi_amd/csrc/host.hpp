@@ -144,6 +144,11 @@ int gpu_build_fm(const std::vector<uint8_t>& T, uint32_t sa_rate, uint32_t q, in
 // build_gpu.hip: starting loci on the device, same result as find_starting_loci()
 int gpu_find_starting_loci(const Graph& g, const std::vector<std::vector<uint32_t>>& paths, uint32_t k, uint32_t step,
                            int device, std::vector<uint32_t>& loci_node, std::vector<uint32_t>& loci_off, std::string* err);
+// ... for any set of paths (trimmed / patches, more than 64, nodes visited twice); *n_hard != 0: left to the host
+int gpu_find_starting_loci_steps(const Graph& g, const std::vector<std::vector<uint32_t>>& paths,
+                                 const std::vector<uint32_t>& path_head, const std::vector<uint32_t>& path_tail,
+                                 uint32_t k, uint32_t step, int device, std::vector<uint32_t>& loci_node,
+                                 std::vector<uint32_t>& loci_off, uint64_t* n_hard, std::string* err);
 int gpu_sort_pairs_u64(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, uint64_t n,
                        unsigned end_bit, std::string* err);
 int gpu_running_max_u64(uint64_t* data, uint64_t n, std::string* err);

@@ -708,6 +708,15 @@ Index* build_index(const Graph& g, const psigpu_index_opts& opts,
   if (opts.build_on_device && bits_suffice) {
     int st = gpu_find_starting_loci(g, paths, k, step, (int)opts.build_on_device - 1, x->loci_node, x->loci_off, err);
     if (st != PSIGPU_OK) { *status = st; delete x; return nullptr; }
+  } else if (opts.build_on_device && !getenv("PSIGPU_HOST_LOCI")) {
+    // trimmed paths (patches), many paths, paths that come back to a node: coverage by path STEPS, on the device as on the
+    // host (round 5); a node with more steps or longer candidate lists than a thread's pool holds sends the lot to the host
+    uint64_t n_hard = 0;
+    int st = gpu_find_starting_loci_steps(g, paths, x->path_head, x->path_tail, k, step, (int)opts.build_on_device - 1, x->loci_node,
+                                          x->loci_off, &n_hard, err);
+    if (st != PSIGPU_OK) { *status = st; delete x; return nullptr; }
+    if (trace) fprintf(stderr, "[psigpu]   starting loci by path steps on the device: %llu node(s) left to the host\n", (unsigned long long)n_hard);
+    if (n_hard) find_starting_loci(g, paths, x->path_head, x->path_tail, k, step, x->loci_node, x->loci_off);
   } else {
     find_starting_loci(g, paths, x->path_head, x->path_tail, k, step, x->loci_node, x->loci_off);
   }

@@ -71,6 +71,46 @@ def test_device_starting_loci_equal_host(seed):
             assert (host.loci[0] == dev.loci[0]).all() and (host.loci[1] == dev.loci[1]).all()
 
 
+def test_device_starting_loci_of_patched_paths(monkeypatch, capfd):
+    """Starting loci of TRIMMED paths (psikt's default: patches with a context), of more than 64 paths and of paths that
+    come back to a node, found on the device by path steps (round 5: k_steps_loci_*) -- the host routine's own scheme --
+    with the same result in the same order; the device routine is the one that ran (it says so under PSIGPU_TRACE)."""
+    monkeypatch.setenv('PSIGPU_TRACE', '1')
+    said = 'starting loci by path steps on the device: 0 node(s) left to the host'
+    cases = []
+    for name in ('x.gfa', 'm.gfa', 'multi.gfa', 'tiny.gfa'):
+        g = psi_amd.Graph.load(os.path.join(REF, name))
+        for k, npaths, context, step in ((21, 4, 0, 1), (21, 3, 26, 1), (12, 5, 12, 2), (31, 2, 36, 1), (10, 8, 11, 3)):
+            cases.append((g, k, npaths, context, step))
+    for seed in (3, 4):
+        nid, lo, lab, eo, et, ref = synth.bubble_graph(40_000, seed=seed)
+        g = psi_amd.Graph.from_csr(nid, lo, lab, eo, et, paths=[ref])
+        cases += [(g, 21, 3, 0, 1), (g, 16, 6, 21, 2)]
+    for g, k, npaths, context, step in cases:
+        host = psi_amd.PathIndex.build(g, k, npaths, step=step, rng_seed=k, patched=True, context=context)
+        capfd.readouterr()
+        dev = psi_amd.PathIndex.build(g, k, npaths, step=step, rng_seed=k, patched=True, context=context, device=0)
+        assert said in capfd.readouterr().err, (k, npaths, context)
+        assert host.trims() == dev.trims() and [a.tolist() for a in host.paths()] == [a.tolist() for a in dev.paths()]
+        hn, ho = host.loci
+        dn, do = dev.loci
+        assert len(hn) == len(dn) and (hn == dn).all() and (ho == do).all(), (k, npaths, context, step)
+    # 70 full paths (more than the 64 coverage bits of the other device routine) and a path that goes round a cycle
+    nid, lo, lab, eo, et, ref = synth.layered_graph(300, max_width=4, max_len=7, seed=1)
+    g = psi_amd.Graph.from_csr(nid, lo, lab, eo, et, paths=[ref])
+    # (seventy candidate steps per node and level: the lists may pass a thread's pool -- then the host routine answers, and says so)
+    host = psi_amd.PathIndex.build(g, 15, 70, rng_seed=2)
+    capfd.readouterr()
+    dev = psi_amd.PathIndex.build(g, 15, 70, rng_seed=2, device=0)
+    assert 'starting loci by path steps on the device' in capfd.readouterr().err
+    assert (host.loci[0] == dev.loci[0]).all() and (host.loci[1] == dev.loci[1]).all()
+    # the host routine on request
+    monkeypatch.setenv('PSIGPU_HOST_LOCI', '1')
+    capfd.readouterr()
+    dev2 = psi_amd.PathIndex.build(g, 15, 70, rng_seed=2, device=0)
+    assert 'by path steps' not in capfd.readouterr().err and (dev2.loci[0] == host.loci[0]).all()
+
+
 def test_device_build_repeats_and_n_runs():
     """identical paths (LCP = whole path: many doubling rounds), N runs, separators"""
     lab = (b'ACGTTGCAACGTTGCA' * 40) + b'NNNN' + (b'GATTACA' * 30) + b'N' + b'ACGTTGCAACGTTGCA' * 10

@@ -1009,3 +1009,44 @@ def test_pack_reads_words_and_mask():
     clean = np.frombuffer(b'ACGT', np.uint8)[rng.integers(0, 4, size=4097)]
     words = np.zeros(4097 // 32 + 3, np.uint64)
     assert L.psigpu_pack_reads(clean.ctypes.data_as(C.c_void_p), 0, len(clean), psi_amd._ptr(words), None) == 0
+
+
+def test_device_loci_routine_on_the_host(ref_data):
+    """The per-node routine the DEVICE runs for the starting loci of trimmed / many / non-simple paths (loci_steps.hpp,
+    build_gpu.hip k_steps_loci_*) is plain C++: run here on the host (test hook psigpu_debug_loci_by_steps) over
+    structures made the way the kernels make them, it returns the loci of find_starting_loci -- which the tests above pin
+    to the brute-force definition -- node by node in the same order, or says that a node is beyond its per-thread pool
+    (cyclic random graphs: the device build then takes the host routine)."""
+    import ctypes as C
+    import random
+    L = psi_amd.lib()
+    L.psigpu_debug_loci_by_steps.restype = C.c_int64
+    L.psigpu_debug_loci_by_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
+
+    def by_steps(g, px, step):
+        n = L.psigpu_debug_loci_by_steps(g.h, px.h, step, None, None, 0)
+        if n < 0:
+            return n, None, None
+        a, b = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        assert L.psigpu_debug_loci_by_steps(g.h, px.h, step, psi_amd._ptr(a), psi_amd._ptr(b), n) == n
+        return n, a[:n], b[:n]
+
+    done = 0
+    for name, cases in (('x', ((21, 3, True, 0, 1), (21, 3, True, 26, 2), (12, 6, True, 12, 1), (31, 2, False, 0, 1))),
+                        ('m', ((21, 3, True, 26, 1), (16, 5, True, 0, 3), (21, 2, False, 0, 1))),
+                        ('tiny', ((8, 2, True, 8, 1), (8, 0, False, 0, 1)))):
+        b, g = _setup(ref_data, name)
+        for k, npaths, patched, ctx, step in cases:
+            px = psi_amd.PathIndex.build(g, k, npaths, step=step, rng_seed=k, patched=patched, context=ctx)
+            n, a, o = by_steps(g, px, step)
+            assert n == len(px.loci[0]) and (a == px.loci[0]).all() and (o == px.loci[1]).all(), (name, k, npaths, ctx)
+            done += 1
+    from psi_amd import synth
+    nid, lo, lab, eo, et, ref = synth.bubble_graph(20_000, seed=3)
+    g = psi_amd.Graph.from_csr(nid, lo, lab, eo, et, paths=[ref])
+    for k, npaths, ctx, step in ((21, 3, 0, 1), (16, 6, 21, 2)):
+        px = psi_amd.PathIndex.build(g, k, npaths, step=step, rng_seed=1, patched=True, context=ctx)
+        n, a, o = by_steps(g, px, step)
+        assert n == len(px.loci[0]) and (a == px.loci[0]).all() and (o == px.loci[1]).all()
+        done += 1
+    assert done == 11

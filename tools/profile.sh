@@ -62,3 +62,6 @@ series=""
 if "--series" in a: series=a[a.index("--series")+1]
 json.dump({"args":"$ARGS","mode":mode,"series":series,"unit":"bytes per step (FETCH_SIZE / WRITE_SIZE x 1024, summed over the dispatches of a step)","per_launch":tr}, open(out+"/traffic.json","w"), indent=1)
 PY
+# keep the summaries, drop the raw traces (gpurun merges at most 64 MiB back)
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
+du -sh $OUT | cut -f1
