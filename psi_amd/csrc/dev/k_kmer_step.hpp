@@ -186,7 +186,7 @@ k_kmer_step(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
   if (seed_key_out) {
 #pragma unroll
     for (int r = 0; r < KS_R; ++r)
-      if (have[r]) { seed_key_out[sd[r]] = key[r]; seed_info_out[sd[r]] = si[r]; }
+      if (have[r]) { seed_key_out[sd[r]] = key[r]; if (seed_info_out) seed_info_out[sd[r]] = si[r]; }      // (equal lengths: nobody reads them)
   }
   // ---- one probe per seed: every round's first load in flight before the first is looked at ----------------------------
   uint64_t h[KS_R];

@@ -32,6 +32,7 @@ struct TableView {
   const TableSlot* ht;                            // every bucket's region one after the other (k_sb_build)
   const uint64_t* boff; uint32_t n_wg, pb;        // bucket b: slots [2 boff[b n_wg], 2 boff[(b + 1) n_wg])
   const uint32_t* seed_next; const uint2* seed_info;
+  uint32_t spr = 0, step = 0;                     // equal read lengths (spr seeds per read): a seed's read and offset are its number divided, seed_info is not read
   const void* seed_wide;                          // two-word seeds: the k-mer of every seed (u128), else nullptr
   const uint32_t* pfx12;                          // 4^12-bit prefix bitmap (nullptr when k < 12)
   const uint32_t* pfx_bits; uint32_t pfx_len;     // prefix bitmap of the seeds, 4^pfx_len bits
@@ -107,7 +108,10 @@ process_done(const GraphView& g, const TableView& tb, const uint2* __restrict__ 
     if (has) {
       // (two-word seeds: the table is keyed by a fingerprint -- a seed counts only when its k-mer is the walk's)
       if constexpr (sizeof(KEY) > 8) has = reinterpret_cast<const u128*>(tb.seed_wide)[s] == want;
-      uint2 si = tb.seed_info[s]; rid = rec_offset + si.x; roff = si.y;
+      uint2 si;
+      if (tb.spr) { const uint32_t rd = s / tb.spr; si = make_uint2(rd, (s - rd * tb.spr) * tb.step); }      // (one random request less per hit)
+      else si = tb.seed_info[s];
+      rid = rec_offset + si.x; roff = si.y;
       nx = dup;                                   // then down the duplicate chain
       if (dup != NIL) dup = tb.seed_next[dup];
     }
