@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_PEAK_GBS = 63.0           # PCIe Gen5 x16, one direction (64 GT/s x 16 lanes, 128b/130b)
 BLOCK = 64                     # bytes per rank block / HBM sector
-PROFILE_ROUND = os.environ.get('PSI_PROFILE_ROUND', 'r04')
+PROFILE_ROUND = os.environ.get('PSI_PROFILE_ROUND', 'r05')
 TRAFFIC_FILES = {'kmer-table': '%s_k_traffic.json', 'locus-table': '%s_l_traffic.json', 'traverse': '%s_t_traffic.json',
                  # the fm-lf series (tools/profile.sh f1 / f2 / f3): locus-table mode with the LF kernels doing the work
                  'fm-lf/after_ftab': '%s_f1_traffic.json', 'fm-lf/no_ftab': '%s_f2_traffic.json',

@@ -44,11 +44,11 @@ import json
 # per STEP (one call of the pipeline = one k_seed_pack dispatch), not per dispatch: the traverser is launched
 # twice in a step -- the loci, then the few items of its spill queue -- and an average over the dispatches halves it
 calls={}
+# (a step = one dispatch of the seeding kernel: k_kmer_step since round 5 -- also in traverse mode -- or k_seed_pack; whichever
+# ran more often is the one of the timed steps, the other one belongs to a single set-up call)
 for k,c,v,n in rows:
-    if k.startswith("void k_seed_pack") or k.startswith("k_seed_pack"): calls[c]=n
-# (the default step is one kernel since round 5: a step = one k_kmer_step dispatch)
-for k,c,v,n in rows:
-    if c not in calls and (k.startswith("void k_kmer_step") or k.startswith("k_kmer_step")): calls[c]=n
+    if k.startswith("void k_seed_pack") or k.startswith("k_seed_pack") or k.startswith("void k_kmer_step") or k.startswith("k_kmer_step"):
+        calls[c]=max(calls.get(c,0),n)
 tr={}
 for k,c,v,n in rows:
     if c in ("FETCH_SIZE","WRITE_SIZE"):
