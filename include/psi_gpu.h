@@ -337,8 +337,9 @@ int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags);
  *   "no_ahead"        1: two-slot pipeline even when reads and offsets are pinned (no transfers queued ahead)
  *   "no_engine_copy"  1: every transfer through hipMemcpyAsync on the pipeline's streams instead of a named SDMA engine;
  *                     takes effect when set before the context's first host-entry call
- *   "wire"            bytes per record on the device-to-host link: 0 = the narrowest that fits (8, 16, 32), or 8 / 16 / 32 =
- *                     nothing narrower than that
+ *   "wire"            bytes per record on the device-to-host link: 0 = the narrowest that fits (5-7 packed, 8, 16, 32), or
+ *                     5 / 6 / 7 / 8 / 16 / 32 = nothing narrower than that
+ *   "widen_threads"   host threads that widen the wire records (0 = min(12, cores / 4)); before the context's first host-entry call
  *   "expected_calls"  PSIGPU_MODE_AUTO: how many chunks this finder will be asked (0 = unknown: assume many)
  *   "expected_seeds"  PSIGPU_MODE_AUTO: ... and how many seeds over all of them (0 = unknown)
  *   "no_lookahead"    1: every sub-batch of the host entry is synchronised before the next one's kernels are queued (rounds 1-3)
@@ -385,8 +386,10 @@ int psigpu_prepare(psigpu_ctx* ctx, uint32_t k);
  * chunk (sequence.hpp:1616).  Hits come back in library-owned pinned host memory.
  * This is SURVEY 8(d)'s timed region (H2D of the reads + kernels + D2H of the hits): the chunk
  * is cut into sub-batches that are pipelined over three streams, so the call costs about
- * max(bytes in, bytes out) / PCIe rate.  The records cross the link as 4 x u32 (node id - first id, node
- * offset, read id - the sub-batch's first, read offset) when the graph's ids are rank + constant, and are
+ * max(bytes in, bytes out) / PCIe rate.  When the graph's ids are rank + constant the records cross the link narrower
+ * than they are -- packed records of 5-7 bytes (blocks of 256 behind their first read id; read id relative to it, read
+ * offset in seed distances, node rank, node offset) for records in read order, else one 64-bit key, else 4 x u32; every
+ * field checked on the device, the next wider form when one does not fit -- and are
  * widened to psigpu_hit by host threads while the next sub-batch is in flight.  Reads held in pinned memory (psigpu_host_alloc) are
  * DMA'd in place; pageable reads are staged by a helper thread. */
 int psigpu_find_seeds(psigpu_ctx* ctx, const char* bases, const uint64_t* read_off,
@@ -529,7 +532,7 @@ typedef struct psigpu_counters {
   uint32_t search_launches, traverse_launches;
   uint32_t sorted_in_place;                    /* PSIGPU_SORT_UNIQUE: sub-batches whose hits, emitted seed by seed, only needed
                                                 * the hits of each seed put in order (no radix sort) */
-  uint32_t wire_bytes_per_hit;                 /* psigpu_find_seeds: bytes per record on the device-to-host link (8 or 16: packed, widened
+  uint32_t wire_bytes_per_hit;                 /* psigpu_find_seeds: bytes per record on the device-to-host link (5-8 or 16: packed, widened
                                                 * on the host; 32: as returned; the widest any sub-batch of the call used); 0 for the
                                                 * device-resident entry */
   uint64_t n_locate_steps;                     /* LF steps K2 walked from occurrences to sampled suffix-array rows (sa_rate > 1) */
