@@ -284,7 +284,7 @@ def slim_line(out, full_path=None):
                          'frac_by_traffic': (tb / (r_['avg_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb and r_.get('avg_launch_ms') else None}
         return b
     if 'traverse' in rbm:
-        routes['traverse'] = brief(rbm['traverse'], ('k_traverse', 'k_table_insert'))
+        routes['traverse'] = brief(rbm['traverse'], ('k_traverse', 'k_table_insert', 'k_kmer_step'))
         if 'fm_route' in rbm['traverse']:
             routes['traverse_fm_route'] = brief(rbm['traverse']['fm_route'], ('k_fm_search', 'k_fm_locate', 'k_traverse'))
     if 'locus-table' in rbm:
@@ -699,6 +699,8 @@ def main():
         kern, c, steps = res['kern'], res['c'], res['steps']
         ix = ix or px
         dom = kernel or max(kern, key=lambda n: kern[n])
+        if dom not in kern:
+            return None                          # (this mode did not run that kernel)
         avg_ms = kern[dom] / steps
         abytes = algorithmic_bytes(dom, c, k, int(ix.view.sa_rate), int(ix.view.ftab_len), implicit_info=bool(uni) and mode == 'kmer-table')
         achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -1151,7 +1153,9 @@ def main():
                 e['k_fm_locate'] = roofline_of(res, m, 'k_fm_locate')
             if m == 'traverse':
                 # paths: one probe of the table of their k-mers + the emit stream; loci: the chunk's seed table, the traverser
-                e['k_kmer_probe'] = roofline_of(res, m, 'k_kmer_probe')
+                # (round 5: the on-path phase is k_kmer_step -- seeding, probe and emission in one kernel -- unless PSIGPU_NO_FUSED)
+                pk = 'k_kmer_step' if 'k_kmer_step' in res['kern'] else 'k_kmer_probe'
+                e[pk] = roofline_of(res, m, pk)
                 e['k_fm_locate'] = roofline_of(res, m, 'k_fm_locate')
                 e['k_table_insert'] = roofline_of(res, m, 'k_table_insert')
                 e['k_traverse'] = roofline_of(res, m, 'k_traverse')
