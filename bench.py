@@ -249,7 +249,9 @@ def slim_line(out, full_path=None):
                               'device_ms_per_step': e2e.get('device_ms_per_step'),
                               'wire_bytes_per_hit': e2e.get('wire_bytes_per_hit'),
                               'ascii_ms_per_step': e2e.get('ascii_ms_per_step'),
-                              'what': 'psigpu_find_seeds_packed: H2D of packed reads + kernels + device sort-unique + D2H of the hits'}
+                              'first_calls_ms_per_step': e2e.get('first_calls_ms_per_step'),
+                              'what': 'psigpu_find_seeds_packed: H2D of packed reads + kernels + device sort-unique + D2H of the hits; '
+                                      'median of 100 calls after 400 untimed ones (first_calls: calls 3-22 of the series)'}
     mg = out.get('multi_gpu')
     if mg and mg.get('end_to_end_all_links'):
         line['value_end_to_end'] = mg['end_to_end_all_links'].get('value')
@@ -1007,24 +1009,26 @@ def main():
                 L.psigpu_free_hits(C.byref(hits))
             return (time.perf_counter() - t1) / reps, n_h
 
-        def host_entry_packed(src, flags, reps):
+        def host_entry_packed(src, flags, reps, warm=400):
             """psigpu_find_seeds_packed: reads as 2-bit words (+ a "not ACGT" bit per base when the chunk has any)"""
             calls = [(finder.ctx, psi_amd._ptr(pr.words), psi_amd._ptr(pr.mask), psi_amd._ptr(pr.off), args.reads, k, step,
                       rec_offset, flags, C.byref(hits)) for pr in src]
             n_h = 0
-            for i in range(2):
-                if L.psigpu_find_seeds_packed(*calls[i % nb]):
-                    raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
-                L.psigpu_free_hits(C.byref(hits))
+            # The call is ~1.5 ms of a dozen host threads, two copy engines and the link working together, and the box takes a
+            # second or two of back-to-back calls to get there (tools/e2e_packed.py, job 20: 2.7 ms over the first 15 calls of
+            # a process, 2.1 over the next 200, 1.5 from then on -- core clocks, link power states): a chunk stream is the
+            # steady state, so the calls are run until they have settled and THEN timed; what the first calls took is kept.
             ts = []
-            for i in range(reps):
+            for i in range(warm + reps):
                 t1 = time.perf_counter()
                 if L.psigpu_find_seeds_packed(*calls[i % nb]):
                     raise RuntimeError(L.psigpu_last_error(finder.ctx).decode())
                 n_h = hits.n
                 L.psigpu_free_hits(C.byref(hits))
                 ts.append(time.perf_counter() - t1)
-            return float(np.median(ts)), n_h, min(ts), max(ts)
+            first = ts[2:22]
+            ts = ts[warm:]
+            return float(np.median(ts)), n_h, min(ts), max(ts), float(np.median(first))
 
         pinned_src = [(p[0].array, p[1].array) for p in pin]
         pageable_src = [(np.ascontiguousarray(b), np.ascontiguousarray(o.astype(np.uint64))) for b, o in batches]
@@ -1035,7 +1039,7 @@ def main():
         t1 = time.perf_counter()
         psi_amd.PackedReads(batches[0][0], batches[0][1], pinned=False, threads=1)
         t_pack1 = time.perf_counter() - t1
-        t_pk, n_pk, t_pk_min, t_pk_max = host_entry_packed(packed_src, psi_amd.ALL | psi_amd.SORT_UNIQUE | uni, 20)
+        t_pk, n_pk, t_pk_min, t_pk_max, t_pk_first = host_entry_packed(packed_src, psi_amd.ALL | psi_amd.SORT_UNIQUE | uni, 100)
         c_e = finder.counters()
         t_su, n_su = host_entry(pinned_src, psi_amd.ALL | psi_amd.SORT_UNIQUE | uni, 10)
         c_a = finder.counters()
@@ -1049,12 +1053,12 @@ def main():
         bytes_out_ascii = float(c_a['wire_bytes_per_hit'] or 32) * n_su
         out['end_to_end'] = {
             'what': 'psigpu_find_seeds_packed: H2D of the reads (2-bit words, in pinned host memory) + kernels + sort-unique on '
-                    'the device + D2H of the hits (8-byte wire records, widened to the 32-byte records by host threads inside '
+                    'the device + D2H of the hits (packed wire records of 5-8 bytes, widened to the 32-byte records by host threads inside '
                     'the call): SURVEY 8(d) timed region; sub-batches pipelined over the two named copy engines and one compute '
-                    'stream; median of 20 calls',
+                    'stream; median of 100 calls after 400 untimed ones (the first calls of a process: first_calls_ms_per_step)',
             'reads_format': '2-bit packed (psigpu_find_seeds_packed); the ASCII entry (psigpu_find_seeds) is ascii_*',
             'value': c_e['n_seeds'] / t_pk, 'unit': 'seeds/s', 'ms_per_step': t_pk * 1e3,
-            'ms_per_step_min': t_pk_min * 1e3, 'ms_per_step_max': t_pk_max * 1e3,
+            'ms_per_step_min': t_pk_min * 1e3, 'ms_per_step_max': t_pk_max * 1e3, 'first_calls_ms_per_step': t_pk_first * 1e3,
             'hits_per_step_sort_unique': int(n_pk), 'hits_per_s': n_pk / t_pk,
             'same_record_count_as_ascii_entry': bool(n_pk == n_su),
             'ascii_ms_per_step': t_su * 1e3, 'ascii_seeds_per_s': c_a['n_seeds'] / t_su,
