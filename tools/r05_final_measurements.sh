@@ -1,5 +1,5 @@
 #!/bin/bash
-# job 19: the round's last measurements -- full GPU suite, the default bench run, the host entry end to end, psikt, profiles of the two
+# The round's last measurements (job 19 of 21 GPU jobs of round 5) -- full GPU suite, the default bench run, the host entry end to end, psikt, profiles of the two
 # modes whose kernels changed after job 17
 O=gpurun_out/r05; mkdir -p $O
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/j19_tests.log 2>&1; echo "tests rc $?"; tail -6 $O/j19_tests.log | cut -c1-300
