@@ -213,6 +213,14 @@ def main():
                                        np.cumsum([0] + [len(g.out[v]) for v in g.ids]),
                                        np.array([rank[t] for v in g.ids for t in g.out[v]], dtype=np.uint64))
                             print(' graph arrays unchanged:', [bool(np.array_equal(np.asarray(a), np.asarray(b))) for a, b in zip(arrays, arrays2)], flush=True)
+                            for nm_, a_, b_ in zip(('ids', 'label_off', 'labels', 'edge_off', 'edge_to'), arrays, arrays2):
+                                a_, b_ = np.asarray(a_), np.asarray(b_)
+                                if a_.shape == b_.shape and not np.array_equal(a_, b_):
+                                    d_ = np.flatnonzero(a_ != b_)
+                                    # (campaign c: the labels' bytes object had changed -- WHAT was written there says who wrote it)
+                                    print('  %s: %d of %d elements differ, first at %s; is %s, was %s; address of the buffer 0x%x; bytes around the first (is): %s'
+                                          % (nm_, len(d_), a_.size, d_[:8].tolist(), a_[d_[:16]].tolist(), b_[d_[:16]].tolist(), a_.ctypes.data,
+                                             a_.view(np.uint8)[max(0, int(d_[0]) * a_.itemsize - 32):int(d_[0]) * a_.itemsize + 96].tobytes().hex()), flush=True)
                             pxh = psi_amd.PathIndex.build(pg, k, npaths, **dict(bargs, device=None))
                             l1, l2 = px.loci, pxh.loci
                             same = bool(np.array_equal(l1[0], l2[0]) and np.array_equal(l1[1], l2[1]))
