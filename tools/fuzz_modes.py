@@ -42,8 +42,20 @@ def main():
         labels = ''.join(g.seq[v] for v in g.ids).encode()
         edge_off = np.cumsum([0] + [len(g.out[v]) for v in g.ids])
         edge_to = [rank[t] for v in g.ids for t in g.out[v]]
+        labels_at_top = bytes(bytearray(labels))          # (a copy of its own: campaign c found the ORIGINAL changed later on)
+
+        def labels_intact(where):
+            if labels == labels_at_top:
+                return
+            a_, b_ = np.frombuffer(labels, np.uint8), np.frombuffer(labels_at_top, np.uint8)
+            d_ = np.flatnonzero(a_ != b_)
+            print('LABELS CHANGED', seed, where, '%d of %d bytes differ, first at %s; is %s, was %s; buffer at 0x%x; bytes around the first (is): %s'
+                  % (len(d_), a_.size, d_[:8].tolist(), a_[d_[:16]].tolist(), b_[d_[:16]].tolist(), a_.ctypes.data,
+                     a_[max(0, int(d_[0]) - 32):int(d_[0]) + 96].tobytes().hex()), flush=True)
+            sys.exit(1)
         pg = psi_amd.Graph.from_csr(g.ids, label_off, labels, edge_off, edge_to,
                                     paths=[[rank[v] for v in g.paths[0][1]]])
+        labels_intact('after the graph object was made')
         for _ in range(2):
             k = rng.choice([3, 8, 12, 13, 16, 21, 25, 31, 31, 32, 40])      # (32, 40: two-word seeds)
             step = rng.choice([1, 2, k, k + 3])
@@ -53,7 +65,9 @@ def main():
             bargs = dict(rng_seed=seed, sa_rate=rng.choice([1, 1, 1, 2, 8]), ftab_len=rng.choice([0, 0, 4, psi_amd.NO_FTAB]),
                          device=rng.choice([None, 0]), patched=patched,
                          context=rng.choice([0, k, k + 1, k + 7]) if patched else 0)
+            labels_intact('before the index build (k %d)' % k)
             px = psi_amd.PathIndex.build(pg, k, npaths, **bargs)
+            labels_intact('after the index build (k %d, npaths %d, on %s)' % (k, npaths, bargs['device']))
             # (round 5) canaries: what the HOST holds of this index and of the inputs, as it is now -- compared again after every
             # finder run below.  The oracle-side disagreements of rounds 4-5 say that something a loaded process holds in host
             # memory changes under it; if it does, what the new bytes look like says who wrote them.
@@ -127,11 +141,14 @@ def main():
                     n_cases += 1
             for mode in ('kmer-table', 'locus-table', 'traverse'):
                 for cap in ((0,) if mode == 'traverse' else (0, 1, 3)):
+                    labels_intact('before the finder of mode %s cap %d' % (mode, cap))
                     f = psi_amd.SeedFinder(pg, k, mode=mode, walk_cap=cap)
                     if mode == 'traverse' and rng.random() < 0.5:
                         f.set_tuning(psi_amd.TUNE_NO_PATH_TABLE)        # the FM index on the paths instead of their k-mer table
                     f.set_path_index(px)
+                    labels_intact('after the finder of mode %s cap %d was loaded' % (mode, cap))
                     got = psi_amd.sort_unique(f.seeds_all(reads, step=step))
+                    labels_intact('after seeds_all of mode %s cap %d' % (mode, cap))
                     if not (got.shape == want.shape and (got == want).all()):
                         print('MISMATCH', seed, k, step, npaths, mode, cap, got.shape, want.shape, 'sa_rate', px.view.sa_rate, 'ftab', px.view.ftab_len,
                               'patched', patched, f.counters(), flush=True)

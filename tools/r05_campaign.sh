@@ -13,7 +13,7 @@ for arm in $ARMS; do
   mkdir -p $O/logs; mv gpurun_out/fuzz_${TAG}_r${r}${arm}_p*.log $O/logs/ 2>/dev/null
   ok=0; bad=0; sig=0; seeds=0
   for f in $O/logs/fuzz_${TAG}_r${r}${arm}_p*.log; do
-    if grep -q "MISMATCH\|HOST CANARY CHANGED" $f; then bad=$((bad+1)); fi
+    if grep -q "MISMATCH\|HOST CANARY CHANGED\|LABELS CHANGED" $f; then bad=$((bad+1)); fi
     if grep -q "fatal signal\|Segmentation\|core dumped\|double free\|Aborted" $f; then sig=$((sig+1)); fi
     if grep -q "Traceback" $f; then bad=$((bad+1)); fi
     s=$(grep -c "^seed" $f); seeds=$((seeds+s))
@@ -23,7 +23,7 @@ for arm in $ARMS; do
   echo "round $r arm $arm: procs $N seeds $seeds mismatch_or_error $bad signal_lines $sig exit_codes: $codes" | tee -a $O/summary.txt
   # keep only the logs of processes with something to say (the rest: their last lines)
   for f in $O/logs/fuzz_${TAG}_r${r}${arm}_p*.log; do
-    if grep -q "MISMATCH\|HOST CANARY CHANGED\|fatal signal\|Segmentation\|Traceback\|double free\|Aborted" $f; then grep -v "^seed" $f > $f.keep; fi
+    if grep -q "MISMATCH\|HOST CANARY CHANGED\|LABELS CHANGED\|fatal signal\|Segmentation\|Traceback\|double free\|Aborted" $f; then grep -v "^seed" $f > $f.keep; fi
     tail -n 2 $f > $f.tail; rm -f $f
   done
 done
