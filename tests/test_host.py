@@ -1050,3 +1050,21 @@ def test_device_loci_routine_on_the_host(ref_data):
         assert n == len(px.loci[0]) and (a == px.loci[0]).all() and (o == px.loci[1]).all()
         done += 1
     assert done == 11
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """Every structure the library fills through a pointer has the size include/psi_gpu.h gives it in its ctypes mirror: a
+    mirror that is too small is a heap overflow in the caller on every call (psigpu_get_counters, psigpu_index_view_get ...)."""
+    import ctypes as C
+    import subprocess
+    names = {'psigpu_counters': psi_amd.Counters, 'psigpu_graph_view': psi_amd.GraphView, 'psigpu_index_view': psi_amd.IndexView,
+             'psigpu_index_opts': psi_amd.IndexOpts, 'psigpu_hits': psi_amd.Hits, 'psigpu_hit': psi_amd.Hit,
+             'psigpu_mem_hit': psi_amd.MemHit, 'psigpu_mems': psi_amd.Mems}
+    src = tmp_path / 'sizes.c'
+    src.write_text('#include <stdio.h>\n#include "psi_gpu.h"\nint main(void) {\n' +
+                   ''.join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) + '  return 0;\n}\n')
+    exe = str(tmp_path / 'sizes')
+    subprocess.check_call(['gcc', '-I' + os.path.join(ROOT, 'include'), str(src), '-o', exe])
+    got = dict(l.split() for l in subprocess.check_output([exe]).decode().splitlines())
+    for n, mirror in names.items():
+        assert int(got[n]) == C.sizeof(mirror), n
