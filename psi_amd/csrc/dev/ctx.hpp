@@ -200,6 +200,40 @@ struct HsaGlobals {
   void give(hsa_signal_t sg) { std::lock_guard<std::mutex> lk(mu); idle.push_back(sg); }
 };
 HsaGlobals g_hsa;
+
+// The two ends of the host entry's engine copies (hsa_amd_memory_async_copy_on_engine) are not freed when their context goes
+// or when a call regrows them, but a second later.  HIP knows nothing of those copies, and ROCr retires a finished copy on
+// a thread of its own some time AFTER the completion signal reached 0 -- touching its bookkeeping of both allocations.  The
+// load campaigns of round 5 caught what a free in that window does: one word decremented and a flag
+// cleared in a small host object that had already gone back to the allocator and on to somebody else.  (The signals
+// themselves are never destroyed for the same reason, above.)
+struct LateFree {
+  struct Item { void* p; bool host; std::chrono::steady_clock::time_point t; };
+  std::mutex mu;
+  std::vector<Item> q;
+  void add(void* p, bool host)
+  {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    q.push_back(Item{ p, host, std::chrono::steady_clock::now() });
+  }
+  void sweep()                                   // (called when a context is made or goes: what has waited long enough is freed)
+  {
+    std::vector<Item> due;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      const auto now = std::chrono::steady_clock::now();
+      size_t keep = 0;
+      for (auto& it : q) {
+        if (now - it.t > std::chrono::seconds(1)) due.push_back(it);
+        else q[keep++] = it;
+      }
+      q.resize(keep);
+    }
+    for (auto& it : due) { if (it.host) (void)hipHostFree(it.p); else (void)hipFree(it.p); }
+  }
+};
+LateFree g_late;
 }  // namespace
 
 // Pinned host buffers for returned hits are recycled process-wide: hipHostMalloc of a few
