@@ -266,7 +266,7 @@ struct PinnedPool {
         free_list.push_back(live[i]);
         live.erase(live.begin() + i);
         // keep at most two idle buffers
-        while (free_list.size() > 2) { (void)hipHostFree(free_list.front().first); free_list.erase(free_list.begin()); }
+        while (free_list.size() > 2) { g_late.add(free_list.front().first, true); free_list.erase(free_list.begin()); }      // (32-byte wire: a copy's landing buffer)
         return;
       }
     (void)hipHostFree(p);
