@@ -214,6 +214,8 @@ struct LateFree {
   void add(void* p, bool host)
   {
     if (!p) return;
+    // (PSIGPU_AB_EARLY_FREE=1: at once, as until round 5 -- the other arm of the campaign that is to show whether this is it)
+    if (getenv("PSIGPU_AB_EARLY_FREE")) { if (host) (void)hipHostFree(p); else (void)hipFree(p); return; }
     std::lock_guard<std::mutex> lk(mu);
     q.push_back(Item{ p, host, std::chrono::steady_clock::now() });
   }

@@ -8,7 +8,10 @@ O=gpurun_out/r05/camp_$TAG; mkdir -p $O
 r=0
 for arm in $ARMS; do
   r=$((r+1)); first=$((F + r*100000))
-  if [ "$arm" = "B" ]; then export PSIGPU_AB_LOAD_HOLE=1; else unset PSIGPU_AB_LOAD_HOLE; fi
+  # (arm C, for the next campaign: arm B with the buffers of the engine copies freed at once, as until the end of round 5)
+  unset PSIGPU_AB_LOAD_HOLE PSIGPU_AB_EARLY_FREE
+  if [ "$arm" = "B" ]; then export PSIGPU_AB_LOAD_HOLE=1; fi
+  if [ "$arm" = "C" ]; then export PSIGPU_AB_LOAD_HOLE=1 PSIGPU_AB_EARLY_FREE=1; fi
   TAG=${TAG}_r${r}${arm} FUZZ_TIMEOUT=${FUZZ_TIMEOUT:-400} bash tools/fuzz_par.sh $first $N 100000 > $O/round_${r}${arm}.out 2>&1
   mkdir -p $O/logs; mv gpurun_out/fuzz_${TAG}_r${r}${arm}_p*.log $O/logs/ 2>/dev/null
   ok=0; bad=0; sig=0; seeds=0
