@@ -964,6 +964,17 @@ def test_bench_line_is_small():
     text = json.dumps(bench.slim_line(fat), allow_nan=False)
     assert len(text) <= bench.LINE_LIMIT
     assert all(k in json.loads(text) for k in ('value', 'roofline', 'cpu_baseline'))
+    # round 5's own full report (the traverse route's on-path kernel is k_kmer_step; the host entry timed in its steady state,
+    # what its first calls took beside it)
+    full5 = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_final_full.json')))
+    line5 = bench.slim_line(full5, 'gpurun_out/bench_full.json')
+    text5 = json.dumps(line5, allow_nan=False)
+    assert len(text5) <= bench.LINE_LIMIT
+    assert line5['end_to_end']['first_calls_ms_per_step'] >= line5['end_to_end']['ms_per_step'] > 0
+    assert line5['end_to_end']['wire_bytes_per_hit'] == 5
+    assert 'k_kmer_step' in line5['routes']['traverse'] and line5['roofline']['kernel'] == 'k_kmer_step'
+    assert 0 < line5['roofline']['frac'] <= 1 and all(0 < (r_[k_]['frac'] or 1) <= 1 for r_ in line5['routes'].values()
+                                                         for k_ in r_ if isinstance(r_[k_], dict))
     # the LF kernel's algorithmic bytes count one rank block per LF step: no series prices itself above the peak
     c = {'n_seeds_valid': 7_000_000, 'n_lf_steps': 7_000_000 * 21, 'n_rows_verified': 0}
     assert bench.algorithmic_bytes('k_fm_search', c, 21, 1, 0) == 64.0 * 7_000_000 * 21
