@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSIGPU_ABI_VERSION 7
+#define PSIGPU_ABI_VERSION 8
 #define PSIGPU_MAX_SEED_LEN 63u   /* psikt takes any -l (src/psikt.cpp:327); seeds are 2-bit packed into one 64-bit word up
                                     to 31 bases and into two words from 32 to 63 */
 #define PSIGPU_MAX_TABLE_SEED_LEN 31u   /* the tabulating query modes (k-mer table, locus table) hold one-word k-mers: longer
@@ -457,6 +457,16 @@ void psigpu_free_mems(psigpu_mems* mems);
  * engine reads it in place.  NULL when no GPU is present. */
 void* psigpu_host_alloc(uint64_t bytes);
 void psigpu_host_free(void* p);
+
+/* (ABI 8) The lifetime rule of the host entry's transfer buffers.  The reference's chunk loop (src/psikt.cpp:190-208) owns its
+ * reads and its output for as long as it likes; here both ends of every raw copy-engine transfer (staging and landing buffers,
+ * memory from psigpu_host_alloc, returned hit arrays) belong to a pool that lives as long as the process: psigpu_destroy,
+ * psigpu_host_free, psigpu_free_hits and a regrowing call hand them back to the pool, never straight to the driver, and the
+ * pool returns memory to the driver only when more than a budget sits idle and only after every engine queue it was used on
+ * has consumed a marker submitted after the buffer came back.  out[0..7] = buffers allocated so far, takes served from the
+ * pool, buffers returned to the driver, queue drains run, idle device bytes, idle host bytes, buffers idle, buffers in use.
+ * `trim_all` != 0 first returns every idle buffer to the driver (by the rule above). */
+void psigpu_copy_pool_stats(uint64_t out[8], int trim_all);
 
 /* Same with the chunk already resident in HBM and the hits left there (n_bases must be the
  * total length of the reads, d_read_off[n_reads]): `d_bases` and

@@ -166,6 +166,7 @@ ABI = [
     ('psigpu_gather_hits', C.c_int, [_P, _P, C.c_uint64, C.c_int, C.POINTER(_P), _U64P, _P]),
     ('psigpu_host_alloc', _P, [C.c_uint64]),
     ('psigpu_host_free', None, [_P]),
+    ('psigpu_copy_pool_stats', None, [C.POINTER(C.c_uint64), C.c_int]),
 ]
 
 _lib = None
@@ -226,6 +227,14 @@ class PinnedArray:
             self.array = None
             _lib.psigpu_host_free(self.ptr)
             self.ptr = None
+
+
+def copy_pool_stats(trim_all: bool = False) -> dict:
+    """The process-wide pool of copy-engine transfer buffers (psigpu_copy_pool_stats, ABI 8)."""
+    out = (C.c_uint64 * 8)()
+    lib().psigpu_copy_pool_stats(out, 1 if trim_all else 0)
+    keys = ('allocated', 'reused', 'returned_to_driver', 'queue_drains', 'idle_device_bytes', 'idle_host_bytes', 'idle', 'in_use')
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def pinned_copy(a: np.ndarray) -> PinnedArray:

@@ -88,11 +88,11 @@ struct psigpu_ctx {
   // host entry point: sub-batches of a chunk pipelined through two slots (H2D | kernels | D2H)
   struct Slot {
     DevBuf bases, off, mask;                     // (mask: packed reads, the sub-batch's "not ACGT" bits)
-    void* h_stage = nullptr; size_t h_cap = 0;   // pinned staging: rebased read offsets, and the bases of pageable callers
+    HostEnd h_stage;                             // pinned staging: rebased read offsets, and the bases of pageable callers
     void* h_stage_dev = nullptr;                 // the same memory as the device addresses it
     hipEvent_t in_ready = nullptr, out_done = nullptr;
     DevBuf d_wire;                               // 16-byte wire records of the slot's sub-batch (k_hits_wire16)
-    void* h_wire = nullptr; size_t h_wire_cap = 0;   // pinned: where they land on the host, before they are widened
+    HostEnd h_wire;                              // pinned: where they land on the host, before they are widened
   } slot[2];
   DevBuf w_hits_alt;
   hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
@@ -119,7 +119,7 @@ struct psigpu_ctx {
   struct FastSlot {
     DevBuf hits, off, wire;
     void* h = nullptr; void* h_dev = nullptr;
-    void* h_wire = nullptr; size_t h_wire_cap = 0;
+    HostEnd h_wire;
     hipEvent_t begin = nullptr, done = nullptr;
   } fast[N_FAST];
   bool opt_no_lookahead = false;
@@ -201,78 +201,48 @@ struct HsaGlobals {
 };
 HsaGlobals g_hsa;
 
-// The two ends of the host entry's engine copies (hsa_amd_memory_async_copy_on_engine) are not freed when their context goes
-// or when a call regrows them, but a second later.  HIP knows nothing of those copies, and ROCr retires a finished copy on
-// a thread of its own some time AFTER the completion signal reached 0 -- touching its bookkeeping of both allocations.  The
-// load campaigns of round 5 caught what a free in that window does: one word decremented and a flag
-// cleared in a small host object that had already gone back to the allocator and on to somebody else.  (The signals
-// themselves are never destroyed for the same reason, above.)
-struct LateFree {
-  struct Item { void* p; bool host; std::chrono::steady_clock::time_point t; };
-  std::mutex mu;
-  std::vector<Item> q;
-  void add(void* p, bool host)
-  {
-    if (!p) return;
-    // (PSIGPU_AB_EARLY_FREE=1: at once, as until round 5 -- the other arm of the campaign that is to show whether this is it)
-    if (getenv("PSIGPU_AB_EARLY_FREE")) { if (host) (void)hipHostFree(p); else (void)hipFree(p); return; }
-    std::lock_guard<std::mutex> lk(mu);
-    q.push_back(Item{ p, host, std::chrono::steady_clock::now() });
-  }
-  void sweep()                                   // (called when a context is made or goes: what has waited long enough is freed)
-  {
-    std::vector<Item> due;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      const auto now = std::chrono::steady_clock::now();
-      size_t keep = 0;
-      for (auto& it : q) {
-        if (now - it.t > std::chrono::seconds(1)) due.push_back(it);
-        else q[keep++] = it;
-      }
-      q.resize(keep);
-    }
-    for (auto& it : due) { if (it.host) (void)hipHostFree(it.p); else (void)hipFree(it.p); }
-  }
+// The engines the host entry has used, per device (engine_copy_init fills this in): what EndPool::trim drains before
+// memory that was an end of an engine copy leaves the process -- see dev/devbuf.hpp, "the lifetime rule".
+struct EngineSet {
+  int device; hsa_agent_t gpu, cpu; uint32_t eng[3];      // host -> device, device -> host (two)
+  void* d_mark; void* h_mark;                             // 64 bytes each, never freed: the marker copies' ends
 };
-LateFree g_late;
+std::mutex g_engines_mu;
+std::vector<EngineSet> g_engines;
 }  // namespace
 
-// Pinned host buffers for returned hits are recycled process-wide: hipHostMalloc of a few
-// hundred MB costs tens of milliseconds, a chunk loop would pay it every call.
+static void engines_quiesce()
+{
+  std::vector<EngineSet> sets;
+  { std::lock_guard<std::mutex> lk(g_engines_mu); sets = g_engines; }
+  for (const EngineSet& es : sets) {
+    for (int i = 0; i < 3; ++i) {
+      if (!es.eng[i]) continue;
+      hsa_signal_t sg;
+      if (!g_hsa.take(&sg)) continue;
+      hsa_signal_store_relaxed(sg, 1);
+      const bool in = i == 0;
+      const hsa_status_t st = hsa_amd_memory_async_copy_on_engine(in ? es.d_mark : es.h_mark, in ? es.gpu : es.cpu, in ? es.h_mark : es.d_mark,
+                                                                  in ? es.cpu : es.gpu, 64, 0, nullptr, sg, (hsa_amd_sdma_engine_id_t)es.eng[i], true);
+      if (st == HSA_STATUS_SUCCESS)
+        while (hsa_signal_wait_scacquire(sg, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) { }
+      else hsa_signal_store_relaxed(sg, 0);
+      g_hsa.give(sg);
+    }
+  }
+}
+
+// Pinned host buffers for returned hits: they are landing buffers of engine copies (32-byte wire) and what the widening
+// threads write into -- from the process-wide pool of copy ends and back to it (hipHostMalloc of a few hundred MB costs tens
+// of milliseconds, a chunk loop would pay it every call).
 namespace {
 struct PinnedPool {
-  std::mutex mu;
-  std::vector<std::pair<void*, size_t>> free_list, live;
   void* get(size_t bytes)
   {
-    std::lock_guard<std::mutex> lk(mu);
-    for (size_t i = 0; i < free_list.size(); ++i)
-      if (free_list[i].second >= bytes) {
-        auto b = free_list[i];
-        free_list.erase(free_list.begin() + i);
-        live.push_back(b);
-        return b.first;
-      }
-    void* p = nullptr;
-    size_t want = bytes + bytes / 8 + 4096;
-    if (hipHostMalloc(&p, want, hipHostMallocMapped) != hipSuccess) return nullptr;
-    live.emplace_back(p, want);
-    return p;
+    size_t cap = 0;
+    return g_ends.take(true, bytes + bytes / 8 + 4096, hipHostMallocMapped, 0, &cap);
   }
-  void put(void* p)
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    for (size_t i = 0; i < live.size(); ++i)
-      if (live[i].first == p) {
-        free_list.push_back(live[i]);
-        live.erase(live.begin() + i);
-        // keep at most two idle buffers
-        while (free_list.size() > 2) { g_late.add(free_list.front().first, true); free_list.erase(free_list.begin()); }      // (32-byte wire: a copy's landing buffer)
-        return;
-      }
-    (void)hipHostFree(p);
-  }
+  void put(void* p) { g_ends.give(p); g_ends.trim(); }
 };
 PinnedPool g_pinned;
 }  // namespace
@@ -339,12 +309,20 @@ static int upload_large(psigpu_ctx* ctx, void* dst, const void* src, size_t byte
   return PSIGPU_OK;
 }
 
-// A/B switches of the load campaigns (read per call: a campaign sets them for its own finders).
+// A/B arms of the load campaigns.  They exist only in a CAMPAIGN BUILD (make DEFS=-DPSIGPU_CAMPAIGN=1
+// LIBNAME=libpsi_gpu_campaign.so OBJDIR=...): the shipped library reads no PSIGPU_AB_* variable -- nothing in the environment
+// can make it skip a fence or return wrong records.
 // PSIGPU_AB_LOAD_HOLE=1 brings back what the loaders did before round 5: pads filled on the null stream with nobody waiting,
 // no device synchronisation when a loader returns, no read-back of checksums (which happened to order the fills).
 // PSIGPU_AB_NO_PAD_ZERO=1 leaves the pads as allocated (with PSIGPU_POISON: a known byte) -- does any answer depend on them?
+// PSIGPU_AB_EARLY_FREE=1: the ends of the engine copies go straight back to HIP (as until round 5) instead of to the pool.
+#ifdef PSIGPU_CAMPAIGN
 static bool ab_load_hole() { return getenv("PSIGPU_AB_LOAD_HOLE") != nullptr; }
 static bool ab_no_pad_zero() { return getenv("PSIGPU_AB_NO_PAD_ZERO") != nullptr; }
+#else
+static constexpr bool ab_load_hole() { return false; }
+static constexpr bool ab_no_pad_zero() { return false; }
+#endif
 // every loader ends here: whatever it queued on any stream (fills, table kernels) has run when the caller gets control back
 static int loader_fence(psigpu_ctx* ctx)
 {

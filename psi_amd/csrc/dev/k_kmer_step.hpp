@@ -28,8 +28,7 @@ k_kmer_step(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
             const uint64_t* __restrict__ params, uint64_t seeds_cap, uint64_t n_bases, uint32_t k, uint32_t step, PackedIn pk, UniformIn un,
             KmerTableView kt, MapView mv, const LocusEnt* __restrict__ ent, bool want_on, bool want_off, uint32_t gocc_thr,
             uint64_t rec_offset, psigpu_hit* __restrict__ hits, uint64_t cap, uint64_t* tile_state, uint32_t serial22,
-            DevCounters* ctr, uint32_t opts /* 2: no look-back (timing experiment, wrong records);
-                                               4: PSIGPU_ANY_ORDER -- the tile's output range by one atomic add */,
+            DevCounters* ctr, uint32_t opts /* 4: PSIGPU_ANY_ORDER -- the tile's output range by one atomic add */,
             uint64_t* __restrict__ seed_key_out = nullptr, uint2* __restrict__ seed_info_out = nullptr /* traverse mode: the seeds'
                                                k-mers and (read, offset) for the chunk's seed table and the traverser behind this kernel */)
 {
@@ -238,8 +237,7 @@ k_kmer_step(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
 #pragma unroll
     for (int i = 0; i < KS_R * 4; ++i) agg += s_cnt[i];
     uint64_t excl = 0;
-    if (opts & 2u) excl = t0;                     // (experiment: as if every seed before this tile had one hit)
-    else if (opts & 4u) {
+    if (opts & 4u) {
       // any order: the tiles' ranges in the order the tiles get here -- nobody waits for a tile in front (n_hits_tab ends as the total)
       unsigned long long at = 0;
       if (lane == 0) at = atomicAdd(&ctr->n_hits_tab.v, (unsigned long long)agg);

@@ -1195,6 +1195,45 @@ def test_host_entry_pipeline_equals_one_batch(monkeypatch, sub_bytes, pinned):
     f.close()
 
 
+def test_copy_ends_live_in_a_process_wide_pool():
+    """The lifetime rule of the host entry's transfer buffers (round 6, include/psi_gpu.h psigpu_copy_pool_stats): contexts
+    that come and go and calls that regrow hand both ends of their engine copies back to ONE pool -- a second finder's
+    staging / landing buffers are the first one's, nothing goes to the driver while finders are closed, and a trim drains the
+    engine queues first.  Records equal before and after (the reference's loop is deterministic, seed_finder.hpp:1724-1732)."""
+    g, reads = _x_case()
+    k, step = 21, 5
+    bases, off = psi_amd.pack_reads(reads[:600])
+    keep = [psi_amd.pinned_copy(bases), psi_amd.pinned_copy(off)]
+    got = []
+    stats = []
+    for life in range(4):
+        f = psi_amd.SeedFinder(g, k)
+        f.create_path_index(2, rng_seed=3)
+        for sub in (1 << 12, 1 << 30):
+            f.set_option('sub_bytes', sub)
+            got.append(f.seeds_all((keep[0].array, keep[1].array), step=step, sort_unique=True))
+            got.append(f.seeds_all(reads[:600], step=step, sort_unique=True))          # pageable reads: staged
+        f.close()
+        stats.append(psi_amd.copy_pool_stats())
+    assert all(_eq(h, got[0]) for h in got[1:]) and len(got[0]) > 0
+    # finders 2..4 are served what finder 1 handed back (a regrown buffer of finder 1 may leave finder 2 one size short, once)
+    assert stats[0]['allocated'] > 0 and stats[1]['allocated'] - stats[0]['allocated'] <= 2, stats
+    assert stats[-1]['allocated'] == stats[1]['allocated'], stats
+    assert stats[-1]['reused'] > stats[0]['reused']
+    assert stats[-1]['returned_to_driver'] == stats[0]['returned_to_driver']
+    assert stats[-1]['idle'] > 0
+    before = psi_amd.copy_pool_stats()
+    after = psi_amd.copy_pool_stats(trim_all=True)
+    assert after['idle'] == 0 and after['idle_device_bytes'] == 0 and after['idle_host_bytes'] == 0
+    assert after['returned_to_driver'] == before['returned_to_driver'] + before['idle']
+    assert after['queue_drains'] == before['queue_drains'] + 1          # the marker copies ran before the memory went
+    assert after['in_use'] == before['in_use']                           # (keep[] is still ours)
+    f = psi_amd.SeedFinder(g, k)
+    f.create_path_index(2, rng_seed=3)
+    assert _eq(f.seeds_all((keep[0].array, keep[1].array), step=step, sort_unique=True), got[0])
+    f.close()
+
+
 @pytest.mark.parametrize('k,step', [(13, 4), (21, 21), (31, 7)])
 def test_traverser_from_prefix_walks_equals_traverser_from_loci(k, step):
     """Traverse mode (TraverserBFS over every starting locus for every chunk, traverser_bfs.hpp:72-161) starts from the loci's

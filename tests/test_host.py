@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(L, name), name + ' is declared in include/psi_gpu.h but not exported'
     bound = {n for n, _, _ in psi_amd.ABI}
     assert declared == bound
-    assert L.psigpu_abi_version() == 7
+    assert L.psigpu_abi_version() == 8
 
 
 def test_no_gpu_means_loud_failure(ref_data):

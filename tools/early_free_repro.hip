@@ -39,6 +39,9 @@ int main(int argc, char** argv)
 {
   const long iters = argc > 1 ? atol(argv[1]) : 100000;
   const long late_us = argc > 2 ? atol(argv[2]) : 0;
+  const long secs = argc > 3 ? atol(argv[3]) : 0;          // (round 6: stop after this many seconds, 0 = after `iters`)
+  const auto t_start = std::chrono::steady_clock::now();
+  long done_iters = 0;
   if (hipSetDevice(0) != hipSuccess || hsa_init() != HSA_STATUS_SUCCESS) { fprintf(stderr, "no device\n"); return 2; }
   std::vector<hsa_agent_t> agents;
   hsa_iterate_agents(agents_cb, &agents);
@@ -64,6 +67,8 @@ int main(int argc, char** argv)
   long bad = 0;
   uint64_t rng = 0x9E3779B97F4A7C15ull * (uint64_t)getpid();
   for (long it = 0; it < iters; ++it) {
+    if (secs && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(secs)) break;
+    ++done_iters;
     rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
     const size_t bytes = 4096 + (rng % 64) * 4096;
     void* h = nullptr; void* d = nullptr;
@@ -102,6 +107,6 @@ int main(int argc, char** argv)
     }
   }
   for (auto& hd : held) { (void)hipHostFree(hd.h); (void)hipFree(hd.d); }
-  printf("%ld iterations, frees %s, %ld bait blocks changed\n", iters, late_us ? "late" : "at once", bad);
+  printf("%ld iterations, frees %s, %ld bait blocks changed\n", done_iters, late_us ? "late" : "at once", bad);
   return bad ? 1 : 0;
 }
