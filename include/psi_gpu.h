@@ -327,6 +327,9 @@ uint32_t psigpu_query_mode(const psigpu_ctx* ctx);     /* the mode queries run i
 #define PSIGPU_TUNE_NO_ROWRECS 4u    /* no per-row records (SaRec, located suffix array): locate through SA + segment table */
 #define PSIGPU_TUNE_NO_PATH_TABLE 8u /* traverse mode: the FM index answers the on-path phase (the reference's scheme as written)
                                         instead of the table of the paths' k-mers */
+#define PSIGPU_TUNE_NO_SWEEP 16u     /* the LF steps by one quad per seed (k_fm_search, rounds 1-5) instead of the level-synchronous
+                                        sweeps (k_fm_sweep: seeds bucketed by interval, rank blocks staged in LDS, live intervals
+                                        compacted by wave ballots) */
 int psigpu_set_tuning(psigpu_ctx* ctx, uint32_t flags);
 
 /* Per-context switches of the host entry (psigpu_find_seeds / _packed), by name -- what the PSIGPU_* environment

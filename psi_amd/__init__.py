@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('PSI_AMD_LIB') or os.path.join(_HERE, 'libpsi_gpu.so')
 
 ALL, ON_PATHS, OFF_PATHS, SORT_UNIQUE, UNIFORM_READS, ANY_ORDER = 3, 1, 2, 4, 8, 16
 MAX_SEED_LEN = 63
-TUNE_NO_DIRECT, TUNE_NO_VERIFY, TUNE_NO_ROWRECS, TUNE_NO_PATH_TABLE = 1, 2, 4, 8
+TUNE_NO_DIRECT, TUNE_NO_VERIFY, TUNE_NO_ROWRECS, TUNE_NO_PATH_TABLE, TUNE_NO_SWEEP = 1, 2, 4, 8, 16
 
 
 class PsiGpuError(RuntimeError):

@@ -20,14 +20,16 @@ struct psigpu_ctx {
     DevBuf saloc;                    // (node rank, offset) per SA row (sa_rate 1, when memory is plentiful)
     DevBuf sarec;                    // per-row records for seed length sarec_k (sa_rate 1, interval table, text resident)
     DevBuf ftabx;                    // interval table with the first row's record in its entries (FtabX), for seed length ftabx_k
+    DevBuf mini;                     // level-synchronous search, index without an interval table: the intervals of all mini_q-mers
+    uint32_t mini_q = 0;
     uint64_t text_len = 0, n_exc = 0, n_segs = 0;
     uint64_t C[4] = { 0, 0, 0, 0 };
     uint32_t ftab_len = 0, exc_shift = EXC_SUPER_SHIFT, sarec_k = 0, ftabx_k = 0;
     bool have_text4 = false, have_saloc = false;
     void release()
     {
-      for (DevBuf* b : { &blocks, &samples, &exc_row, &exc_sa, &ftab, &text4, &seg, &seg_dir, &seg_rank, &saloc, &sarec, &ftabx }) b->release();
-      text_len = n_exc = n_segs = 0; ftab_len = sarec_k = ftabx_k = 0; have_text4 = have_saloc = false;
+      for (DevBuf* b : { &blocks, &samples, &exc_row, &exc_sa, &ftab, &text4, &seg, &seg_dir, &seg_rank, &saloc, &sarec, &ftabx, &mini }) b->release();
+      text_len = n_exc = n_segs = 0; ftab_len = sarec_k = ftabx_k = mini_q = 0; have_text4 = have_saloc = false;
     }
   };
   std::vector<std::unique_ptr<FmPart>> parts;      // parts[0] always exists
@@ -58,6 +60,8 @@ struct psigpu_ctx {
   float lkt_build_ms = 0.f;
   std::string lkt_note;
   DevBuf w_seedout, w_seedres, w_iv_tiles_off, w_defer, w_hit_a, w_hit_seed;
+  DevBuf w_sw_rec[2], w_sw_cnt, w_sw_off[2], w_sw_tiles;      // level-synchronous FM search (k_fm_sweep): records, bucket counts / offsets
+  uint32_t opt_sweep_tail = 3;     // ... steps at the end of a seed that go to memory directly instead of getting a round of their own
   DevBuf w_tilestate;              // k_kmer_step's look-back words, one per tile (a word carries the serial of the call that wrote it)
   const void* tilestate_clean = nullptr;      // the allocation that was last zeroed whole
   bool opt_no_fused = false;       // A/B, tests: the default step as three kernels (k_seed_pack, k_kmer_probe, k_kmer_emit)

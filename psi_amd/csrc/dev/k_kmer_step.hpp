@@ -5,9 +5,9 @@
 // seed written and read back in between (a third of the step's traffic, two launches, and a probe kernel with one load
 // in flight per lane).  A workgroup takes the next tile (KS_R rounds of 256 seeds; a ticket, so tiles start in order),
 // packs its seeds' keys in registers, issues the first table load of all its rounds before it looks at any, counts the
-// tile's hits and learns its first output slot by a decoupled look-back over the tiles before it: tile_state[t] is ONE
-// 64-bit word -- flag (aggregate / inclusive prefix), the call's serial number, the count -- so a word is either this
-// call's or ignored and nothing needs a fence.  The records come out in seed order exactly as k_kmer_emit writes them
+// tile's hits and learns its first output slot by a decoupled look-back over the tiles before it, in two levels (tiles of
+// its group of 64, groups before its group): tile_state[t] / group_state[g] is ONE 64-bit word -- flag (aggregate / inclusive
+// prefix), the call's serial number, the count -- so a word is either this call's or ignored and nothing needs a fence.  The records come out in seed order exactly as k_kmer_emit writes them
 // (emit_round: the transposed stores, the spread of a seed with many hits over the wave).
 // The general (not equal-length) reads locate their read as k_seed_pack does, from the scanned seed offsets.
 // Traverse mode runs the same kernel over the table of the PATHS' k-mers and has it leave the seeds' k-mers and (read, offset)
@@ -20,6 +20,8 @@ constexpr int KS_R = KS_ROUNDS;      // (measured: tools/r05_step_ab.sh)
 constexpr uint32_t KS_TILE = 256 * KS_R;
 constexpr uint64_t KS_AGG = 1ull << 62, KS_PFX = 2ull << 62, KS_VAL = (1ull << 40) - 1;
 constexpr uint32_t KS_SERIAL = (1u << 22) - 1;
+// look-back words a call of up to n seeds needs: one per tile (+ slack), one per group of 64 tiles behind them
+__host__ __device__ inline uint64_t ks_state_words(uint64_t n_seeds) { return (n_seeds / KS_TILE + 66) + (n_seeds / KS_TILE) / 64 + 4; }
 __device__ __forceinline__ uint64_t ks_word(uint64_t flag, uint32_t serial22, uint64_t v) { return flag | ((uint64_t)serial22 << 40) | v; }
 
 template <bool PACKED, bool UNIFORM>
@@ -243,16 +245,48 @@ k_kmer_step(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
       if (lane == 0) at = atomicAdd(&ctr->n_hits_tab.v, (unsigned long long)agg);
       excl = (uint64_t)__shfl((unsigned long long)at, 0);
     } else
-    if (tile != 0) {
+    {
+      // Two levels (round 6).  Round 5 walked back over the TILES, 64 per step, until it met a tile that had published its
+      // prefix: with ~2 000 tiles of the same age resident, none of the tiles just in front has one yet, and a tile walked up to
+      // thirty windows -- thirty memory latencies in a row -- while holding its slot on the CU (0.06 ms of the kernel).  Now
+      // tiles come in GROUPS of 64: a tile adds the aggregates of the tiles before it in its own group (one window, one
+      // load) and the groups before its group (a second load, issued beside the first: at most ~110 groups, of which the ~30
+      // in flight have at least their aggregate out as soon as their 64 tiles have counted).  A group's words are published
+      // by its last tile: the aggregate when the group's tiles have all counted, the inclusive prefix when that tile knows
+      // its own.  Nobody waits for a prefix: an aggregate is enough to go on.
+      const uint64_t grp = tile >> 6;
+      const uint32_t pos = (uint32_t)tile & 63u;
+      uint64_t* const group_state = tile_state + ((seeds_cap + KS_TILE - 1) / KS_TILE + 1);
       if (lane == 0) __hip_atomic_store(&tile_state[tile], ks_word(KS_AGG, serial22, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int64_t top = (int64_t)tile - 1;              // the window: tiles top, top - 1, ... top - 63 on lanes 0 .. 63
-      while (true) {
+      int64_t top = (int64_t)grp - 1;               // the window over the groups: groups top, top - 1, ... on lanes 0 .. 63
+      auto load_groups = [&]() -> uint64_t {
         const int64_t idx = top - (int64_t)lane;
-        // (before tile 0: an inclusive prefix of nothing)
-        const uint64_t w = idx >= 0 ? __hip_atomic_load(&tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ks_word(KS_PFX, serial22, 0);
+        return idx >= 0 ? __hip_atomic_load(&group_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ks_word(KS_PFX, serial22, 0);
+      };
+      uint64_t wg = load_groups();                  // (in flight beside the first look at the own group)
+      uint64_t s_in = 0;
+      if (pos) {
+        while (true) {
+          const uint64_t w = lane < pos ? __hip_atomic_load(&tile_state[(grp << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          const bool ready = lane >= pos || ((w >> 62) != 0 && (uint32_t)((w >> 40) & KS_SERIAL) == serial22);
+          if (__ballot(ready) == ~0ull) {
+            uint64_t part = lane < pos ? (w & KS_VAL) : 0ull;
+            for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+            s_in = part;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const bool closes = pos == 63u;
+      if (closes && lane == 0) __hip_atomic_store(&group_state[grp], ks_word(KS_AGG, serial22, s_in + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool fresh = true;
+      while (true) {
+        const uint64_t w = fresh ? wg : load_groups();
+        fresh = false;
         const bool ready = (w >> 62) != 0 && (uint32_t)((w >> 40) & KS_SERIAL) == serial22;
         const uint64_t m_ready = __ballot(ready), m_pfx = __ballot(ready && (w >> 62) == 2);
-        const uint32_t n_ready = m_ready == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m_ready) - 1u;      // tiles ready from the window's top
+        const uint32_t n_ready = m_ready == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m_ready) - 1u;      // groups ready from the window's top
         const uint32_t first_pfx = m_pfx ? (uint32_t)__ffsll((long long)m_pfx) - 1u : 64u;
         if (first_pfx < n_ready || (first_pfx == 64u && n_ready == 64u)) {
           const uint32_t upto = first_pfx < 64u ? first_pfx : 63u;      // add lanes 0 .. upto
@@ -261,15 +295,14 @@ k_kmer_step(const char* __restrict__ bases, const uint64_t* __restrict__ read_of
           excl += part;
           if (first_pfx < 64u) break;
           top -= 64;
-        } else __builtin_amdgcn_s_sleep(2);
+        } else __builtin_amdgcn_s_sleep(1);
       }
+      excl += s_in;
+      if (closes && lane == 0) __hip_atomic_store(&group_state[grp], ks_word(KS_PFX, serial22, excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane == 0) {
       s_prefix = excl;
-      if (!(opts & 4u)) {
-        __hip_atomic_store(&tile_state[tile], ks_word(KS_PFX, serial22, excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t0 + KS_TILE >= n_seeds) ctr->n_hits_tab.v = excl + agg;    // the last tile: what the step wrote (or would have, past cap)
-      }
+      if (!(opts & 4u) && t0 + KS_TILE >= n_seeds) ctr->n_hits_tab.v = excl + agg;    // the last tile: what the step wrote (or would have, past cap)
     }
   }
   __syncthreads();

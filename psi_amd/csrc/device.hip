@@ -58,6 +58,7 @@ namespace {
 #include "dev/types.hpp"
 #include "dev/k_seed.hpp"
 #include "dev/k_fm_search.hpp"
+#include "dev/k_fm_sweep.hpp"
 #include "dev/k_emit_common.hpp"
 #include "dev/k_locus_table.hpp"
 #include "dev/k_kmer_table.hpp"

@@ -275,6 +275,47 @@ def test_snv_graph_vs_oracle(k, step, npaths, err):
     f.close()
 
 
+@pytest.mark.parametrize('k,step,ftab_len,sa_rate,tail', [
+    (21, 21, 0, 1, 3), (21, 21, psi_amd.NO_FTAB, 1, 3), (21, 7, 9, 4, 0), (31, 31, psi_amd.NO_FTAB, 32, 3), (31, 9, 13, 1, 1),
+    (13, 13, 13, 1, 3), (9, 4, psi_amd.NO_FTAB, 1, 3), (5, 5, psi_amd.NO_FTAB, 4, 3), (25, 25, 4, 32, 2), (30, 30, 6, 1, 0)])
+def test_level_synchronous_search_equals_the_quad_search(query_mode, k, step, ftab_len, sa_rate, tail):
+    """Every LF step of every seed (index_iter.hpp:835-841 -> fmindex.hpp:851-869) by k_fm_sweep -- seeds bucketed by interval,
+    rank blocks staged in LDS, rounds of five steps -- equals the quad-per-seed search of rounds 1-5 (TUNE_NO_SWEEP) and the
+    oracle, with and without an interval table, whole and sampled suffix array, seeds longer than a record's sixteen
+    characters (refill), seeds no longer than the table's q-mers (no step at all), and with a gocc threshold."""
+    if query_mode != 'locus-table':
+        pytest.skip('the FM search answers the on-path phase in locus-table mode')
+    sg = synth.snv_graph(200_000, 6_000, n_block=20_000, seed=k + 100)
+    g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path])
+    bases, off = synth.sim_reads_snv(sg, 2500, 150, seed=k + 1, sub_rate=0.005)
+    ix = psi_amd.PathIndex.build(g, k, 2, rng_seed=5, ftab_len=ftab_len, sa_rate=sa_rate)
+    res = {}
+    for name, tune in (('sweep', psi_amd.TUNE_NO_DIRECT | psi_amd.TUNE_NO_VERIFY),
+                       ('quad', psi_amd.TUNE_NO_DIRECT | psi_amd.TUNE_NO_VERIFY | psi_amd.TUNE_NO_SWEEP)):
+        f = psi_amd.SeedFinder(g, k, mode='locus-table')
+        f.set_tuning(tune)
+        f.set_option('sweep_tail', tail)
+        f.set_path_index(ix)
+        raw = f.seeds_all((bases, off), step=step)
+        c = f.counters()
+        thr_hits = None
+        f.set_gocc_threshold(2)
+        thr_hits = psi_amd.sort_unique(f.seeds_on_paths((bases, off), step=step))
+        f.set_gocc_threshold(0)
+        res[name] = (psi_amd.sort_unique(raw), len(raw), c, thr_hits)
+        if name == 'sweep':
+            want = _oracle_hits((sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to), f, bases, off, k, step)
+        f.close()
+    assert len(want) > 2500 and _eq(res['sweep'][0], want) and _eq(res['quad'][0], want)
+    assert res['sweep'][1] == res['quad'][1]                               # the raw streams have one length
+    assert _eq(res['sweep'][3], res['quad'][3]) and len(res['sweep'][3]) <= len(want)
+    cs, cq = res['sweep'][2], res['quad'][2]
+    assert cs['n_seeds_on_path'] == cq['n_seeds_on_path'] and cs['n_hits_on_path'] == cq['n_hits_on_path']
+    assert cs['search_launches'] >= 7 and cq['search_launches'] == 1       # rounds of six launches + the totals, against one kernel
+    if k > 13 or (ftab_len == psi_amd.NO_FTAB and k > 6):
+        assert cs['n_lf_steps'] > 0
+
+
 @pytest.mark.parametrize('seed', range(4))
 def test_layered_graph_vs_brute(seed):
     """dense random DAGs with N bases, out-degree up to 4 and short nodes: stresses the
