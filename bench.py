@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_PEAK_GBS = 63.0           # PCIe Gen5 x16, one direction (64 GT/s x 16 lanes, 128b/130b)
 BLOCK = 64                     # bytes per rank block / HBM sector
-PROFILE_ROUND = os.environ.get('PSI_PROFILE_ROUND', 'r05')
+PROFILE_ROUND = os.environ.get('PSI_PROFILE_ROUND', 'r06')
 TRAFFIC_FILES = {'kmer-table': '%s_k_traffic.json', 'locus-table': '%s_l_traffic.json', 'traverse': '%s_t_traffic.json',
                  # the fm-lf series (tools/profile.sh f1 / f2 / f3): locus-table mode with the LF kernels doing the work
                  'fm-lf/after_ftab': '%s_f1_traffic.json', 'fm-lf/no_ftab': '%s_f2_traffic.json',
@@ -287,6 +287,8 @@ def slim_line(out, full_path=None):
         return b
     if 'traverse' in rbm:
         routes['traverse'] = brief(rbm['traverse'], ('k_traverse', 'k_table_insert', 'k_kmer_step'))
+        if rbm['traverse'].get('by_chunk_reads'):      # ms per 1 M reads at 1 / 2 / 4 M reads per chunk (psikt -c)
+            routes['traverse']['ms_per_1M_reads_by_chunk'] = {n_: v_.get('ms_per_1M_reads') for n_, v_ in rbm['traverse']['by_chunk_reads'].items()}
         if 'fm_route' in rbm['traverse']:
             routes['traverse_fm_route'] = brief(rbm['traverse']['fm_route'], ('k_fm_search', 'k_fm_locate', 'k_traverse'))
     if 'locus-table' in rbm:
@@ -481,10 +483,27 @@ def main():
                     help="kmer-table: path k-mers and the starting loci's k-walks tabulated once in HBM, one probe "
                          "per seed; locus-table: FM index on the paths, table for the loci; traverse: FM index + "
                          "every starting locus traversed per chunk, as the reference does")
+    ap.add_argument('--psikt-reads', type=int, default=10_000_000,
+                    help='reads of the FASTQ the live psikt run answers (0 = no psikt run); chunks of 1 M reads (psikt -c 1000000)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    # ---- psikt as a process, LIVE (round 6): the drop-in CLI on this configuration -- a 10 M-read FASTQ, GFA graph,
+    # `psikt -l 21 -n 1 -c 1000000 -I ix` -- run to its end as a child process BEFORE this process makes its first GPU call (a
+    # child started later would be a fork of a process that holds the device; run beside the timed steps it would disturb them).
+    psikt_live = None
+    if (args.gpus == 1 and not args.lean and args.psikt_reads > 0 and args.reads == 1_000_000 and args.k == 21
+            and os.path.exists(os.path.join(ROOT, 'psi_amd', 'bin', 'psikt'))):
+        t_pk = time.time()
+        try:
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'psikt_config1.py'), '--live', '--reads', str(args.psikt_reads),
+                                 '--chunk', '1000000', '--backbone', str(args.backbone), '--snvs', str(args.snvs), '--nblock', str(args.nblock)],
+                                capture_output=True, text=True, timeout=900)
+            psikt_live = json.loads(pr.stdout.strip().splitlines()[-1])
+            psikt_live['child_wall_s'] = time.time() - t_pk
+        except Exception as ex:
+            log('live psikt run failed (%s: %s)' % (type(ex).__name__, ex))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -1147,6 +1166,35 @@ def main():
             f2.set_path_index(px)
             f2.prepare()
             by_mode[m] = time_mode(f2, 10, 3, m, False)
+            if m == 'traverse' and args.reads == 1_000_000:
+                # the reference's scheme as a function of the chunk size (psikt -c, src/psikt.cpp:190-208): the sweep over the
+                # loci's prefix walks and the traverser's walk over the survivors are paid per CHUNK, the seed table per seed
+                sweep = {}
+                d_hits2, n_out2 = C.c_void_p(), C.c_uint64()
+                for m_reads in (2_000_000, 4_000_000):
+                    try:
+                        b_, o_ = synth.sim_reads_snv(sg, m_reads, args.read_len, seed=4242)
+                        db_, do_ = torch.from_numpy(b_).cuda(), torch.from_numpy(o_.astype(np.int64)).cuda()
+                        call = (f2.ctx, db_.data_ptr(), do_.data_ptr(), m_reads, len(b_), k, step, 0,
+                                psi_amd.ALL | uni | (0 if args.ordered else psi_amd.ANY_ORDER), stream, C.byref(d_hits2), C.byref(n_out2))
+                        for _ in range(2):
+                            if L.psigpu_find_seeds_device(*call):
+                                raise RuntimeError(L.psigpu_last_error(f2.ctx).decode())
+                        torch.cuda.synchronize()
+                        t_ = time.perf_counter()
+                        for _ in range(5):
+                            if L.psigpu_find_seeds_device(*call):
+                                raise RuntimeError(L.psigpu_last_error(f2.ctx).decode())
+                        torch.cuda.synchronize()
+                        ms_ = (time.perf_counter() - t_) / 5 * 1e3
+                        c_ = f2.counters()
+                        sweep[str(m_reads)] = {'ms_per_chunk': ms_, 'ms_per_1M_reads': ms_ / (m_reads / 1e6), 'hits': int(c_['n_hits']),
+                                               'ms_table': float(c_['ms_table']), 'ms_traverse': float(c_['ms_traverse']),
+                                               'ms_probe': float(c_['ms_probe']), 'n_kpaths': int(c_['n_kpaths'])}
+                        del db_, do_, b_, o_
+                    except Exception as ex:
+                        sweep[str(m_reads)] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+                by_mode[m]['chunk_sweep'] = sweep
             f2.close()
         rbm = {}
         for m, res in by_mode.items():
@@ -1163,6 +1211,9 @@ def main():
                 e['k_fm_locate'] = roofline_of(res, m, 'k_fm_locate')
                 e['k_table_insert'] = roofline_of(res, m, 'k_table_insert')
                 e['k_traverse'] = roofline_of(res, m, 'k_traverse')
+                if res.get('chunk_sweep'):
+                    e['by_chunk_reads'] = dict({str(args.reads): {'ms_per_chunk': e['ms_per_step'], 'ms_per_1M_reads': e['ms_per_step'] / (args.reads / 1e6)}},
+                                               **res['chunk_sweep'])
             rbm[m] = e
         # traverse mode with the FM index answering the on-path phase: the reference's scheme as written
         f2 = psi_amd.SeedFinder(g, k, device=local_rank, mode='traverse')
@@ -1220,21 +1271,21 @@ def main():
                                  'note': 'steady state is the metric (index load excluded, SURVEY 8d); a finder that answers fewer '
                                          'chunks than this is better off in traverse mode: psigpu_set_query_mode( PSIGPU_MODE_AUTO )'}
 
-        # ---- psikt as a process on this configuration (tools/psikt_config1.py on the GPU box -> profiles/): the chunk loop a
-        # drop-in user runs (src/psikt.cpp:190-208), wall clock, beside the library calls above.  A recorded run, named as such.
-        pw_path = os.path.join(ROOT, 'profiles', '%s_psikt_config1.json' % PROFILE_ROUND)
-        if os.path.exists(pw_path) and args.reads == 1_000_000 and k == 21:
-            try:
-                pj = json.load(open(pw_path))
-                best = pj['runs'].get('index from file, 2nd run') or pj['runs'].get('patched, 2nd run') or {}
-                first = pj['runs'].get('patched (default)') or {}
-                out['psikt_wall'] = {'source': 'profiles/%s_psikt_config1.json (recorded run of tools/psikt_config1.py: 1 M-read FASTQ, GFA graph, '
-                                               'psikt -l 21 -n 1 -c 0)' % PROFILE_ROUND,
-                                     'find_seeds_s': best.get('find_s'), 'device_s': best.get('device_s'), 'load_reads_s': best.get('load_reads_s'),
-                                     'process_wall_s_index_from_file': best.get('wall_s'), 'process_wall_s_first_run': first.get('wall_s'),
-                                     'index_s_first_run': first.get('index_s'), 'hits': best.get('hits')}
-            except Exception as ex:
-                log('psikt wall record not readable (%s)' % ex)
+        # ---- psikt as a process on this configuration: the chunk loop a drop-in user runs (src/psikt.cpp:190-208), wall clock,
+        # measured by THIS run (the child process at the top of main)
+        if psikt_live and psikt_live.get('runs'):
+            best = psikt_live['runs'].get('index from file, 2nd run') or {}
+            first = psikt_live['runs'].get('index from file') or {}
+            out['psikt_wall'] = {'source': 'live: tools/psikt_config1.py --live run by this bench process before its first GPU call '
+                                           '(%d-read FASTQ, GFA graph, psikt -l 21 -n 1 -c %d -I ix; files in %s)'
+                                           % (psikt_live.get('reads', 0), psikt_live.get('chunk', 0), psikt_live.get('dir', '?')),
+                                 'reads': psikt_live.get('reads'), 'chunk': psikt_live.get('chunk'),
+                                 'find_seeds_s': best.get('find_s'), 'find_seeds_s_per_1M_reads': best.get('find_s_per_1M_reads'),
+                                 'reads_per_s': best.get('reads_per_s'), 'device_s': best.get('device_s'),
+                                 'parse_pack_s_per_chunk': best.get('parse_pack_s_per_chunk'), 'breakdown_s': best.get('breakdown_s'),
+                                 'process_wall_s_index_from_file': best.get('wall_s'), 'process_wall_s_first_run': first.get('wall_s'),
+                                 'index_s_first_run': first.get('index_s'), 'hits': best.get('hits'), 'rc': best.get('rc'),
+                                 'child_wall_s': psikt_live.get('child_wall_s'), 'inputs_s': psikt_live.get('inputs_s')}
 
         # ---- CPU baseline + parity gate -------------------------------------------------------------
         if args.cpu_reads != 0:

@@ -403,6 +403,8 @@ struct SeedBuckets {
   uint32_t n_buckets;        // 4^pb
   uint32_t n_wg;             // workgroups of the count / scatter kernels
   uint32_t k;
+  uint32_t tile;             // seeds per workgroup of those kernels (SB_TILE; four times that with the finer partition of large chunks,
+                             // so that the count matrix -- buckets x workgroups -- stays a fraction of the data)
 };
 
 __device__ __forceinline__ uint32_t sb_bucket(uint64_t key, uint32_t k, uint32_t pb) { return pb ? (uint32_t)(key >> (2 * (k - pb))) : 0u; }
@@ -417,7 +419,7 @@ k_sb_count(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ p
   for (uint32_t i = threadIdx.x; i < sb.n_buckets; i += 256) hist[i] = 0;
   __syncthreads();
   const uint64_t n_seeds = min(params[0], seeds_cap);
-  const uint64_t s0 = (uint64_t)blockIdx.x * SB_TILE, s1 = min(n_seeds, s0 + SB_TILE);
+  const uint64_t s0 = (uint64_t)blockIdx.x * sb.tile, s1 = min(n_seeds, s0 + sb.tile);
   for (uint64_t s = s0 + threadIdx.x; s < s1; s += 256 * 8) {        // eight independent loads per thread in flight
     uint64_t key[8];
 #pragma unroll
@@ -438,7 +440,7 @@ k_sb_scatter(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__
   for (uint32_t i = threadIdx.x; i < sb.n_buckets; i += 256) cur[i] = (uint32_t)off[(uint64_t)i * sb.n_wg + blockIdx.x];
   __syncthreads();
   const uint64_t n_seeds = min(params[0], seeds_cap);
-  const uint64_t s0 = (uint64_t)blockIdx.x * SB_TILE, s1 = min(n_seeds, s0 + SB_TILE);
+  const uint64_t s0 = (uint64_t)blockIdx.x * sb.tile, s1 = min(n_seeds, s0 + sb.tile);
   for (uint64_t s = s0 + threadIdx.x; s < s1; s += 256 * 8) {
     uint64_t key[8];
 #pragma unroll

@@ -311,11 +311,20 @@ int run( Options const& o, Logger& log )
    * reference's loop loads, seeds, loads: src/psikt.cpp:190-208 -- parsing 1 M reads costs several device calls) */
   auto chunk_a = finder.create_readrecord();
   auto chunk_b = finder.create_readrecord();
+  chunk_a.keep_names = chunk_b.keep_names = false;      /* (nothing here looks at a read's name: a million std::strings per chunk) */
+  /* how long parsing + packing a chunk took on the thread that did it (the loop itself only waits for it) */
+  double t_parse_a = 0, t_parse_b = 0, t_parse_all = 0;
+  auto timed_read = [ & ]( decltype( chunk_a )& into, double& took ) {
+    auto const t = std::chrono::steady_clock::now();
+    bool const have = readRecords( into, reads_iss, o.chunk_size );
+    took = seconds_since( t );
+    return have;
+  };
   auto* chunk_p = &chunk_a;
   auto* next_p = &chunk_b;
   std::future< bool > first_chunk;
   if ( !o.indexonly )
-    first_chunk = std::async( std::launch::async, [ & ] { return readRecords( chunk_a, reads_iss, o.chunk_size ); } );
+    first_chunk = std::async( std::launch::async, [ & ] { return timed_read( chunk_a, t_parse_a ); } );
   log.info( "Looking for an existing path index..." );
   auto t0 = std::chrono::steady_clock::now();
   if ( finder.load_path_index( o.pindex_path, o.context, o.step_size, o.dindex_min_ris, o.dindex_max_ris ) ) {
@@ -366,31 +375,44 @@ int run( Options const& o, Logger& log )
   auto traverser = finder.create_traverser();
   log.info( "Finding seeds..." );
   auto t_all = std::chrono::steady_clock::now();
-  double t_device = 0;
+  double t_device = 0, t_wait_reads = 0, t_call = 0, t_count = 0, t_push = 0;
   std::future< bool > next_chunk;      /* the chunk being read into *next_p while the device is busy */
+  double* parse_p = &t_parse_a;
+  double* parse_next_p = &t_parse_b;
   while ( true ) {
     log.info( "Loading a read chunk..." );
     auto t_load = std::chrono::steady_clock::now();
     bool have;
     if ( first_chunk.valid() ) have = first_chunk.get();
-    else if ( next_chunk.valid() ) { have = next_chunk.get(); std::swap( chunk_p, next_p ); }
-    else have = readRecords( *chunk_p, reads_iss, o.chunk_size );
+    else if ( next_chunk.valid() ) { have = next_chunk.get(); std::swap( chunk_p, next_p ); std::swap( parse_p, parse_next_p ); }
+    else have = timed_read( *chunk_p, *parse_p );
+    t_wait_reads += seconds_since( t_load );
     if ( !have ) break;
     auto& chunk = *chunk_p;
+    t_parse_all += *parse_p;
+    /* (parsed and packed in ...: on the thread that read the chunk, mostly while the device answered the chunk before;
+     * waited ...: what this loop stood still for it) */
     log.info( "Fetched " + std::to_string( chunk.size() ) + " reads with total length of " +
-              std::to_string( chunk.length_sum() ) + "bp in " + std::to_string( seconds_since( t_load ) ) + " s." );
+              std::to_string( chunk.length_sum() ) + "bp in " + std::to_string( *parse_p ) + " s (waited " +
+              std::to_string( seconds_since( t_load ) ) + " s)." );
     /* (the reader is this thread's again only after the get() above: one thread at a time on the stream) */
     if ( o.chunk_size != 0 )
-      next_chunk = std::async( std::launch::async, [ &, np = next_p ] { return readRecords( *np, reads_iss, o.chunk_size ); } );
+      next_chunk = std::async( std::launch::async, [ &, np = next_p, tp = parse_next_p ] { return timed_read( *np, *tp ); } );
     finder.get_seeds( seeds, chunk, o.distance );
     auto seeds_index = finder.index_reads( seeds );
     log.info( "Finding all seeds..." );
     auto st = finder.get_stats();
     if ( more.empty() ) {
+      auto const t_a = std::chrono::steady_clock::now();
       psigpu_hits hits = finder.seeds_all_hits( seeds, seeds_index, traverser );
+      auto const t_b = std::chrono::steady_clock::now();
       found += hits.n;
       covered += count_covered_reads( hits );
+      auto const t_c = std::chrono::steady_clock::now();
       writer.push( hits );                             // takes ownership, frees after writing
+      t_call += std::chrono::duration< double >( t_b - t_a ).count();
+      t_count += std::chrono::duration< double >( t_c - t_b ).count();
+      t_push += seconds_since( t_c );
       st = finder.get_stats();
     } else {
       /* reads are independent given the index: GPU r answers the r-th contiguous range of the chunk
@@ -430,10 +452,18 @@ int run( Options const& o, Logger& log )
     log.info( "Found seeds on paths: " + std::to_string( st.n_hits_on_path ) + ", off paths: " +
               std::to_string( st.n_hits_off_path ) + " (raw), device time " + std::to_string( st.ms_total ) + " ms." );
   }
+  auto const t_fin = std::chrono::steady_clock::now();
   if ( !writer.finish() ) throw std::runtime_error( "cannot write to '" + o.output_path + "'" );
   fclose( out );
+  double const t_finish = seconds_since( t_fin );
   log.info( "Found seed in " + std::to_string( seconds_since( t_all ) ) + " s (" + std::to_string( t_device ) +
             " s on the device)." );
+  /* where the loop's time went (round 6): waiting for the reader, inside the library call (transfers, kernels, widening),
+   * counting covered reads, waiting for the writer's queue, and the writer's last chunk; beside it what the reader's thread
+   * spent parsing + packing (overlapped with the calls) */
+  log.info( "Seed loop breakdown: wait_reads " + std::to_string( t_wait_reads ) + " s, call " + std::to_string( t_call ) +
+            " s, count " + std::to_string( t_count ) + " s, push " + std::to_string( t_push ) + " s, finish_write " +
+            std::to_string( t_finish ) + " s; parse+pack (reader thread) " + std::to_string( t_parse_all ) + " s." );
   log.info( "Total number of seeds found: " + std::to_string( found ) );            // src/psikt.cpp:59-80
   log.info( "Number of reads covered: " + std::to_string( covered ) );
   if ( !getenv( "PSIKT_CLEAN_EXIT" ) ) {

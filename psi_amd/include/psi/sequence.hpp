@@ -8,6 +8,10 @@
 #ifndef PSI_AMD_SEQUENCE_HPP__
 #define PSI_AMD_SEQUENCE_HPP__
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -42,12 +46,22 @@ namespace psi {
       n_ += len;
     }
     PinnedChars& operator+=( std::string const& s ) { append( s.data(), s.size() ); return *this; }
+    /** n bytes, contents unspecified (the parallel reader fills them): one allocation, no doubling */
+    void resize_uninitialized( std::size_t n ) { if ( n > cap_ ) grow_exact( n ); n_ = n; }
     std::string substr( std::size_t pos, std::size_t len ) const { return std::string( p_ + pos, len ); }
   private:
-    void grow( std::size_t want )
+    void grow_exact( std::size_t want )
+    {
+      std::size_t const keep = n_;
+      n_ = 0;                                   /* (nothing to carry over) */
+      grow( want + want / 16 + 4096, true );
+      n_ = keep;
+    }
+    void grow( std::size_t want, bool exact = false )
     {
       std::size_t cap = cap_ ? cap_ : ( 1u << 20 );
       while ( cap < want ) cap *= 2;
+      if ( exact ) cap = want;
       bool pinned = true;
       char* q = static_cast< char* >( psigpu_host_alloc( cap ) );
       if ( q == nullptr ) { q = static_cast< char* >( std::malloc( cap ) ); pinned = false; }
@@ -144,6 +158,11 @@ namespace psi {
     std::uint64_t get_record_offset() const { return rec_offset; }
     void set_record_offset( std::uint64_t v ) { rec_offset = v; }
     void clear() { name.clear(); bases.clear(); offsets.assign( 1, 0 ); rec_offset = 0; is_packed = false; n_not_acgt = 0; }
+    /** false: readRecords leaves `name` empty (psikt never looks at a read's name; a million std::strings per chunk are
+     *  a fifth of its parsing time) */
+    bool keep_names = true;
+    /** (the parallel reader: `offsets` and `bases` were filled in bulk) */
+    void set_bulk_lengths( std::size_t first, bool same ) { first_len = first; same_len = same; is_packed = false; }
     void push_back( std::string const& n, std::string const& s )
     {
       push_back( n.data(), n.size(), s.data(), s.size() );
@@ -176,10 +195,169 @@ namespace psi {
       gz_ = gzopen( path.c_str(), "rb" );
       if ( gz_ == nullptr ) throw std::runtime_error( "cannot open file '" + path + "'" );
       gzbuffer( gz_, 1 << 20 );
+      /* A plain (not gzip'd) FASTQ file of four-line records is mapped and parsed by several threads (round 6: the serial
+       * parser below reads 2-4 M reads/s, a tenth of what the device answers); anything else -- gzip, FASTA, one sequence
+       * per line, a record the fast path does not recognise -- goes through the serial parser, from the same byte on. */
+      int fd = ::open( path.c_str(), O_RDONLY );
+      if ( fd >= 0 ) {
+        struct stat sb;
+        unsigned char head[ 2 ] = { 0, 0 };
+        if ( fstat( fd, &sb ) == 0 && S_ISREG( sb.st_mode ) && sb.st_size >= 2 && pread( fd, head, 2, 0 ) == 2 &&
+             !( head[ 0 ] == 0x1f && head[ 1 ] == 0x8b ) && head[ 0 ] == '@' ) {
+          void* m = mmap( nullptr, (std::size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0 );
+          if ( m != MAP_FAILED ) { map_ = static_cast< char const* >( m ); map_len_ = (std::size_t)sb.st_size; fast_ = true; }
+        }
+        ::close( fd );
+      }
+      unsigned const hw = std::thread::hardware_concurrency();
+      threads_ = std::max( 1u, std::min( 16u, hw / 4 ? hw / 4 : 1u ) );
+      if ( char const* e = std::getenv( "PSI_READER_THREADS" ) ) threads_ = std::max( 1, std::atoi( e ) );
+      if ( std::getenv( "PSI_READER_SERIAL" ) ) fast_ = false;
     }
     SeqStreamIn( SeqStreamIn const& ) = delete;
-    ~SeqStreamIn() { if ( gz_ ) gzclose( gz_ ); }
+    ~SeqStreamIn()
+    {
+      if ( gz_ ) gzclose( gz_ );
+      if ( map_ ) munmap( const_cast< char* >( map_ ), map_len_ );
+    }
     std::uint64_t counts() const { return count_; }
+    bool fast() const { return fast_; }
+
+    /** Up to `num` records (0 = all that are left) by the parallel parser.  Returns 1 when records were read, 0 at the end
+     *  of the input, -1 when the input is not what the fast path takes (the stream then continues with the serial parser
+     *  from the same byte; `records` is left cleared). */
+    int read_chunk_fast( Records& records, std::uint64_t num )
+    {
+      if ( !fast_ ) return -1;
+      if ( fpos_ >= map_len_ ) return 0;
+      unsigned const T = threads_;
+      /* ---- 1. the positions of the newlines in a window that holds the chunk ---- */
+      struct Slice { std::size_t begin, end; std::vector< std::uint32_t > nl; std::uint64_t first_line; };
+      std::vector< Slice > slices;
+      std::uint64_t lines = 0;
+      std::uint64_t const want_lines = num ? 4 * num : ~0ull;
+      std::size_t wpos = fpos_;
+      std::size_t guess = map_len_ - fpos_;
+      if ( num ) {
+        /* the first record's length x num, and a little more */
+        char const* p = map_ + fpos_;
+        char const* e = map_ + map_len_;
+        int seen = 0;
+        while ( p < e && seen < 4 ) { char const* q = static_cast< char const* >( std::memchr( p, '\n', e - p ) ); if ( !q ) { p = e; break; } p = q + 1; ++seen; }
+        std::size_t const rec_len = std::max< std::size_t >( 8, p - ( map_ + fpos_ ) );
+        guess = std::min< std::size_t >( guess, (std::size_t)( (double)rec_len * (double)num * 1.01 ) + ( 1u << 16 ) );
+      }
+      while ( lines < want_lines && wpos < map_len_ ) {
+        std::size_t const wend = std::min( map_len_, wpos + guess );
+        std::size_t const per = ( wend - wpos + T - 1 ) / T;
+        std::size_t const s0 = slices.size();
+        for ( unsigned t = 0; t < T; ++t ) {
+          std::size_t const b = std::min( wend, wpos + t * per ), e2 = std::min( wend, b + per );
+          if ( e2 > b ) slices.push_back( Slice{ b, e2, {}, 0 } );
+        }
+        if ( per >= ( 1ull << 32 ) ) return leave_fast();          /* (offsets inside a slice are 32 bits) */
+        auto scan = [ & ]( std::size_t i ) {
+          Slice& sl = slices[ i ];
+          sl.nl.reserve( ( sl.end - sl.begin ) / 64 + 16 );
+          char const* base = map_ + sl.begin;
+          char const* p = base;
+          char const* e = map_ + sl.end;
+          while ( p < e ) {
+            char const* q = static_cast< char const* >( std::memchr( p, '\n', e - p ) );
+            if ( !q ) break;
+            sl.nl.push_back( (std::uint32_t)( q - base ) );
+            p = q + 1;
+          }
+        };
+        run_parallel( slices.size() - s0, [ & ]( std::size_t i ) { scan( s0 + i ); } );
+        for ( std::size_t i = s0; i < slices.size(); ++i ) { slices[ i ].first_line = lines; lines += slices[ i ].nl.size(); }
+        wpos = wend;
+        guess = std::max< std::size_t >( guess / 8, 1u << 20 );
+      }
+      bool const at_eof = wpos >= map_len_;
+      bool const virtual_nl = at_eof && map_[ map_len_ - 1 ] != '\n';      /* the last line ends with the file */
+      std::uint64_t const lines_all = lines + ( virtual_nl ? 1 : 0 );
+      std::uint64_t n_rec = std::min< std::uint64_t >( num ? num : ~0ull, lines_all / 4 );
+      if ( n_rec == 0 || ( lines_all < want_lines && lines_all % 4 != 0 ) ) return leave_fast();      /* a truncated record, blank lines at the end ...: the serial parser says what it is */
+      /* position of newline `i` (the virtual one at the end of the file included) */
+      auto nl_pos = [ & ]( std::uint64_t i, std::size_t& hint ) -> std::size_t {
+        if ( i >= lines ) return map_len_;
+        while ( i >= slices[ hint ].first_line + slices[ hint ].nl.size() ) ++hint;
+        return slices[ hint ].begin + slices[ hint ].nl[ i - slices[ hint ].first_line ];
+      };
+      auto slice_of = [ & ]( std::uint64_t i ) -> std::size_t {
+        std::size_t lo = 0, hi = slices.size();
+        while ( hi - lo > 1 ) { std::size_t const mid = ( lo + hi ) / 2; if ( slices[ mid ].first_line <= i ) lo = mid; else hi = mid; }
+        return lo;
+      };
+      /* ---- 2. every record's sequence line (start, length), checked; lengths summed per thread ---- */
+      std::vector< std::uint64_t > seq_at( n_rec );
+      std::vector< std::uint32_t > seq_len( n_rec );
+      std::vector< std::uint64_t > name_at;
+      std::vector< std::uint32_t > name_len;
+      bool const names = records.keep_names;
+      if ( names ) { name_at.resize( n_rec ); name_len.resize( n_rec ); }
+      std::vector< std::uint64_t > part_sum( T + 1, 0 );
+      std::vector< int > part_bad( T, 0 ), part_same( T, 1 );
+      std::size_t const fpos = fpos_;
+      run_parallel( T, [ & ]( std::size_t t ) {
+        std::uint64_t const r0 = n_rec * t / T, r1 = n_rec * ( t + 1 ) / T;
+        if ( r0 == r1 ) return;
+        std::size_t hint = slice_of( r0 ? 4 * r0 - 1 : 0 );
+        std::size_t start = r0 ? nl_pos( 4 * r0 - 1, hint ) + 1 : fpos;
+        std::uint64_t sum = 0;
+        std::uint32_t first = 0;
+        for ( std::uint64_t r = r0; r < r1; ++r ) {
+          std::size_t const e0 = nl_pos( 4 * r, hint ), e1 = nl_pos( 4 * r + 1, hint ), e2 = nl_pos( 4 * r + 2, hint ), e3 = nl_pos( 4 * r + 3, hint );
+          if ( e0 == start || map_[ start ] != '@' || e2 == e1 + 1 || map_[ e1 + 1 ] != '+' ) { part_bad[ t ] = 1; return; }
+          std::size_t sl = e1 - ( e0 + 1 );
+          if ( sl && map_[ e1 - 1 ] == '\r' ) --sl;
+          if ( sl == 0 || sl >= ( 1ull << 32 ) ) { part_bad[ t ] = 1; return; }      /* (an empty sequence: the serial parser's business) */
+          seq_at[ r ] = e0 + 1; seq_len[ r ] = (std::uint32_t)sl;
+          if ( r == r0 ) first = (std::uint32_t)sl; else if ( sl != first ) part_same[ t ] = 0;
+          if ( names ) {
+            std::size_t nl = 0, ll = e0 - start;
+            if ( ll && map_[ e0 - 1 ] == '\r' ) --ll;
+            while ( 1 + nl < ll && map_[ start + 1 + nl ] != ' ' && map_[ start + 1 + nl ] != '\t' ) ++nl;
+            name_at[ r ] = start + 1; name_len[ r ] = (std::uint32_t)nl;
+          }
+          sum += sl;
+          start = e3 + 1;
+        }
+        part_sum[ t + 1 ] = sum;
+      } );
+      for ( unsigned t = 0; t < T; ++t ) if ( part_bad[ t ] ) return leave_fast();
+      for ( unsigned t = 0; t < T; ++t ) part_sum[ t + 1 ] += part_sum[ t ];
+      /* ---- 3. bases back to back, offsets, names ---- */
+      records.clear();
+      records.set_record_offset( count_ );
+      records.bases.resize_uninitialized( part_sum[ T ] );
+      records.offsets.resize( n_rec + 1 );
+      if ( names ) records.name.resize( n_rec );
+      char* const dst = records.bases.data();
+      run_parallel( T, [ & ]( std::size_t t ) {
+        std::uint64_t const r0 = n_rec * t / T, r1 = n_rec * ( t + 1 ) / T;
+        std::uint64_t at = part_sum[ t ];
+        for ( std::uint64_t r = r0; r < r1; ++r ) {
+          records.offsets[ r ] = at;
+          std::memcpy( dst + at, map_ + seq_at[ r ], seq_len[ r ] );
+          at += seq_len[ r ];
+          if ( names ) records.name[ r ].assign( map_ + name_at[ r ], name_len[ r ] );
+        }
+      } );
+      records.offsets[ n_rec ] = part_sum[ T ];
+      bool same = true;
+      for ( unsigned t = 0; t < T; ++t ) same = same && part_same[ t ];
+      for ( std::uint64_t t = 1; same && t < T; ++t ) {
+        std::uint64_t const r0 = n_rec * t / T;
+        if ( r0 < n_rec && r0 != n_rec * ( t + 1 ) / T && seq_len[ r0 ] != seq_len[ 0 ] ) same = false;
+      }
+      records.set_bulk_lengths( seq_len[ 0 ], same );
+      std::size_t h2 = slice_of( 4 * n_rec - 1 );
+      fpos_ = std::min( map_len_, nl_pos( 4 * n_rec - 1, h2 ) + 1 );
+      count_ += n_rec;
+      return 1;
+    }
 
     /** Next record; false at end of input. */
     bool next( std::string& name, std::string& seq )
@@ -200,6 +378,24 @@ namespace psi {
     }
   private:
     static constexpr std::size_t BLOCK = 4u << 20;
+
+    template < typename F >
+    static void run_parallel( std::size_t n, F fn )
+    {
+      if ( n <= 1 ) { if ( n ) fn( 0 ); return; }
+      std::vector< std::thread > th;
+      for ( std::size_t i = 1; i < n; ++i ) th.emplace_back( [ i, &fn ] { fn( i ); } );
+      fn( 0 );
+      for ( auto& t : th ) t.join();
+    }
+    /* the input is not what the fast path takes: the serial parser goes on from the byte the fast path stands at */
+    int leave_fast()
+    {
+      fast_ = false;
+      if ( gzseek( gz_, (z_off_t)fpos_, SEEK_SET ) < 0 ) throw std::runtime_error( "read error" );
+      pos_ = end_ = 0; eof_ = false;
+      return -1;
+    }
 
     /* Views stay valid until the next call.  `keep` is where the current record starts in the
      * block buffer: line() preserves everything from there on when it refills, and positions
@@ -266,6 +462,10 @@ namespace psi {
     bool eof_ = false;
     std::string tmp_name_;
     std::uint64_t count_ = 0;
+    char const* map_ = nullptr;               /* the fast path: the file, mapped */
+    std::size_t map_len_ = 0, fpos_ = 0;
+    bool fast_ = false;
+    unsigned threads_ = 1;
   };
 
   /**
@@ -278,7 +478,15 @@ namespace psi {
   {
     records.clear();
     records.set_record_offset( iss.counts() );
-    while ( ( num == 0 || records.size() < num ) && iss.next_into( records ) ) { }
+    int const fast = iss.read_chunk_fast( records, num );
+    if ( fast == 0 ) return false;
+    if ( fast < 0 ) {
+      records.clear();
+      records.set_record_offset( iss.counts() );
+      bool const names = records.keep_names;
+      while ( ( num == 0 || records.size() < num ) && iss.next_into( records ) ) { }
+      if ( !names ) records.name.clear();
+    }
     if ( records.size() != 0 ) records.pack();    /* 2 bits per base for the host link (a few threads, ~10 ms per 150 Mbp) */
     return records.size() != 0;
   }

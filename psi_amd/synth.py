@@ -32,10 +32,36 @@ class SnvGraph:
         return len(self.node_id)
 
 
+def clustered_positions(rng, lo: int, hi: int, n: int, frac: float = 0.2, window: int = 200, spacing: int = 8) -> np.ndarray:
+    """`n` distinct sorted positions in [lo, hi): a share `frac` of them in windows of `window` bp where sites come every
+    ~`spacing` bp (geometric gaps), the rest uniform -- real variation clusters (1000G: hotspots, HLA), uniform SNVs do not."""
+    n_cl = int(n * frac)
+    per = max(1, window // spacing)
+    n_win = max(1, (n_cl + per - 1) // per) if n_cl else 0
+    starts = rng.integers(lo, max(lo + 1, hi - window), size=n_win)
+    gaps = rng.geometric(1.0 / spacing, size=(n_win, per * 2))
+    offs = np.cumsum(gaps, axis=1)
+    cl = (starts[:, None] + offs)[offs < window] if n_win else np.zeros(0, np.int64)
+    if len(cl) > n_cl:
+        cl = rng.choice(cl, size=n_cl, replace=False)
+    uni = rng.integers(lo, hi, size=int((n - len(cl)) * 1.02) + 8)
+    pos = np.unique(np.concatenate([cl.astype(np.int64), uni]))
+    pos = pos[(pos >= lo) & (pos < hi)]
+    if len(pos) > n:
+        # thin the UNIFORM part only, so that the clusters keep their density
+        is_cl = np.isin(pos, cl)
+        drop = rng.choice(np.flatnonzero(~is_cl), size=min(len(pos) - n, int((~is_cl).sum())), replace=False)
+        pos = np.delete(pos, drop)
+    return np.sort(pos)
+
+
 def snv_graph(length: int, n_snv: int, n_block: int = 0, max_node: int = 32,
-              seed: int = 11) -> SnvGraph:
+              seed: int = 11, cluster_frac: float = 0.0, cluster_window: int = 200, cluster_spacing: int = 8) -> SnvGraph:
     """Linear backbone of `length` uniform ACGT bases (first `n_block` are N), `n_snv`
-    bi-allelic SNV bubbles at uniform distinct positions outside the N block."""
+    bi-allelic SNV bubbles at uniform distinct positions outside the N block.
+    `cluster_frac` > 0: that share of the sites sits in windows of `cluster_window` bp at one site per ~`cluster_spacing` bp
+    (round 6: the uniform stand-in is kind to the tabulating modes -- 2.9 k-walks per locus; clustered sites are what
+    1000G variation looks like)."""
     rng = np.random.default_rng(seed)
     code = rng.integers(0, 4, size=length, dtype=np.uint8)
     backbone = _ACGT[code]
@@ -43,7 +69,9 @@ def snv_graph(length: int, n_snv: int, n_block: int = 0, max_node: int = 32,
     lo = n_block + 1
     n_snv = min(n_snv, max(0, (length - 1 - lo)))
     rng2 = np.random.default_rng(seed + 1)
-    if n_snv:
+    if n_snv and cluster_frac > 0:
+        pos = clustered_positions(rng2, lo, length - 1, n_snv, cluster_frac, cluster_window, cluster_spacing)
+    elif n_snv:
         pos = np.unique(rng2.integers(lo, length - 1, size=int(n_snv * 1.02) + 8))
         if len(pos) > n_snv:
             pos = np.sort(rng2.choice(pos, size=n_snv, replace=False))
@@ -174,13 +202,20 @@ def layered_graph(n_layers: int, max_width: int = 3, max_len: int = 9, seed: int
             np.asarray(edge_off, np.uint64), np.asarray(edge_to, np.uint32), ref_path)
 
 
-def bubble_graph(length: int, seed: int = 31, site_every: int = 20, max_node: int = 32):
+def bubble_graph(length: int, seed: int = 31, site_every: int = 20, max_node: int = 32,
+                 hot_frac: float = 0.0, hot_len: int = 120, hot_every: int = 3):
     """HLA-like high-branching graph (BASELINE.json configs[4]): a backbone with a variant site
     every ~`site_every` bp; sites are SNVs with 2-4 alleles, insertions / deletions of 1-50 bp
     (a deletion is an edge that skips the deleted backbone, an insertion an extra node).
+    `hot_frac` > 0: that share of the backbone lies in hot regions of `hot_len` bp with a site every ~`hot_every` bp (exon 2/3 of
+    a class-I gene: ten sites inside one 31-mer window -> 2^10 and more k-walks from the loci in front of it).
     Returns (node_id, label_off, labels, edge_off, edge_to, ref_path).  Built with Python loops:
     meant for graphs up to a few Mbp."""
     rng = np.random.default_rng(seed)
+    hot = np.zeros(length + 1, bool)
+    if hot_frac > 0:
+        for h0 in rng.integers(0, max(1, length - hot_len), size=max(1, int(length * hot_frac / hot_len))):
+            hot[int(h0):int(h0) + hot_len] = True
     bb = _ACGT[rng.integers(0, 4, size=length)]
     labels: List[bytes] = []
     out: List[List[int]] = []
@@ -205,7 +240,8 @@ def bubble_graph(length: int, seed: int = 31, site_every: int = 20, max_node: in
     pos = 0
     tails: List[int] = []            # nodes whose next edge goes to the next backbone piece
     while pos < length:
-        gap = int(rng.integers(max(2, site_every // 2), site_every * 3 // 2 + 1))
+        ev = hot_every if hot[pos] else site_every
+        gap = int(rng.integers(max(2, ev // 2), max(3, ev * 3 // 2 + 1)))
         end = min(length, pos + gap)
         first, last = chain(bytes(bb[pos:end]))
         node = first
@@ -220,7 +256,7 @@ def bubble_graph(length: int, seed: int = 31, site_every: int = 20, max_node: in
         pos = end
         if pos >= length - 60:
             continue
-        kind = rng.random()
+        kind = rng.random() * (0.6 if hot[pos] else 1.0)      # (hot regions: substitutions only, as in the exons)
         if kind < 0.6:                                   # SNV with 2..4 alleles
             n_all = int(rng.choice([2, 2, 2, 3, 4]))
             ref_base = int(np.where(_ACGT == bb[pos])[0][0])

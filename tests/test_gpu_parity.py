@@ -136,8 +136,11 @@ def test_seed_table_builds_agree(monkeypatch, query_mode):
     z = np.load(os.path.join(GOLDEN, 'hits_x_reads_n1000l100e0i0_k21_d1.npz'))
     reads = [str(r) for r in z['reads']]
     g = _graph(str(z['graph']))
-    for sb_max in (None, '0'):
-        if sb_max is not None:
+    for sb_max in (None, '0', 'pb7'):
+        if sb_max == 'pb7':               # the partition by SEVEN leading bases (chunks of 9 M .. 36 M seeds) on a small chunk
+            monkeypatch.delenv('PSIGPU_SB_MAX')
+            monkeypatch.setenv('PSIGPU_SB_PB', '7')
+        elif sb_max is not None:
             monkeypatch.setenv('PSIGPU_SB_MAX', sb_max)
         f = psi_amd.SeedFinder(g, 21)
         f.create_path_index(1)
@@ -152,7 +155,7 @@ def test_seed_table_builds_agree(monkeypatch, query_mode):
             want = np.array(brute.hit_set(bg, reads[:60], k, k), dtype=np.uint64).reshape(-1, 4)
             assert _eq(got, want)
             f.close()
-    monkeypatch.delenv('PSIGPU_SB_MAX')
+    monkeypatch.delenv('PSIGPU_SB_PB')
 
 
 def test_traverser_truth_table():

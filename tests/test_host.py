@@ -870,11 +870,13 @@ def records_dump(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize('fmt', ['fastq', 'fastq.gz', 'fasta', 'text', 'crlf'])
-@pytest.mark.parametrize('chunk', [0, 1, 7])
-def test_read_records_formats_and_chunks(records_dump, tmp_path, fmt, chunk):
+@pytest.mark.parametrize('fmt', ['fastq', 'fastq.gz', 'fasta', 'text', 'crlf', 'fastq-blank'])
+@pytest.mark.parametrize('chunk,reader', [(0, ''), (1, ''), (7, ''), (0, 'serial'), (7, 'serial'), (7, 'threads=1'), (5, 'threads=13')])
+def test_read_records_formats_and_chunks(records_dump, tmp_path, fmt, chunk, reader):
     """Every format the CLI accepts, read ids global across chunks, records longer than the reader's
-    block and an unterminated last line."""
+    block and an unterminated last line.  Plain four-line FASTQ goes through the parallel parser (round 6), everything
+    else -- and a file the parallel parser gives up on half way: a blank line between two records -- through the serial
+    one; same records whoever reads them (PSI_READER_SERIAL / PSI_READER_THREADS)."""
     import gzip
     import subprocess
     rng = np.random.default_rng(5)
@@ -884,7 +886,8 @@ def test_read_records_formats_and_chunks(records_dump, tmp_path, fmt, chunk):
     names = ['r%d' % i for i in range(len(reads))]
     if fmt.startswith('fastq') or fmt == 'crlf':
         eol = '\r\n' if fmt == 'crlf' else '\n'
-        text = ''.join('@%s some comment%s%s%s+%s%s%s' % (n, eol, r, eol, eol, 'I' * len(r), eol) for n, r in zip(names, reads))
+        text = ''.join('@%s some comment%s%s%s+%s%s%s%s' % (n, eol, r, eol, eol, 'I' * len(r), eol, eol if fmt == 'fastq-blank' and i == 20 else '')
+                       for i, (n, r) in enumerate(zip(names, reads)))
         text = text[:-len(eol)]                   # no terminator on the last line
     elif fmt == 'fasta':
         text = ''.join('>%s desc\n%s\n' % (n, r) for n, r in zip(names, reads))
@@ -898,7 +901,12 @@ def test_read_records_formats_and_chunks(records_dump, tmp_path, fmt, chunk):
     else:
         with open(path, 'w', newline='') as f:
             f.write(text)
-    out = subprocess.check_output([records_dump, path, str(chunk)]).decode().split('\n')
+    env = dict(os.environ)
+    if reader == 'serial':
+        env['PSI_READER_SERIAL'] = '1'
+    elif reader.startswith('threads='):
+        env['PSI_READER_THREADS'] = reader.split('=')[1]
+    out = subprocess.check_output([records_dump, path, str(chunk)], env=env).decode().split('\n')
     recs = [l.split('\t') for l in out if l and not l.startswith('#')]
     chunks = [l.split() for l in out if l.startswith('#chunk')]
     assert [(int(a), b, c) for a, b, c in recs] == [(i, n, r) for i, (n, r) in enumerate(zip(names, reads))]
