@@ -1032,6 +1032,113 @@ def test_config4_hla_full_size(query_mode):
     f.close()
 
 
+def _standin_row(name, what, g, make_index, reads, k, n_reads, extra=None):
+    """One stand-in through the three query modes + AUTO (round 6): what the tables cost on it (k-mers tabulated, device bytes,
+    build time), what the walk cap leaves to the traverser, whether the traverser spills, what AUTO decides, the step's device
+    time per mode -- and that the modes return ONE record set.  Returns (row, finder of the default mode, its sorted records)."""
+    import json
+    import torch
+    bases, off = reads
+    row = {'stand_in': name, 'what': what, 'k': k, 'reads': n_reads, 'nodes': int(g.n_nodes), 'modes': {}}
+    px = make_index()
+    row['starting_loci'] = int(px.view.n_loci)
+    digest, keep, keep_su = None, None, None
+    for mode in ('kmer-table', 'locus-table', 'traverse', 'auto'):
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        f = psi_amd.SeedFinder(g, k, mode=mode, walk_cap=0)
+        if mode == 'auto':
+            f.set_option('expected_calls', 1)          # (one chunk to answer: psikt on this FASTQ)
+        f.set_path_index(px)
+        f.prepare()
+        torch.cuda.synchronize()
+        dev_bytes = free0 - torch.cuda.mem_get_info()[0]
+        su = f.seeds_all((bases, off), step=k, sort_unique=True)
+        ms = []
+        for _ in range(3):
+            f.seeds_all((bases, off), step=k, sort_unique=True)
+            ms.append(f.counters()['ms_total'])
+        c = f.counters()
+        d = (len(su), int((su * np.array([3, 5, 7, 11], np.uint64)).sum(dtype=np.uint64)))
+        assert digest is None or d == digest, (name, mode)
+        digest = d
+        row['modes'][mode] = {'resolved_to': f.query_mode(), 'device_bytes_index_and_tables': int(dev_bytes),
+                              'locus_kmers_tabulated': int(c['n_locus_kmers']), 'path_kmers_tabulated': int(c['n_path_kmers']),
+                              'table_build_ms': float(c['ms_locus_table_build']),
+                              'loci_left_to_the_traverser': int(c['n_loci_traversed']),
+                              'share_of_loci_left_to_the_traverser': float(c['n_loci_traversed']) / max(1, int(c['n_loci'])),
+                              'n_spilled': int(c['n_spilled']), 'traverse_launches': int(c['traverse_launches']),
+                              'device_ms_per_step': float(np.median(ms)), 'hits': int(c['n_hits']), 'fused_step': int(c['fused_step'])}
+        if mode == 'kmer-table':
+            keep, keep_su = f, su
+        else:
+            f.close()
+    row['records_sort_unique'] = digest[0]
+    if extra:
+        row.update(extra)
+    print('standin ' + json.dumps(row))
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out_dir):
+        json.dump(row, open(os.path.join(out_dir, 'standin_%s.json' % name), 'w'), indent=1)
+    return row, keep, keep_su, px
+
+
+@pytest.mark.parametrize('query_mode', ['kmer-table'], indirect=True)
+def test_clustered_variation_stand_in(query_mode):
+    """configs[1] with CLUSTERED variation (round-5 review: uniform bi-allelic SNVs are kind to the tabulating modes -- 2.9
+    k-walks per locus): 51 Mbp, 1.1 M SNVs of which a fifth sit in 200-bp windows at one site per ~8 bp (up to ten sites in one
+    21-mer window), 1 M x 150 bp reads, k = 21.  The three modes and AUTO return one record set; the checker that takes
+    nothing from the product (_independent_windows: loci by the brute-force definition, the oracle's own suffix array) agrees
+    on windows drawn over the graph; the row of numbers goes to gpurun_out/standin_clustered.json.
+    Ref: seed_finder.hpp:1481-1585 (the loci), traverser_bfs.hpp:72-161."""
+    k = 21
+    sg = synth.snv_graph(51_000_000, 1_100_000, n_block=11_000_000, seed=11, cluster_frac=0.2)
+    g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to, paths=[sg.ref_path])
+    bases, off = synth.sim_reads_snv(sg, 1_000_000, 150, seed=13)
+    c = np.zeros(len(sg.alt) + 1, np.int64)
+    c[1:] = np.cumsum(sg.alt != 0)
+    w = c[k:] - c[:-k]
+    row, f, su, px = _standin_row('clustered', 'snv_graph(51 Mbp, 1.1 M SNVs, cluster_frac 0.2), 1 M x 150 bp reads, k = 21, one path', g,
+                                  lambda: psi_amd.PathIndex.build(g, k, 1, rng_seed=1, device=0), (bases, off), k, 1_000_000,
+                                  {'max_sites_in_a_k_window': int(w.max()), 'share_of_k_windows_with_3_or_more_sites': float((w >= 3).mean())})
+    assert row['max_sites_in_a_k_window'] >= 6 and len(su) >= 7_000_000
+    assert row['modes']['kmer-table']['fused_step'] == 1
+    # windows that hold a cluster are among them: the positions of the densest windows + random ones
+    n_loci, n_hits = _independent_windows(sg, px, f, k, 6, 50_000, 11_000_100, 50_900_000)
+    dense = np.flatnonzero(w >= max(6, int(w.max()) - 2))
+    for pos in dense[:: max(1, len(dense) // 3)][:3]:
+        lo_p = int(max(11_000_100, min(int(pos) - 25_000, 50_900_000 - 50_001)))
+        a, b = _independent_windows(sg, px, f, k, 1, 50_000, lo_p, lo_p + 50_001, seed=int(pos) % 1000)
+        n_loci += a; n_hits += b
+    assert n_loci > 10_000 and n_hits > 9 * 300 * 7
+    f.close()
+
+
+@pytest.mark.parametrize('query_mode', ['kmer-table'], indirect=True)
+def test_hla_hot_region_stand_in(query_mode):
+    """configs[4] with regions that EXPLODE (round-5 review: the old stand-in averages 2.9 k-walks per locus and never
+    spills): bubble_graph(5 Mbp) with 5 % of the backbone in hot regions of 120 bp with a substitution site every ~3 bp
+    -- ten sites of 2-4 alleles inside one 31-mer window, 2^10 .. 7 x 10^4 walks from the loci in front of it -- 1 M x 150 bp
+    walk reads, k = 31, no path index.  The walk cap leaves those loci to the per-chunk traverser in every mode, whose LDS
+    stack overflows into the spill queue (n_spilled > 0); same record set in all modes and AUTO; the oracle (the reference's
+    traverser over ALL loci, traverser_bfs.hpp:72-161) on the first reads."""
+    import json
+    k, n_reads = 31, 1_000_000
+    nid, lo, lab, eo, et, ref = synth.bubble_graph(5_000_000, seed=31, hot_frac=0.05)
+    g = psi_amd.Graph.from_csr(nid, lo, lab, eo, et, paths=[ref])
+    bases, off = synth.sim_reads_walk(nid, lo, lab, eo, et, n_reads, 150, seed=33)
+    row, f, su, px = _standin_row('hla_hot', 'bubble_graph(5 Mbp, hot_frac 0.05: a site every ~3 bp in 120-bp regions), 1 M x 150 bp walk reads, '
+                                  'k = 31, no path index', g, lambda: psi_amd.PathIndex.build(g, k, 0, device=0), (bases, off), k, n_reads)
+    per_read = (150 - k) // k + 1
+    assert len(np.unique(su[:, 2] * np.uint64(1000) + su[:, 3])) == n_reads * per_read      # every seed of every walk read is found
+    assert row['modes']['kmer-table']['loci_left_to_the_traverser'] > 0                     # the walk cap bites
+    assert row['modes']['traverse']['n_spilled'] > 0 or row['modes']['kmer-table']['n_spilled'] > 0
+    n_chk = 4_000
+    want = _oracle_hits((nid, lo, lab, eo, et), f, bases[:n_chk * 150], off[:n_chk + 1], k, k, threads=8)
+    assert len(want) >= n_chk * per_read and _eq(su[su[:, 2] < n_chk], want)
+    f.close()
+
+
 # ---------------------------------------------------------------------------------------
 # randomised differential test: arbitrary small graphs (long nodes, N runs, out-degree up to 5,
 # back edges / cycles, reads with N and ragged lengths) against the brute-force definition
