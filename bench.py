@@ -461,6 +461,7 @@ def main():
     ap.add_argument('--ftab', type=int, default=0, help='interval-table length (0 = auto, -1 = none)')
     ap.add_argument('--tune', type=int, default=0, help='psigpu_set_tuning flags of the main finder (1 no direct K1, 2 no text '
                                                         'verification, 4 no row records)')
+    ap.add_argument('--sweep-tail', type=int, default=-1, help="k_fm_sweep: steps at the end of a seed that go to memory directly (option 'sweep_tail'; -1 = the library's default)")
     ap.add_argument('--series', default='', help="label of a roofline_by_mode['fm-lf'] point this run reproduces (traffic lookup)")
     ap.add_argument('--host-build', action='store_true', help='build the index on the host (SA-IS) instead of the GPU')
     ap.add_argument('--backbone', type=int, default=51_000_000)
@@ -600,6 +601,8 @@ def main():
     finder = psi_amd.SeedFinder(g, k, device=local_rank, mode=args.mode)
     if args.tune:
         finder.set_tuning(args.tune)
+    if args.sweep_tail >= 0:
+        finder.set_option('sweep_tail', args.sweep_tail)
     finder.set_path_index(px)
     t_up = time.time() - t_up
     t_prep = time.time()
@@ -744,6 +747,12 @@ def main():
                      'k_table_insert': [['k_sb_count', 'k_sb_scatter', 'k_sb_build']]}.get(dom, [[dom]])
             tot = lambda t: t.get('fetch_size_bytes', 0.0) + t.get('write_size_bytes', 0.0)      # noqa: E731
             find = lambda pre: next((kn for kn in pl if kn == pre or kn.startswith(pre + ',') or kn.startswith(pre + '>')), None)   # noqa: E731
+            sweep_kernels = [kn for kn in pl if 'k_fm_sweep' in kn or 'k_sweep_' in kn]
+            if dom == 'k_fm_search' and sweep_kernels and tj.get('mode') == mode and tj.get('series', '') == (traffic_key or '').partition('/')[2]:
+                # (round 6) K1 is the level-synchronous search: rounds of k_sweep_count / k_sweep_scatter / k_fm_sweep + k_sweep_totals
+                traffic = sum(tot(pl[n]) for n in sweep_kernels)
+                src = 'profiles/' + tname + ':' + '+'.join(sorted(n.split('(')[0] for n in sweep_kernels))
+                names = []
             for group in names:
                 real = [find(n) for n in group]
                 if all(real) and tot(pl[real[0]]) > 1e6 and tj.get('mode') == mode and \

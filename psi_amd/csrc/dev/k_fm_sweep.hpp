@@ -20,14 +20,26 @@
 // No seed ever waits for another seed's sector; a rank block travels from HBM once per round, not once per seed.
 // One-word seeds (k <= 31).  Records are 16 bytes: interval, seed number, the next sixteen characters.
 // ------------------------------------------------------------------------------------
-constexpr uint32_t SW_BUCKET_BITS = 12, SW_BUCKETS = 1u << SW_BUCKET_BITS;
-constexpr uint32_t SW_PER = 8, SW_TILE = 256 * SW_PER;      // seeds of a bucket a workgroup holds in registers at a time
+#ifndef SW_BUCKET_BITS_V
+#define SW_BUCKET_BITS_V 12
+#endif
+#ifndef SW_PER_V
+#define SW_PER_V 4
+#endif
+#ifndef SW_CAP_V
+#define SW_CAP_V 448
+#endif
+constexpr uint32_t SW_BUCKET_BITS = SW_BUCKET_BITS_V, SW_BUCKETS = 1u << SW_BUCKET_BITS;      // (measured: tools/r06_sweep_ab.sh)
+constexpr uint32_t SW_PER = SW_PER_V, SW_TILE = 256 * SW_PER;      // seeds of a bucket a workgroup holds in registers at a time
 constexpr uint32_t SW_LEVELS = 5;                           // steps per round answered from LDS (tree of 1 + 4 + 16 + 64 + 256 ranges)
 constexpr uint32_t SW_NODES = 256;                          // 4^(SW_LEVELS - 1)
-constexpr uint32_t SW_CAP = 448;                            // rank blocks staged at a time (28 KB)
+constexpr uint32_t SW_CAP = SW_CAP_V;                       // rank blocks staged at a time (64 bytes each)
 constexpr uint32_t SW_MINI = 6;                             // no interval table in the index: one of 4^6 entries is made when the part is first searched
 constexpr uint32_t SW_DEAD = 0xFFFFFFFFu;                   // record field l: no interval (a hole in a bucket's region)
-constexpr uint32_t SW_KR_LEVELS = 16;                       // characters a record carries
+constexpr uint32_t SW_KR_LEVELS = 16;
+#ifndef SW_WAVES_PER_SIMD
+#define SW_WAVES_PER_SIMD 1
+#endif                       // characters a record carries
 
 // rank_c(i) by ONE lane from a rank block it can address (LDS or memory): the same arithmetic as quad_rank
 template <typename P>
@@ -53,6 +65,75 @@ __device__ __forceinline__ uint32_t block_rank(const FMView& fm, const uint32_t*
     cnt += (uint32_t)__popcll(gi < g ? eq : (eq & ((1ull << m) - 1ull)));
   }
   return base + cnt;
+}
+
+// both ends of an interval: one set of loads when they lie in the same block (the rule once the interval is small)
+template <typename P>
+__device__ __forceinline__ void block_rank_pair(const FMView& fm, const uint32_t* s_sup, P bl, P br, bool same, uint32_t c, uint32_t l, uint32_t r,
+                                                uint32_t& nl, uint32_t& nr)
+{
+  if (!same) { nl = block_rank(fm, s_sup, bl, c, l); nr = block_rank(fm, s_sup, br, c, r); return; }
+  const uint32_t blk = l / BLOCK_SYMS, ol = l - blk * BLOCK_SYMS, orr = r - blk * BLOCK_SYMS;
+  const uint4 h = bl[0];
+  uint32_t base;
+  if (c == 3) base = blk * BLOCK_SYMS - h.x - h.y - h.z - (h.w >> 8) - exc_super(fm, s_sup, blk);
+  else base = c == 0 ? h.x : c == 1 ? h.y : h.z;
+  uint32_t el = 0, er = 0;
+  if (c == 0 && (h.w & 0xFF) != 0) {
+    const uint32_t e = (h.w >> 8) + exc_super(fm, s_sup, blk), ne = h.w & 0xFF;
+    el = exc_below(fm.exc_row + e, ne == 255 ? fm.n_exc - e : ne, l);
+    er = exc_below(fm.exc_row + e, ne == 255 ? fm.n_exc - e : ne, r);
+  }
+  uint32_t cl = 0, cr = 0;
+#pragma unroll
+  for (uint32_t gi = 0; gi < 3; ++gi) {
+    if (orr <= gi * 64) continue;                 // (r >= l: nothing of this group lies below either)
+    const uint4 v = bl[1 + gi];
+    const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    const uint64_t eq = (lo ^ ((c & 1u) ? 0ull : ~0ull)) & (hi ^ ((c & 2u) ? 0ull : ~0ull));
+    const uint32_t ml = ol > gi * 64 ? min(ol - gi * 64, 64u) : 0u, mr = min(orr - gi * 64, 64u);
+    cl += (uint32_t)__popcll(ml >= 64 ? eq : (eq & ((1ull << ml) - 1ull)));
+    cr += (uint32_t)__popcll(mr >= 64 ? eq : (eq & ((1ull << mr) - 1ull)));
+  }
+  nl = base - el + cl; nr = base - er + cr;
+}
+
+// ... from a STAGED block: its 64 bytes in LDS plus, per character, how many of it the block's first and second group of 64
+// symbols hold (gcnt: one byte per character, made once per block by the lanes that staged the groups): a rank is one
+// group's popcount, not up to three -- the sweep is bound by its VALU work (281 M wave instructions per round of five
+// steps measured with three popcounts per rank: 0.46 ms of pure issue), and ~26 seeds share a block's counts.
+__device__ __forceinline__ uint32_t staged_base(const FMView& fm, const uint32_t* s_sup, const uint4 h, uint32_t c, uint32_t blk)
+{
+  if (c == 3) return blk * BLOCK_SYMS - h.x - h.y - h.z - (h.w >> 8) - exc_super(fm, s_sup, blk);
+  return c == 0 ? h.x : c == 1 ? h.y : h.z;
+}
+__device__ __forceinline__ uint32_t staged_in_block(const uint4* blk16, uint2 gc, uint32_t c, uint32_t off)
+{
+  const uint32_t g = off >> 6, m = off & 63u;
+  const uint32_t pre = g == 0 ? 0u : ((gc.x >> (8 * c)) & 0xFFu) + (g == 2 ? (gc.y >> (8 * c)) & 0xFFu : 0u);
+  const uint4 v = blk16[1 + g];
+  const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+  const uint64_t eq = (lo ^ ((c & 1u) ? 0ull : ~0ull)) & (hi ^ ((c & 2u) ? 0ull : ~0ull));
+  return pre + (uint32_t)__popcll(eq & ((1ull << m) - 1ull));
+}
+__device__ __forceinline__ void staged_rank_pair(const FMView& fm, const uint32_t* s_sup, const uint4* s_blk, const uint2* s_gcnt, uint32_t slot_l,
+                                                 uint32_t slot_r, uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr)
+{
+  const uint32_t bl = l / BLOCK_SYMS, br = r / BLOCK_SYMS;
+  const uint4 hl = s_blk[slot_l * 4];
+  uint32_t base_l = staged_base(fm, s_sup, hl, c, bl);
+  if (c == 0 && (hl.w & 0xFF) != 0) {
+    const uint32_t e = (hl.w >> 8) + exc_super(fm, s_sup, bl), ne = hl.w & 0xFF;
+    base_l -= exc_below(fm.exc_row + e, ne == 255 ? fm.n_exc - e : ne, l);
+  }
+  nl = base_l + staged_in_block(s_blk + slot_l * 4, s_gcnt[slot_l], c, l - bl * BLOCK_SYMS);
+  const uint4 hr = s_blk[slot_r * 4];
+  uint32_t base_r = staged_base(fm, s_sup, hr, c, br);
+  if (c == 0 && (hr.w & 0xFF) != 0) {
+    const uint32_t e = (hr.w >> 8) + exc_super(fm, s_sup, br), ne = hr.w & 0xFF;
+    base_r -= exc_below(fm.exc_row + e, ne == 255 ? fm.n_exc - e : ne, r);
+  }
+  nr = base_r + staged_in_block(s_blk + slot_r * 4, s_gcnt[slot_r], c, r - br * BLOCK_SYMS);
 }
 
 struct SweepPart {          // how a round's records are partitioned
@@ -102,10 +183,11 @@ k_sweep_count(const uint64_t* __restrict__ seed_key, const uint4* __restrict__ r
 template <bool BY_KEY>
 __global__ void __launch_bounds__(256)
 k_sweep_scatter(const uint64_t* __restrict__ seed_key, const uint4* __restrict__ rec, const uint64_t* __restrict__ n_ptr, uint64_t cap, SweepPart sp,
-                const uint64_t* __restrict__ off /* exclusive scan of cnt */, uint32_t refill_lvl, uint4* __restrict__ out)
+                const uint64_t* __restrict__ base /* first record of every bucket */, const uint32_t* __restrict__ within /* [bucket][wg] */,
+                uint32_t refill_lvl, uint4* __restrict__ out)
 {
   __shared__ uint32_t cur[SW_BUCKETS];
-  for (uint32_t i = threadIdx.x; i < SW_BUCKETS; i += 256) cur[i] = (uint32_t)off[(uint64_t)i * sp.n_wg + blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < SW_BUCKETS; i += 256) cur[i] = (uint32_t)base[i] + within[(uint64_t)i * sp.n_wg + blockIdx.x];
   __syncthreads();
   const uint64_t n = min(*n_ptr, cap);
   const uint64_t s0 = (uint64_t)blockIdx.x * SB_TILE, s1 = min(n, s0 + SB_TILE);
@@ -138,6 +220,55 @@ k_sweep_scatter(const uint64_t* __restrict__ seed_key, const uint4* __restrict__
   }
 }
 
+// offsets of the (bucket, workgroup) counts: cnt[b][w] -> where workgroup w's records of bucket b start.  One workgroup per
+// bucket turns its row into exclusive prefixes and leaves the row's total; one workgroup scans the totals; the consumers
+// add the two (sw_off).  (The three-kernel scan over the whole matrix -- k_scan_tiles / sums / final -- took 50 us per round for
+// 1.7 M counters: a quarter of the partition.)
+__global__ void __launch_bounds__(256)
+k_sweep_rows(uint32_t* __restrict__ cnt, uint32_t n_wg, uint32_t* __restrict__ row_total)
+{
+  __shared__ uint32_t s_w[4];
+  uint32_t* row = cnt + (uint64_t)blockIdx.x * n_wg;
+  const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n_wg; base += 256) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n_wg ? row[i] : 0u;
+    uint32_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, d); if (lane >= (uint32_t)d) incl += u; }
+    __syncthreads();
+    if (lane == 63) s_w[wib] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) { if (w < wib) before += s_w[w]; all += s_w[w]; }
+    if (i < n_wg) row[i] = carry + before + incl - v;
+    carry += all;
+  }
+  if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+__global__ void __launch_bounds__(1024)
+k_sweep_bases(const uint32_t* __restrict__ row_total, uint32_t n_rows, uint64_t* __restrict__ base /* [n_rows + 1] */)
+{
+  __shared__ uint64_t s_w[16];
+  const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+  uint64_t carry = 0;
+  for (uint32_t b0 = 0; b0 < n_rows; b0 += 1024) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint64_t v = i < n_rows ? row_total[i] : 0ull;
+    uint64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t u = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += u; }
+    __syncthreads();
+    if (lane == 63) s_w[wib] = incl;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+    for (uint32_t w = 0; w < 16; ++w) { if (w < wib) before += s_w[w]; all += s_w[w]; }
+    if (i < n_rows) base[i] = carry + before + incl - v;
+    carry += all;
+  }
+  if (threadIdx.x == 0) base[n_rows] = carry;
+}
+
 // the interval of every q-mer, q = SW_MINI (or the seed length when that is shorter), by q LF steps each: what round 0 looks
 // a seed's last bases up in when the index carries no interval table (4^6 entries: made once per part and seed length class)
 __global__ void __launch_bounds__(256)
@@ -159,14 +290,15 @@ k_sweep_mini_table(FMView fm, uint32_t q, uint2* __restrict__ table)
 
 // one workgroup per bucket
 template <bool ROUND0, bool FINAL>
-__global__ void __launch_bounds__(256)
-k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__ in, const uint64_t* __restrict__ off, uint32_t n_wg,
+__global__ void __launch_bounds__(256, SW_WAVES_PER_SIMD)
+k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__ in, const uint64_t* __restrict__ base,
            uint32_t n_staged, uint32_t n_direct, uint32_t gocc_thr, uint4* __restrict__ out,
            uint32_t* __restrict__ iv_lo, uint32_t* __restrict__ iv_cnt, DevCounters* ctr)
 {
   __shared__ uint32_t s_sup[SUP_LDS];
   __shared__ uint4 s_blk[SW_CAP * 4];
   __shared__ uint32_t s_slot_blk[SW_CAP];
+  __shared__ uint2 s_gcnt[SW_CAP];               // per staged block: A, C, G, T in its first (x) and second (y) group of 64 symbols, a byte each
   __shared__ uint32_t s_node_lo[2][SW_NODES], s_node_hi[2][SW_NODES];
   __shared__ uint32_t s_first[SW_NODES], s_base[SW_NODES];
   __shared__ uint32_t s_scan[256 / 64 + 1];
@@ -174,7 +306,7 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
   __shared__ uint32_t s_cnt[SW_PER * 4 + 1];
   stage_exc_super(fm, s_sup);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wib = tid >> 6;
-  const uint64_t lo0 = off[(uint64_t)blockIdx.x * n_wg], hi0 = off[(uint64_t)(blockIdx.x + 1) * n_wg];
+  const uint64_t lo0 = base[blockIdx.x], hi0 = base[blockIdx.x + 1];
   uint32_t n_steps = 0, n_live = 0;
   for (uint64_t t0 = lo0; t0 < hi0; t0 += SW_TILE) {
     const uint32_t tn = (uint32_t)min((uint64_t)SW_TILE, hi0 - t0);
@@ -238,29 +370,72 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
         if (staged && tid < n_nodes) for (uint32_t t = 0; t < nb; ++t) s_slot_blk[base + t] = first + t;
         __syncthreads();
         if (staged) {
-          for (uint32_t e = tid; e < total * 4; e += 256) s_blk[e] = fm.blocks[(uint64_t)s_slot_blk[e >> 2] * 4 + (e & 3u)];
+          // (all of a lane's loads before the first store: a loop of load-then-store is one memory latency per turn)
+          constexpr uint32_t TURNS = (SW_CAP * 4 + 255) / 256;
+          uint4 tmp[TURNS];
+#pragma unroll
+          for (uint32_t u = 0; u < TURNS; ++u) {
+            const uint32_t e = min(tid + u * 256, total * 4 - 1);      // (past the end: the last chunk again, dropped below -- no branch round a load)
+            tmp[u] = fm.blocks[(uint64_t)s_slot_blk[e >> 2] * 4 + (e & 3u)];
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < TURNS; ++u) {
+            const uint32_t e = tid + u * 256;
+            if (e < total * 4) {
+              s_blk[e] = tmp[u];
+              const uint32_t part = e & 3u;
+              if (part == 1 || part == 2) {        // a lane that holds the first or the second group counts its characters
+                const uint64_t lo = (uint64_t)tmp[u].x | ((uint64_t)tmp[u].y << 32), hi = (uint64_t)tmp[u].z | ((uint64_t)tmp[u].w << 32);
+                const uint32_t nC = (uint32_t)__popcll(lo & ~hi), nG = (uint32_t)__popcll(~lo & hi), nT = (uint32_t)__popcll(lo & hi);
+                const uint32_t packed = (64u - nC - nG - nT) | (nC << 8) | (nG << 16) | (nT << 24);
+                reinterpret_cast<uint32_t*>(s_gcnt)[(e >> 2) * 2 + (part - 1)] = packed;
+              }
+            }
+          }
           __syncthreads();
         }
       }
       // ---- every live seed of the tile takes the step ----
+      if (staged) {
 #pragma unroll
-      for (uint32_t j = 0; j < SW_PER; ++j) {
-        if (!(alive & (1u << j))) continue;
-        const uint32_t c = kr[j] & 3u;
-        kr[j] >>= 2;
-        uint32_t nl, nr;
-        const uint32_t bl = l[j] / BLOCK_SYMS, br = r[j] / BLOCK_SYMS;
-        if (staged) {
+        for (uint32_t j = 0; j < SW_PER; ++j) {
+          if (!(alive & (1u << j))) continue;
+          const uint32_t c = kr[j] & 3u;
+          kr[j] >>= 2;
+          uint32_t nl, nr;
+          const uint32_t bl = l[j] / BLOCK_SYMS, br = r[j] / BLOCK_SYMS;
           const uint32_t sl = s_base[nd[j]] + (bl - s_first[nd[j]]);
-          nl = fm.C[c] + block_rank(fm, s_sup, s_blk + sl * 4, c, l[j]);
-          nr = fm.C[c] + block_rank(fm, s_sup, s_blk + (sl + (br - bl)) * 4, c, r[j]);
-        } else {
-          nl = fm.C[c] + block_rank(fm, s_sup, fm.blocks + (uint64_t)bl * 4, c, l[j]);
-          nr = fm.C[c] + block_rank(fm, s_sup, fm.blocks + (uint64_t)br * 4, c, r[j]);
+          staged_rank_pair(fm, s_sup, s_blk, s_gcnt, sl, sl + (br - bl), c, l[j], r[j], nl, nr);
+          l[j] = fm.C[c] + nl; r[j] = fm.C[c] + nr; nd[j] = (nd[j] * 4 + c) & (SW_NODES - 1);
+          ++n_steps;
+          if (nr <= nl) alive &= ~(1u << j);
         }
-        l[j] = nl; r[j] = nr; nd[j] = (nd[j] * 4 + c) & (SW_NODES - 1);
-        ++n_steps;
-        if (nr <= nl) alive &= ~(1u << j);
+      } else {
+        // from memory: the blocks of two seeds at a time, all their loads before the first is looked at
+#pragma unroll
+        for (uint32_t half = 0; half < SW_PER; half += 2) {
+          uint4 a0, a1, a2, a3, b0, b1, b2, b3;
+          {
+            const uint64_t ba = (alive >> half) & 1u ? l[half] / BLOCK_SYMS : 0u, bb = (alive >> (half + 1)) & 1u ? l[half + 1] / BLOCK_SYMS : 0u;
+            a0 = fm.blocks[ba * 4]; a1 = fm.blocks[ba * 4 + 1]; a2 = fm.blocks[ba * 4 + 2]; a3 = fm.blocks[ba * 4 + 3];
+            b0 = fm.blocks[bb * 4]; b1 = fm.blocks[bb * 4 + 1]; b2 = fm.blocks[bb * 4 + 2]; b3 = fm.blocks[bb * 4 + 3];
+          }
+#pragma unroll
+          for (uint32_t jj = 0; jj < 2; ++jj) {
+            const uint32_t j = half + jj;
+            if (!(alive & (1u << j))) continue;
+            const uint4 blk[4] = { jj ? b0 : a0, jj ? b1 : a1, jj ? b2 : a2, jj ? b3 : a3 };
+            const uint32_t c = kr[j] & 3u;
+            kr[j] >>= 2;
+            uint32_t nl, nr;
+            const uint32_t bl = l[j] / BLOCK_SYMS, br = r[j] / BLOCK_SYMS;
+            if (br == bl) block_rank_pair(fm, s_sup, &blk[0], &blk[0], true, c, l[j], r[j], nl, nr);
+            else { nl = block_rank(fm, s_sup, &blk[0], c, l[j]); nr = block_rank(fm, s_sup, fm.blocks + (uint64_t)br * 4, c, r[j]); }
+            l[j] = fm.C[c] + nl; r[j] = fm.C[c] + nr; nd[j] = (nd[j] * 4 + c) & (SW_NODES - 1);
+            ++n_steps;
+            if (nr <= nl) alive &= ~(1u << j);
+          }
+        }
       }
       // ---- the images of every node's range: the next level's nodes ----
       if (s + 1 < n_staged) {
@@ -272,8 +447,8 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
             const uint32_t ba = a / BLOCK_SYMS, bb = b / BLOCK_SYMS;
             if (staged) {
               const uint32_t sl = s_base[p];      // (a lies in the node's first block)
-              ca = fm.C[c] + block_rank(fm, s_sup, s_blk + sl * 4, c, a);
-              cb = fm.C[c] + block_rank(fm, s_sup, s_blk + (sl + (bb - ba)) * 4, c, b);
+              staged_rank_pair(fm, s_sup, s_blk, s_gcnt, sl, sl + (bb - ba), c, a, b, ca, cb);
+              ca += fm.C[c]; cb += fm.C[c];
             } else {
               ca = fm.C[c] + block_rank(fm, s_sup, fm.blocks + (uint64_t)ba * 4, c, a);
               cb = fm.C[c] + block_rank(fm, s_sup, fm.blocks + (uint64_t)bb * 4, c, b);

@@ -314,7 +314,7 @@ def test_level_synchronous_search_equals_the_quad_search(query_mode, k, step, ft
     assert _eq(res['sweep'][3], res['quad'][3]) and len(res['sweep'][3]) <= len(want)
     cs, cq = res['sweep'][2], res['quad'][2]
     assert cs['n_seeds_on_path'] == cq['n_seeds_on_path'] and cs['n_hits_on_path'] == cq['n_hits_on_path']
-    assert cs['search_launches'] >= 7 and cq['search_launches'] == 1       # rounds of six launches + the totals, against one kernel
+    assert cs['search_launches'] >= 6 and cq['search_launches'] == 1       # rounds of five launches + the totals, against one kernel
     if k > 13 or (ftab_len == psi_amd.NO_FTAB and k > 6):
         assert cs['n_lf_steps'] > 0
 
@@ -779,15 +779,23 @@ def _independent_windows(sg, px, finder, k, n_windows, wlen, lo_pos, hi_pos, see
     return n_loci_checked, n_hits_checked
 
 
+_config1_cache = {}
+
+
 def test_query_modes_agree_at_full_size(query_mode):
     """BASELINE.json configs[1] at full size (51 Mbp, 1.1 M SNVs, 1 M x 150 bp reads, k = 21): the
     three query modes return the same 7.0 M sort-unique records, every seed is found where it was sampled."""
     k = 21
-    sg = synth.snv_graph(51_000_000, 1_100_000, n_block=11_000_000, seed=11)
-    g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to,
-                               paths=[sg.ref_path])
-    bases, off = synth.sim_reads_snv(sg, 1_000_000, 150, seed=13)
-    px = psi_amd.PathIndex.build(g, k, 1, rng_seed=1, device=0)
+    if query_mode == 'locus-table':
+        pytest.skip('the same three finders as the kmer-table parametrisation (the fixture changes nothing for it)')
+    # graph, reads, index and the oracle's records: once per session (round-5 review: each of the four parametrisations rebuilt them)
+    if 'sg' not in _config1_cache:
+        sg = synth.snv_graph(51_000_000, 1_100_000, n_block=11_000_000, seed=11)
+        g = psi_amd.Graph.from_csr(sg.node_id, sg.label_off, sg.labels, sg.edge_off, sg.edge_to,
+                                   paths=[sg.ref_path])
+        bases, off = synth.sim_reads_snv(sg, 1_000_000, 150, seed=13)
+        _config1_cache.update(sg=sg, g=g, bases=bases, off=off, px=psi_amd.PathIndex.build(g, k, 1, rng_seed=1, device=0))
+    sg, g, bases, off, px = (_config1_cache[n] for n in ('sg', 'g', 'bases', 'off', 'px'))
     res = {}
     for mode in ('kmer-table', 'locus-table', 'traverse'):
         f = psi_amd.SeedFinder(g, k, mode=mode)
@@ -804,14 +812,15 @@ def test_query_modes_agree_at_full_size(query_mode):
     assert len(np.unique(hits[:, 2] * np.uint64(1000) + hits[:, 3])) == 7_000_000
     # ... and they are the ORACLE's records: the C restatement of the reference path over the same index
     # paths and starting loci, all 1 M reads (a few seconds on the box's host cores)
-    import oracle
-    from bench import oracle_objects
-    og, pidx = oracle_objects(sg, px)
-    ln, lo = px.loci
-    want = oracle.sort_unique(oracle.seeds_all(og, pidx, bytes(bases), off, k, k, ln, lo,
-                                               threads=oracle.lib().orc_max_threads()))
-    want = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
-    assert _eq(res['kmer-table'], want)
+    if 'want' not in _config1_cache:
+        import oracle
+        from bench import oracle_objects
+        og, pidx = oracle_objects(sg, px)
+        ln, lo = px.loci
+        want = oracle.sort_unique(oracle.seeds_all(og, pidx, bytes(bases), off, k, k, ln, lo,
+                                                   threads=oracle.lib().orc_max_threads()))
+        _config1_cache['want'] = want[np.lexsort((want[:, 1], want[:, 0], want[:, 3], want[:, 2]))]
+    assert _eq(res['kmer-table'], _config1_cache['want'])
     # ... and a checker that takes nothing from the product: 20 random 50-kbp windows, loci by the brute-force definition,
     # the oracle's own suffix array (once per run of the suite: the modes agree, asserted above)
     if query_mode == 'kmer-table':
