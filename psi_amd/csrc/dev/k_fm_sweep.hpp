@@ -365,7 +365,7 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
 #pragma unroll
         for (uint32_t w = 0; w < 4; ++w) { if (w < wib) before += s_scan[w]; total += s_scan[w]; }
         const uint32_t base = before + incl - nb;
-        staged = total <= SW_CAP;
+        staged = total != 0 && total <= SW_CAP;      // (no block at all: every interval of the tile has died)
         if (tid < n_nodes) { s_first[tid] = first; s_base[tid] = base; }
         if (staged && tid < n_nodes) for (uint32_t t = 0; t < nb; ++t) s_slot_blk[base + t] = first + t;
         __syncthreads();

@@ -98,6 +98,27 @@ for i in range(240):
 f.set_option('wire', 0)
 print(json.dumps({'label': 'wire formats alternated, 100 calls each', 'packed_median_ms': float(np.median(abw[0])), 'packed_min_ms': min(abw[0]),
                   'keys8_median_ms': float(np.median(abw[8])), 'keys8_min_ms': min(abw[8])}), flush=True)
+if os.environ.get('E2E_ENGINE_AB'):
+    # (round 6, review item 1c) the transfers by raw HSA engine copies (default) against HIP stream copies (option no_engine_copy,
+    # read when a context makes its pipeline): two finders over one index, alternated call by call
+    f2 = psi_amd.SeedFinder(g, 21, device=0)
+    f2.set_option('no_engine_copy', 1)
+    f2.set_path_index(px)
+    f2.prepare()
+    calls2 = [(f2.ctx,) + c[1:] for c in calls]
+    abe = {0: [], 1: []}
+    for i in range(440):
+        v = i & 1
+        cs = (calls2 if v else calls)[(i >> 1) % 2]
+        t = time.perf_counter()
+        assert L.psigpu_find_seeds_packed(*cs) == 0
+        L.psigpu_free_hits(C.byref(hits))
+        if i >= 240:
+            abe[v].append((time.perf_counter() - t) * 1e3)
+    print(json.dumps({'label': 'engine copies against HIP stream copies, alternated, 100 calls each (after 120 warm-up calls each)',
+                      'engine_copy_median_ms': float(np.median(abe[0])), 'engine_copy_min_ms': min(abe[0]),
+                      'hip_stream_copy_median_ms': float(np.median(abe[1])), 'hip_stream_copy_min_ms': min(abe[1])}), flush=True)
+    f2.close()
 if os.environ.get('E2E_TRACE'):
     # PSIGPU_TRACE=2: the timeline of the default (two sub-batches in flight) path; =1: the synchronous loop's
     for tr in ('2', '2', '1'):
