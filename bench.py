@@ -1286,12 +1286,13 @@ def main():
             best = psikt_live['runs'].get('index from file, 2nd run') or {}
             first = psikt_live['runs'].get('index from file') or {}
             out['psikt_wall'] = {'source': 'live: tools/psikt_config1.py --live run by this bench process before its first GPU call '
-                                           '(%d-read FASTQ, GFA graph, psikt -l 21 -n 1 -c %d -I ix; files in %s)'
-                                           % (psikt_live.get('reads', 0), psikt_live.get('chunk', 0), psikt_live.get('dir', '?')),
+                                           '(%d-read FASTQ, GFA graph, psikt -l 21 -n 1 -c %d -I ix; inputs in %s, records written to %s)'
+                                           % (psikt_live.get('reads', 0), psikt_live.get('chunk', 0), psikt_live.get('dir', '?'), best.get('out_path', '?')),
                                  'reads': psikt_live.get('reads'), 'chunk': psikt_live.get('chunk'),
                                  'find_seeds_s': best.get('find_s'), 'find_seeds_s_per_1M_reads': best.get('find_s_per_1M_reads'),
                                  'reads_per_s': best.get('reads_per_s'), 'device_s': best.get('device_s'),
                                  'parse_pack_s_per_chunk': best.get('parse_pack_s_per_chunk'), 'breakdown_s': best.get('breakdown_s'),
+                                 'call_ms_per_chunk': best.get('call_ms_per_chunk'),
                                  'process_wall_s_index_from_file': best.get('wall_s'), 'process_wall_s_first_run': first.get('wall_s'),
                                  'index_s_first_run': first.get('index_s'), 'hits': best.get('hits'), 'rc': best.get('rc'),
                                  'child_wall_s': psikt_live.get('child_wall_s'), 'inputs_s': psikt_live.get('inputs_s')}

@@ -470,6 +470,11 @@ void psigpu_host_free(void* p);
  * pool, buffers returned to the driver, queue drains run, idle device bytes, idle host bytes, buffers idle, buffers in use.
  * `trim_all` != 0 first returns every idle buffer to the driver (by the rule above). */
 void psigpu_copy_pool_stats(uint64_t out[8], int trim_all);
+/* (ABI 8) `count` hit arrays of `n_records` records made ahead of time: taken from the pool above and handed straight back, so
+ * that the first calls of a chunk loop find their output arrays waiting instead of pinning a few hundred megabytes each
+ * (psikt does this on a side thread while the graph is parsed: src/psikt.cpp:190-208 has no such cost -- its records go to
+ * the file one callback at a time).  Returns how many could be made.  Needs a GPU runtime, no context. */
+uint32_t psigpu_reserve_hit_arrays(uint64_t n_records, uint32_t count);
 
 /* Same with the chunk already resident in HBM and the hits left there (n_bases must be the
  * total length of the reads, d_read_off[n_reads]): `d_bases` and

@@ -167,6 +167,7 @@ ABI = [
     ('psigpu_host_alloc', _P, [C.c_uint64]),
     ('psigpu_host_free', None, [_P]),
     ('psigpu_copy_pool_stats', None, [C.POINTER(C.c_uint64), C.c_int]),
+    ('psigpu_reserve_hit_arrays', C.c_uint32, [C.c_uint64, C.c_uint32]),
 ]
 
 _lib = None

@@ -210,10 +210,21 @@ Options parse_args( int argc, char** argv )
   return o;
 }
 
-/* Writes hit arrays in the order they are pushed, on its own thread; owns them until written. */
+/* Writes hit arrays in the order they are pushed, on its own thread; owns them until written.  The thread also counts the
+ * reads a chunk covers (the arrays are sorted by read id: the changes of read id along them) -- round 6: that count was an
+ * OpenMP loop on the main thread, and the 128 spinning OpenMP threads starved the FASTQ reader's threads of their cores
+ * (0.07 s per 7 M records, and the parse of the next chunk took 0.14 s instead of 0.02).  A regular file is written by a few
+ * threads at once (pwrite at the chunk's offsets), anything else by one write after the other. */
 class HitWriter {
 public:
-  explicit HitWriter( FILE* f ) : out_( f ), th_( [ this ] { loop(); } ) {}
+  explicit HitWriter( FILE* f ) : out_( f ), th_( [ this ] { loop(); } )
+  {
+    fflush( f );
+    fd_ = fileno( f );
+    struct stat sb;
+    seekable_ = fd_ >= 0 && fstat( fd_, &sb ) == 0 && S_ISREG( sb.st_mode );
+    if ( seekable_ ) { off_t const at = lseek( fd_, 0, SEEK_CUR ); if ( at < 0 ) seekable_ = false; else pos_ = (std::uint64_t)at; }
+  }
   ~HitWriter() { finish(); }
   void push( psigpu_hits h )
   {
@@ -231,9 +242,20 @@ public:
       cv_.notify_all();
     }
     th_.join();
+    if ( seekable_ && ok_ ) ok_ = lseek( fd_, (off_t)pos_, SEEK_SET ) >= 0;
     return ok_;
   }
+  /** reads covered by the chunks written so far (complete after finish()) */
+  unsigned long long covered() const { return covered_; }
 private:
+  static constexpr unsigned MAX_THREADS = 32;
+  unsigned const THREADS = [] { char const* e = getenv( "PSIKT_WRITE_THREADS" ); unsigned const t = e ? (unsigned)atoi( e ) : 8u; return t < 1 ? 1u : t > MAX_THREADS ? MAX_THREADS : t; }();
+  static unsigned long long count_changes( psigpu_hit const* d, std::uint64_t a, std::uint64_t b )
+  {
+    unsigned long long n = 0;
+    for ( std::uint64_t i = a ? a : 1; i < b; ++i ) n += d[ i ].read_id != d[ i - 1 ].read_id;
+    return n;
+  }
   void loop()
   {
     while ( true ) {
@@ -244,7 +266,34 @@ private:
         if ( q_.empty() ) return;
         h = q_.front();
       }
-      if ( h.n && fwrite( h.data, sizeof( psigpu_hit ), h.n, out_ ) != h.n ) ok_ = false;
+      if ( h.n ) {
+        std::uint64_t const n = h.n;
+        unsigned long long part[ MAX_THREADS ] = { 0 };
+        bool wrote[ MAX_THREADS ];
+        std::vector< std::thread > th;
+        for ( unsigned t = 0; t < THREADS; ++t ) {
+          wrote[ t ] = true;
+          auto job = [ &, t ] {
+            std::uint64_t const a = n * t / THREADS, b = n * ( t + 1 ) / THREADS;
+            if ( seekable_ ) {
+              char const* p = reinterpret_cast< char const* >( h.data + a );
+              std::uint64_t left = ( b - a ) * sizeof( psigpu_hit ), at = pos_ + a * sizeof( psigpu_hit );
+              while ( left ) {
+                ssize_t const w = pwrite( fd_, p, left, (off_t)at );
+                if ( w <= 0 ) { wrote[ t ] = false; break; }
+                p += w; at += (std::uint64_t)w; left -= (std::uint64_t)w;
+              }
+            }
+            part[ t ] = count_changes( h.data, a, b );
+          };
+          if ( t + 1 < THREADS ) th.emplace_back( job ); else job();
+        }
+        for ( auto& t : th ) t.join();
+        if ( !seekable_ && fwrite( h.data, sizeof( psigpu_hit ), n, out_ ) != n ) ok_ = false;
+        for ( unsigned t = 0; t < THREADS; ++t ) { covered_ += part[ t ]; ok_ = ok_ && wrote[ t ]; }
+        covered_ += 1;                                      /* (the chunk's first read) */
+        pos_ += n * sizeof( psigpu_hit );
+      }
       psigpu_free_hits( &h );
       std::lock_guard< std::mutex > lk( mu_ );
       q_.pop_front();
@@ -252,21 +301,16 @@ private:
     }
   }
   FILE* out_;
+  int fd_ = -1;
+  bool seekable_ = false;
+  std::uint64_t pos_ = 0;
+  unsigned long long covered_ = 0;
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque< psigpu_hits > q_;
   bool done_ = false, ok_ = true;
   std::thread th_;
 };
-
-/* distinct read ids in an array sorted by read id */
-unsigned long long count_covered_reads( psigpu_hits const& h )
-{
-  unsigned long long n = h.n ? 1 : 0;
-#pragma omp parallel for reduction( + : n ) schedule( static )
-  for ( long long i = 1; i < (long long)h.n; ++i ) n += h.data[ i ].read_id != h.data[ i - 1 ].read_id;
-  return n;
-}
 
 double seconds_since( std::chrono::steady_clock::time_point t0 )
 {
@@ -276,7 +320,14 @@ double seconds_since( std::chrono::steady_clock::time_point t0 )
 int run( Options const& o, Logger& log )
 {
   /* the HIP runtime takes a few hundred milliseconds to come up: let it do so while the graph file is parsed */
-  std::thread warm( [] { void* p = psigpu_host_alloc( 4096 ); if ( p != nullptr ) psigpu_host_free( p ); } );
+  /* ... and the output arrays of the first chunks are pinned there too (three go round: one being filled, two with the writer):
+   * the library's first call assumes ten records per read, later ones what the chunks before had */
+  std::uint64_t const warm_records = o.chunk_size ? (std::uint64_t)( (double)o.chunk_size * 10.0 * 1.25 ) + 8192 : 0;
+  std::thread warm( [ warm_records ] {
+    void* p = psigpu_host_alloc( 4096 );
+    if ( p != nullptr ) psigpu_host_free( p );
+    if ( p != nullptr && warm_records && warm_records < ( 1ull << 26 ) ) (void)psigpu_reserve_hit_arrays( warm_records, 3 );
+  } );
   struct Joiner { std::thread& t; ~Joiner() { if ( t.joinable() ) t.join(); } } warm_guard{ warm };
   log.info( "Loading input graph from file '" + o.graph_path + "'..." );
   Graph graph( o.graph_path, o.follow_reversing );
@@ -375,7 +426,7 @@ int run( Options const& o, Logger& log )
   auto traverser = finder.create_traverser();
   log.info( "Finding seeds..." );
   auto t_all = std::chrono::steady_clock::now();
-  double t_device = 0, t_wait_reads = 0, t_call = 0, t_count = 0, t_push = 0;
+  double t_device = 0, t_wait_reads = 0, t_call = 0, t_count = 0, t_push = 0, t_last_call = 0;
   std::future< bool > next_chunk;      /* the chunk being read into *next_p while the device is busy */
   double* parse_p = &t_parse_a;
   double* parse_next_p = &t_parse_b;
@@ -407,10 +458,10 @@ int run( Options const& o, Logger& log )
       psigpu_hits hits = finder.seeds_all_hits( seeds, seeds_index, traverser );
       auto const t_b = std::chrono::steady_clock::now();
       found += hits.n;
-      covered += count_covered_reads( hits );
       auto const t_c = std::chrono::steady_clock::now();
       writer.push( hits );                             // takes ownership, frees after writing
       t_call += std::chrono::duration< double >( t_b - t_a ).count();
+      t_last_call = std::chrono::duration< double >( t_b - t_a ).count();
       t_count += std::chrono::duration< double >( t_c - t_b ).count();
       t_push += seconds_since( t_c );
       st = finder.get_stats();
@@ -439,7 +490,6 @@ int run( Options const& o, Logger& log )
       st = finder.get_stats();
       for ( size_t r = 0; r < nd; ++r ) {
         found += part[ r ].n;
-        covered += count_covered_reads( part[ r ] );
         writer.push( part[ r ] );
         if ( r ) {
           auto s2 = more[ r - 1 ]->get_stats();
@@ -450,10 +500,12 @@ int run( Options const& o, Logger& log )
     }
     t_device += st.ms_total * 1e-3;
     log.info( "Found seeds on paths: " + std::to_string( st.n_hits_on_path ) + ", off paths: " +
-              std::to_string( st.n_hits_off_path ) + " (raw), device time " + std::to_string( st.ms_total ) + " ms." );
+              std::to_string( st.n_hits_off_path ) + " (raw), device time " + std::to_string( st.ms_total ) + " ms, call " +
+              std::to_string( t_last_call * 1e3 ) + " ms." );
   }
   auto const t_fin = std::chrono::steady_clock::now();
   if ( !writer.finish() ) throw std::runtime_error( "cannot write to '" + o.output_path + "'" );
+  covered = writer.covered();
   fclose( out );
   double const t_finish = seconds_since( t_fin );
   log.info( "Found seed in " + std::to_string( seconds_since( t_all ) ) + " s (" + std::to_string( t_device ) +
