@@ -1297,6 +1297,21 @@ def main():
                                  'index_s_first_run': first.get('index_s'), 'hits': best.get('hits'), 'rc': best.get('rc'),
                                  'child_wall_s': psikt_live.get('child_wall_s'), 'inputs_s': psikt_live.get('inputs_s')}
 
+        # ---- the other stand-ins (round 6): clustered variation and an HLA graph whose hot regions explode -- rows recorded by the
+        # -m gpu tests of the same names (tests/test_gpu_parity.py::test_clustered_variation_stand_in / test_hla_hot_region_stand_in
+        # write them; tools copy them to profiles/): what the tables cost there, what the walk cap leaves to the traverser, spills,
+        # AUTO's decision, device time per mode
+        rows = []
+        for name in ('clustered', 'hla_hot'):
+            sp = os.path.join(ROOT, 'profiles', '%s_standin_%s.json' % (PROFILE_ROUND, name))
+            if os.path.exists(sp):
+                try:
+                    rows.append(json.load(open(sp)))
+                except Exception as ex:
+                    log('stand-in row %s not readable (%s)' % (sp, ex))
+        if rows:
+            out['stand_ins_recorded'] = rows
+
         # ---- CPU baseline + parity gate -------------------------------------------------------------
         if args.cpu_reads != 0:
             import oracle

@@ -54,6 +54,8 @@ struct psigpu_ctx {
   DevBuf w_pfx_surv;               // ... those of them that pass a chunk's prefix maps (k_pfx_filter -> k_traverse)
   uint32_t pfx_depth = 0;          // bases of a prefix walk: min(k, 14) -- the depth of the chunk's long prefix map
   uint64_t pfx_n = 0;
+  const void* pfx_src = nullptr;   // the loci the walks start from (all starting loci, or what a table's walk cap left over) and how many
+  uint64_t pfx_src_n = 0;
   bool pfx_ready = false, pfx_failed = false;
   float pfx_build_ms = 0.f;
   uint64_t lkt_ht_size = 0, lkt_n_ent = 0, lkt_n_res = 0, lkt_n_walks = 0;
