@@ -36,6 +36,16 @@ for _ in range(5):
     c = f.counters()
     for n in ('ms_total', 'ms_probe', 'ms_table', 'ms_traverse', 'ms_pack', 'ms_search', 'ms_locate'):
         ms[n] = ms.get(n, 0.0) + c[n] / 5
+import time
+pk = psi_amd.PackedReads(bases, off, pinned=True, threads=8)
+ts = []
+for i in range(8):
+    t = time.perf_counter()
+    h = f.seeds_all_packed(pk, step=k, sort_unique=True)
+    ts.append((time.perf_counter() - t) * 1e3)
+host_ms = float(np.median(ts[3:]))
+host_dev_ms = float(f.counters()['ms_total'])
+print(json.dumps({'host_entry_ms_incl_python_copy': host_ms, 'host_entry_device_ms': host_dev_ms, 'host_entry_hits': int(len(h))}))
 print(json.dumps({'stand_in': which, 'mode': mode, 'starting_loci': int(px.view.n_loci), 'ms': {a: round(b, 4) for a, b in ms.items()},
                   'n_kpaths': int(c['n_kpaths']), 'n_spilled': int(c['n_spilled']), 'traverse_launches': int(c['traverse_launches']),
                   'n_loci_traversed': int(c['n_loci_traversed']), 'hits': int(c['n_hits'])}))
