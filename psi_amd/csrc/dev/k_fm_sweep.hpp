@@ -98,42 +98,55 @@ __device__ __forceinline__ void block_rank_pair(const FMView& fm, const uint32_t
   nl = base - el + cl; nr = base - er + cr;
 }
 
-// ... from a STAGED block: its 64 bytes in LDS plus, per character, how many of it the block's first and second group of 64
-// symbols hold (gcnt: one byte per character, made once per block by the lanes that staged the groups): a rank is one
-// group's popcount, not up to three -- the sweep is bound by its VALU work (281 M wave instructions per round of five
-// steps measured with three popcounts per rank: 0.46 ms of pure issue), and ~26 seeds share a block's counts.
+// ... from a STAGED block: its 64 bytes in LDS plus, per half-group of 32 symbols, how many A / C / G / T lie in front of it
+// inside the block (s_cum: six words per block, a byte per character; made once per block by the lanes that staged its
+// groups -- k_fm_sweep's staging): a rank is then ONE 32-bit popcount, where a block read from memory costs up to three
+// 64-bit ones over two bit planes.  The sweep is bound by its VALU work (281 M wave instructions per round of five steps
+// with three popcounts per rank, 176 M with one 64-bit popcount, measured; 0.29 ms of pure issue), and ~26 seeds share a
+// block's counts.
 __device__ __forceinline__ uint32_t staged_base(const FMView& fm, const uint32_t* s_sup, const uint4 h, uint32_t c, uint32_t blk)
 {
   if (c == 3) return blk * BLOCK_SYMS - h.x - h.y - h.z - (h.w >> 8) - exc_super(fm, s_sup, blk);
   return c == 0 ? h.x : c == 1 ? h.y : h.z;
 }
-__device__ __forceinline__ uint32_t staged_in_block(const uint4* blk16, uint2 gc, uint32_t c, uint32_t off)
+// symbols of character c among the first `off` of the block in `slot`
+__device__ __forceinline__ uint32_t staged_in_block(const uint4* s_blk, const uint32_t* s_cum, uint32_t slot, uint32_t c, uint32_t off)
 {
-  const uint32_t g = off >> 6, m = off & 63u;
-  const uint32_t pre = g == 0 ? 0u : ((gc.x >> (8 * c)) & 0xFFu) + (g == 2 ? (gc.y >> (8 * c)) & 0xFFu : 0u);
-  const uint4 v = blk16[1 + g];
-  const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-  const uint64_t eq = (lo ^ ((c & 1u) ? 0ull : ~0ull)) & (hi ^ ((c & 2u) ? 0ull : ~0ull));
-  return pre + (uint32_t)__popcll(eq & ((1ull << m) - 1ull));
+  const uint32_t h = off >> 5, m = off & 31u;
+  const uint32_t pre = (s_cum[slot * 6 + h] >> (8 * c)) & 0xFFu;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(s_blk) + slot * 16 + 4 + (h >> 1) * 4 + (h & 1u);      // the group's planes: lo lo hi hi
+  const uint32_t lo = w[0], hi = w[2];
+  const uint32_t eq = (lo ^ ((c & 1u) ? 0u : ~0u)) & (hi ^ ((c & 2u) ? 0u : ~0u));
+  return pre + (uint32_t)__popc(eq & ((1u << m) - 1u));
 }
-__device__ __forceinline__ void staged_rank_pair(const FMView& fm, const uint32_t* s_sup, const uint4* s_blk, const uint2* s_gcnt, uint32_t slot_l,
+__device__ __forceinline__ uint32_t staged_rank(const FMView& fm, const uint32_t* s_sup, const uint4* s_blk, const uint32_t* s_cum, uint32_t slot,
+                                                uint32_t c, uint32_t i)
+{
+  const uint32_t blk = i / BLOCK_SYMS;
+  const uint4 hd = s_blk[slot * 4];
+  uint32_t base = staged_base(fm, s_sup, hd, c, blk);
+  if (c == 0 && (hd.w & 0xFF) != 0) {
+    const uint32_t e = (hd.w >> 8) + exc_super(fm, s_sup, blk), ne = hd.w & 0xFF;
+    base -= exc_below(fm.exc_row + e, ne == 255 ? fm.n_exc - e : ne, i);
+  }
+  return base + staged_in_block(s_blk, s_cum, slot, c, i - blk * BLOCK_SYMS);
+}
+__device__ __forceinline__ void staged_rank_pair(const FMView& fm, const uint32_t* s_sup, const uint4* s_blk, const uint32_t* s_cum, uint32_t slot_l,
                                                  uint32_t slot_r, uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr)
 {
-  const uint32_t bl = l / BLOCK_SYMS, br = r / BLOCK_SYMS;
-  const uint4 hl = s_blk[slot_l * 4];
-  uint32_t base_l = staged_base(fm, s_sup, hl, c, bl);
-  if (c == 0 && (hl.w & 0xFF) != 0) {
-    const uint32_t e = (hl.w >> 8) + exc_super(fm, s_sup, bl), ne = hl.w & 0xFF;
-    base_l -= exc_below(fm.exc_row + e, ne == 255 ? fm.n_exc - e : ne, l);
-  }
-  nl = base_l + staged_in_block(s_blk + slot_l * 4, s_gcnt[slot_l], c, l - bl * BLOCK_SYMS);
-  const uint4 hr = s_blk[slot_r * 4];
-  uint32_t base_r = staged_base(fm, s_sup, hr, c, br);
-  if (c == 0 && (hr.w & 0xFF) != 0) {
-    const uint32_t e = (hr.w >> 8) + exc_super(fm, s_sup, br), ne = hr.w & 0xFF;
-    base_r -= exc_below(fm.exc_row + e, ne == 255 ? fm.n_exc - e : ne, r);
-  }
-  nr = base_r + staged_in_block(s_blk + slot_r * 4, s_gcnt[slot_r], c, r - br * BLOCK_SYMS);
+  nl = staged_rank(fm, s_sup, s_blk, s_cum, slot_l, c, l);
+  if (slot_r == slot_l) {
+    // both ends in one block (the rule once the interval is small): the header's part is shared, the second end adds its own symbols
+    const uint32_t blk = l / BLOCK_SYMS, ol = l - blk * BLOCK_SYMS, orr = r - blk * BLOCK_SYMS;
+    uint32_t d = staged_in_block(s_blk, s_cum, slot_l, c, orr) - staged_in_block(s_blk, s_cum, slot_l, c, ol);
+    const uint4 hd = s_blk[slot_l * 4];
+    if (c == 0 && (hd.w & 0xFF) != 0) {
+      const uint32_t e = (hd.w >> 8) + exc_super(fm, s_sup, blk), ne = hd.w & 0xFF;
+      const uint32_t nn = ne == 255 ? fm.n_exc - e : ne;
+      d -= exc_below(fm.exc_row + e, nn, r) - exc_below(fm.exc_row + e, nn, l);
+    }
+    nr = nl + d;
+  } else nr = staged_rank(fm, s_sup, s_blk, s_cum, slot_r, c, r);
 }
 
 struct SweepPart {          // how a round's records are partitioned
@@ -298,7 +311,7 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
   __shared__ uint32_t s_sup[SUP_LDS];
   __shared__ uint4 s_blk[SW_CAP * 4];
   __shared__ uint32_t s_slot_blk[SW_CAP];
-  __shared__ uint2 s_gcnt[SW_CAP];               // per staged block: A, C, G, T in its first (x) and second (y) group of 64 symbols, a byte each
+  __shared__ uint32_t s_cum[SW_CAP * 6];         // per staged block and half-group of 32 symbols: A, C, G, T in front of it inside the block, a byte each
   __shared__ uint32_t s_node_lo[2][SW_NODES], s_node_hi[2][SW_NODES];
   __shared__ uint32_t s_first[SW_NODES], s_base[SW_NODES];
   __shared__ uint32_t s_scan[256 / 64 + 1];
@@ -384,13 +397,23 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
             if (e < total * 4) {
               s_blk[e] = tmp[u];
               const uint32_t part = e & 3u;
-              if (part == 1 || part == 2) {        // a lane that holds the first or the second group counts its characters
-                const uint64_t lo = (uint64_t)tmp[u].x | ((uint64_t)tmp[u].y << 32), hi = (uint64_t)tmp[u].z | ((uint64_t)tmp[u].w << 32);
-                const uint32_t nC = (uint32_t)__popcll(lo & ~hi), nG = (uint32_t)__popcll(~lo & hi), nT = (uint32_t)__popcll(lo & hi);
-                const uint32_t packed = (64u - nC - nG - nT) | (nC << 8) | (nG << 16) | (nT << 24);
-                reinterpret_cast<uint32_t*>(s_gcnt)[(e >> 2) * 2 + (part - 1)] = packed;
+              if (part != 0) {                     // a lane that holds a group of 64 symbols counts the characters of its two halves
+                const uint32_t c0 = __popc(tmp[u].x & ~tmp[u].z), g0 = __popc(~tmp[u].x & tmp[u].z), t0 = __popc(tmp[u].x & tmp[u].z);
+                const uint32_t c1 = __popc(tmp[u].y & ~tmp[u].w), g1 = __popc(~tmp[u].y & tmp[u].w), t1 = __popc(tmp[u].y & tmp[u].w);
+                s_cum[(e >> 2) * 6 + (part - 1) * 2] = (32u - c0 - g0 - t0) | (c0 << 8) | (g0 << 16) | (t0 << 24);
+                s_cum[(e >> 2) * 6 + (part - 1) * 2 + 1] = (32u - c1 - g1 - t1) | (c1 << 8) | (g1 << 16) | (t1 << 24);
               }
             }
+          }
+          __syncthreads();
+          // ... and the counts of every half become the counts IN FRONT of it (bytes add without carries: at most 160 per character)
+          for (uint32_t b = tid; b < total; b += 256) {
+            uint32_t hc[5];
+#pragma unroll
+            for (uint32_t q = 0; q < 5; ++q) hc[q] = s_cum[b * 6 + q];
+            uint32_t run = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 6; ++q) { s_cum[b * 6 + q] = run; if (q < 5) run += hc[q]; }
           }
           __syncthreads();
         }
@@ -405,7 +428,7 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
           uint32_t nl, nr;
           const uint32_t bl = l[j] / BLOCK_SYMS, br = r[j] / BLOCK_SYMS;
           const uint32_t sl = s_base[nd[j]] + (bl - s_first[nd[j]]);
-          staged_rank_pair(fm, s_sup, s_blk, s_gcnt, sl, sl + (br - bl), c, l[j], r[j], nl, nr);
+          staged_rank_pair(fm, s_sup, s_blk, s_cum, sl, sl + (br - bl), c, l[j], r[j], nl, nr);
           l[j] = fm.C[c] + nl; r[j] = fm.C[c] + nr; nd[j] = (nd[j] * 4 + c) & (SW_NODES - 1);
           ++n_steps;
           if (nr <= nl) alive &= ~(1u << j);
@@ -447,7 +470,7 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
             const uint32_t ba = a / BLOCK_SYMS, bb = b / BLOCK_SYMS;
             if (staged) {
               const uint32_t sl = s_base[p];      // (a lies in the node's first block)
-              staged_rank_pair(fm, s_sup, s_blk, s_gcnt, sl, sl + (bb - ba), c, a, b, ca, cb);
+              staged_rank_pair(fm, s_sup, s_blk, s_cum, sl, sl + (bb - ba), c, a, b, ca, cb);
               ca += fm.C[c]; cb += fm.C[c];
             } else {
               ca = fm.C[c] + block_rank(fm, s_sup, fm.blocks + (uint64_t)ba * 4, c, a);
