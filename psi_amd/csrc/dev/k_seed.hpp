@@ -433,11 +433,12 @@ k_sb_count(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ p
 
 __global__ void __launch_bounds__(256)
 k_sb_scatter(const uint64_t* __restrict__ seed_key, const uint64_t* __restrict__ params, uint64_t seeds_cap, SeedBuckets sb,
-             const uint64_t* __restrict__ off /* exclusive scan of cnt */, ulonglong2* __restrict__ out_rec /* (k-mer, seed) */,
+             const uint64_t* __restrict__ base /* first record of every bucket */, const uint32_t* __restrict__ within /* [bucket][wg]: the
+             workgroup's first record inside the bucket (k_sweep_rows) */, ulonglong2* __restrict__ out_rec /* (k-mer, seed) */,
              uint32_t* __restrict__ seed_next)
 {
   extern __shared__ uint32_t cur[];
-  for (uint32_t i = threadIdx.x; i < sb.n_buckets; i += 256) cur[i] = (uint32_t)off[(uint64_t)i * sb.n_wg + blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < sb.n_buckets; i += 256) cur[i] = (uint32_t)base[i] + within[(uint64_t)i * sb.n_wg + blockIdx.x];
   __syncthreads();
   const uint64_t n_seeds = min(params[0], seeds_cap);
   const uint64_t s0 = (uint64_t)blockIdx.x * sb.tile, s1 = min(n_seeds, s0 + sb.tile);
