@@ -70,6 +70,8 @@ struct psigpu_ctx {
   // per-call workspace (grow-only)
   DevBuf in_bases;                 // host entry, reads in pinned memory: the chunk's reads (transfers queued ahead of the compute loop)
   DevBuf in_mask;                  // ... packed reads: their "not ACGT" bits
+  DevBuf in_off;                   // ... the chunk's read offsets as the caller holds them (round 6: moved by the copy engine beside the
+                                   // reads; until then k_rebase_offsets read them from host memory -- 22 us of the compute stream per sub-batch)
   DevBuf w_bases, w_read_off, w_cnt, w_tiles, w_seed_off, w_seed_key, w_seed_info,
       w_seed_next, w_ht, w_pfx, w_pfx12, w_iv_lo, w_iv_cnt, w_iv_aux, w_hit_off, w_iv_tiles,
       w_chunks, w_chunk_fill, w_chunk_off, w_chunk_tiles, w_hits, w_spill_a, w_spill_b, w_ctr, w_total,
