@@ -100,6 +100,12 @@ def main():
         log = os.path.join(args.dir, 'psi.log')
         if os.path.exists(log):
             os.remove(log)
+        if args.live:             # (the records of the run before are 2 GB of dirty pages: their write-back is not this run's business)
+            try:
+                os.remove('/tmp/psikt_live_out.gam')
+            except OSError:
+                pass
+            os.sync()
         t = time.time()
         # (--live: the records go to /tmp -- the box's disk-backed file system, i.e. the page cache -- as a user's out.gam would; the
         # inputs are read from /dev/shm.  tools/r06_psikt_writer_sweep.sh measured both: 0.33 s per 10 M reads' records on /tmp,
