@@ -27,7 +27,7 @@
 #define SW_PER_V 4
 #endif
 #ifndef SW_CAP_V
-#define SW_CAP_V 448
+#define SW_CAP_V 320
 #endif
 constexpr uint32_t SW_BUCKET_BITS = SW_BUCKET_BITS_V, SW_BUCKETS = 1u << SW_BUCKET_BITS;      // (measured: tools/r06_sweep_ab.sh)
 constexpr uint32_t SW_PER = SW_PER_V, SW_TILE = 256 * SW_PER;      // seeds of a bucket a workgroup holds in registers at a time
@@ -37,8 +37,10 @@ constexpr uint32_t SW_CAP = SW_CAP_V;                       // rank blocks stage
 constexpr uint32_t SW_MINI = 6;                             // no interval table in the index: one of 4^6 entries is made when the part is first searched
 constexpr uint32_t SW_DEAD = 0xFFFFFFFFu;                   // record field l: no interval (a hole in a bucket's region)
 constexpr uint32_t SW_KR_LEVELS = 16;
-#ifndef SW_WAVES_PER_SIMD
-#define SW_WAVES_PER_SIMD 1
+// four workgroups per CU (128 VGPRs, 36 KB of LDS): a level is a chain of barriers and one memory round trip, and what hides it is
+// another workgroup -- 0.84 -> 0.78 ms after the table, 1.48 -> 1.34 without against three per CU; five (96 VGPRs) spill and lose it again
+#ifndef SW_OCCUPANCY_ATTR
+#define SW_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif                       // characters a record carries
 
 // rank_c(i) by ONE lane from a rank block it can address (LDS or memory): the same arithmetic as quad_rank
@@ -303,14 +305,13 @@ k_sweep_mini_table(FMView fm, uint32_t q, uint2* __restrict__ table)
 
 // one workgroup per bucket
 template <bool ROUND0, bool FINAL>
-__global__ void __launch_bounds__(256, SW_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(256) SW_OCCUPANCY_ATTR
 k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__ in, const uint64_t* __restrict__ base,
            uint32_t n_staged, uint32_t n_direct, uint32_t gocc_thr, uint4* __restrict__ out,
            uint32_t* __restrict__ iv_lo, uint32_t* __restrict__ iv_cnt, DevCounters* ctr)
 {
   __shared__ uint32_t s_sup[SUP_LDS];
   __shared__ uint4 s_blk[SW_CAP * 4];
-  __shared__ uint32_t s_slot_blk[SW_CAP];
   __shared__ uint32_t s_cum[SW_CAP * 6];         // per staged block and half-group of 32 symbols: A, C, G, T in front of it inside the block, a byte each
   __shared__ uint32_t s_node_lo[2][SW_NODES], s_node_hi[2][SW_NODES];
   __shared__ uint32_t s_first[SW_NODES], s_base[SW_NODES];
@@ -380,40 +381,45 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
         const uint32_t base = before + incl - nb;
         staged = total != 0 && total <= SW_CAP;      // (no block at all: every interval of the tile has died)
         if (tid < n_nodes) { s_first[tid] = first; s_base[tid] = base; }
-        if (staged && tid < n_nodes) for (uint32_t t = 0; t < nb; ++t) s_slot_blk[base + t] = first + t;
         __syncthreads();
         if (staged) {
-          // (all of a lane's loads before the first store: a loop of load-then-store is one memory latency per turn)
-          constexpr uint32_t TURNS = (SW_CAP * 4 + 255) / 256;
-          uint4 tmp[TURNS];
+          // One lane per block: which node's range the slot lies in (a search over the nodes' first slots: at most 256), the
+          // block's 64 bytes by four loads, the counts in front of its six half-groups in registers -- no list of blocks filled by
+          // one lane (65-130 stores in a row at the tree's root), no second pass over the counts, two barriers less per level.
+          // All of a lane's loads before the first store.
+          constexpr uint32_t TURNS = (SW_CAP + 255) / 256;
+          uint4 tmp[TURNS][4];
 #pragma unroll
           for (uint32_t u = 0; u < TURNS; ++u) {
-            const uint32_t e = min(tid + u * 256, total * 4 - 1);      // (past the end: the last chunk again, dropped below -- no branch round a load)
-            tmp[u] = fm.blocks[(uint64_t)s_slot_blk[e >> 2] * 4 + (e & 3u)];
+            const uint32_t slot = min(tid + u * 256, total - 1);      // (past the end: the last block again, dropped below -- no branch round a load)
+            uint32_t lo_n = 0, hi_n = n_nodes;                        // the last node whose first slot is <= slot (empty nodes share a first slot
+            while (hi_n - lo_n > 1) {                                 // with the node behind them: the LAST of equals is the one that holds blocks)
+              const uint32_t mid = (lo_n + hi_n) >> 1;
+              if (s_base[mid] <= slot) lo_n = mid; else hi_n = mid;
+            }
+            const uint64_t blk = s_first[lo_n] + (slot - s_base[lo_n]);
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) tmp[u][w] = fm.blocks[blk * 4 + w];
           }
 #pragma unroll
           for (uint32_t u = 0; u < TURNS; ++u) {
-            const uint32_t e = tid + u * 256;
-            if (e < total * 4) {
-              s_blk[e] = tmp[u];
-              const uint32_t part = e & 3u;
-              if (part != 0) {                     // a lane that holds a group of 64 symbols counts the characters of its two halves
-                const uint32_t c0 = __popc(tmp[u].x & ~tmp[u].z), g0 = __popc(~tmp[u].x & tmp[u].z), t0 = __popc(tmp[u].x & tmp[u].z);
-                const uint32_t c1 = __popc(tmp[u].y & ~tmp[u].w), g1 = __popc(~tmp[u].y & tmp[u].w), t1 = __popc(tmp[u].y & tmp[u].w);
-                s_cum[(e >> 2) * 6 + (part - 1) * 2] = (32u - c0 - g0 - t0) | (c0 << 8) | (g0 << 16) | (t0 << 24);
-                s_cum[(e >> 2) * 6 + (part - 1) * 2 + 1] = (32u - c1 - g1 - t1) | (c1 << 8) | (g1 << 16) | (t1 << 24);
+            const uint32_t slot = tid + u * 256;
+            if (slot < total) {
+              uint32_t run = 0;
+#pragma unroll
+              for (uint32_t w = 0; w < 4; ++w) {
+                const uint4 v = tmp[u][w];
+                s_blk[slot * 4 + w] = v;
+                if (w) {                           // a group of 64 symbols: the characters of its two halves (bytes add without carries: at most 160 each)
+                  const uint32_t c0 = __popc(v.x & ~v.z), g0 = __popc(~v.x & v.z), t0 = __popc(v.x & v.z);
+                  const uint32_t c1 = __popc(v.y & ~v.w), g1 = __popc(~v.y & v.w), t1 = __popc(v.y & v.w);
+                  s_cum[slot * 6 + (w - 1) * 2] = run;
+                  run += (32u - c0 - g0 - t0) | (c0 << 8) | (g0 << 16) | (t0 << 24);
+                  s_cum[slot * 6 + (w - 1) * 2 + 1] = run;
+                  run += (32u - c1 - g1 - t1) | (c1 << 8) | (g1 << 16) | (t1 << 24);
+                }
               }
             }
-          }
-          __syncthreads();
-          // ... and the counts of every half become the counts IN FRONT of it (bytes add without carries: at most 160 per character)
-          for (uint32_t b = tid; b < total; b += 256) {
-            uint32_t hc[5];
-#pragma unroll
-            for (uint32_t q = 0; q < 5; ++q) hc[q] = s_cum[b * 6 + q];
-            uint32_t run = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 6; ++q) { s_cum[b * 6 + q] = run; if (q < 5) run += hc[q]; }
           }
           __syncthreads();
         }
