@@ -24,8 +24,11 @@ constexpr uint32_t KS_SERIAL = (1u << 22) - 1;
 __host__ __device__ inline uint64_t ks_state_words(uint64_t n_seeds) { return (n_seeds / KS_TILE + 66) + (n_seeds / KS_TILE) / 64 + 4; }
 __device__ __forceinline__ uint64_t ks_word(uint64_t flag, uint32_t serial22, uint64_t v) { return flag | ((uint64_t)serial22 << 40) | v; }
 
+#ifndef KS_OCC_ATTR
+#define KS_OCC_ATTR
+#endif
 template <bool PACKED, bool UNIFORM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) KS_OCC_ATTR
 k_kmer_step(const char* __restrict__ bases, const uint64_t* __restrict__ read_off, const uint64_t* __restrict__ seed_off, uint64_t n_reads,
             const uint64_t* __restrict__ params, uint64_t seeds_cap, uint64_t n_bases, uint32_t k, uint32_t step, PackedIn pk, UniformIn un,
             KmerTableView kt, MapView mv, const LocusEnt* __restrict__ ent, bool want_on, bool want_off, uint32_t gocc_thr,
