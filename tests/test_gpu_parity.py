@@ -1400,6 +1400,13 @@ def test_copy_ends_live_in_a_process_wide_pool():
     f.create_path_index(2, rng_seed=3)
     assert _eq(f.seeds_all((keep[0].array, keep[1].array), step=step, sort_unique=True), got[0])
     f.close()
+    # hit arrays made ahead of time (psikt's side thread): they wait in the pool, the next taker of that size gets one of them
+    s0 = psi_amd.copy_pool_stats()
+    assert psi_amd.lib().psigpu_reserve_hit_arrays(200_000, 2) == 2
+    s1 = psi_amd.copy_pool_stats()
+    assert s1['allocated'] == s0['allocated'] + 2 and s1['idle'] == s0['idle'] + 2 and s1['in_use'] == s0['in_use']
+    assert psi_amd.lib().psigpu_reserve_hit_arrays(200_000, 2) == 2
+    assert psi_amd.copy_pool_stats()['allocated'] == s1['allocated']          # (the same two again)
 
 
 @pytest.mark.parametrize('k,step', [(13, 4), (21, 21), (31, 7)])
