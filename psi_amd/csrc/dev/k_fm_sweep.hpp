@@ -363,25 +363,43 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
       const bool tree = s < n_staged;
       const uint32_t n_nodes = tree ? 1u << (2 * s) : 0u;
       bool staged = false;
+      uint32_t nofs = 0;                            // where this wave reads the nodes' first slots (its own copy, or the workgroup's)
       if (tree) {
         __syncthreads();
         // ---- the level's rank blocks: every node's block range, one after the other in the staging area ----
+        // Up to 64 nodes (the first four levels): EVERY wave scans the nodes' block counts itself and keeps its own copy of the
+        // first slots (s_base / s_first hold four copies of 64 entries) -- nothing crosses a wave, so the two barriers of the
+        // scan go (a level is a chain of barriers and one memory round trip: 5 us per tile and level by the counters).  The
+        // last level's 256 nodes are scanned by the workgroup.
+        const bool own = n_nodes <= 64;
+        nofs = own ? wib * 64 : 0u;
+        const uint32_t node = own ? lane : tid;
         uint32_t first = 0, nb = 0;
-        if (tid < n_nodes) {
-          const uint32_t a = s_node_lo[cur][tid], b = s_node_hi[cur][tid];
+        if (node < n_nodes) {
+          const uint32_t a = s_node_lo[cur][node], b = s_node_hi[cur][node];
           if (b > a) { first = a / BLOCK_SYMS; nb = b / BLOCK_SYMS - first + 1; }
         }
         uint32_t incl = nb;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, d); if (lane >= (uint32_t)d) incl += u; }
-        if (lane == 63) s_scan[wib] = incl;
-        __syncthreads();
-        uint32_t before = 0, total = 0;
+        uint32_t total, base;
+        if (own) {
+          total = (uint32_t)__shfl((int)incl, 63);
+          base = incl - nb;
+          s_first[nofs + lane] = first; s_base[nofs + lane] = base;
+          __builtin_amdgcn_s_waitcnt(0xc07f);          // (lgkmcnt(0): the wave's own LDS stores before its own loads)
+          __builtin_amdgcn_wave_barrier();
+        } else {
+          if (lane == 63) s_scan[wib] = incl;
+          __syncthreads();
+          uint32_t before = 0;
+          total = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < 4; ++w) { if (w < wib) before += s_scan[w]; total += s_scan[w]; }
-        const uint32_t base = before + incl - nb;
+          for (uint32_t w = 0; w < 4; ++w) { if (w < wib) before += s_scan[w]; total += s_scan[w]; }
+          base = before + incl - nb;
+          if (tid < n_nodes) { s_first[tid] = first; s_base[tid] = base; }
+          __syncthreads();
+        }
         staged = total != 0 && total <= SW_CAP;      // (no block at all: every interval of the tile has died)
-        if (tid < n_nodes) { s_first[tid] = first; s_base[tid] = base; }
-        __syncthreads();
         if (staged) {
           // One lane per block: which node's range the slot lies in (a search over the nodes' first slots: at most 256), the
           // block's 64 bytes by four loads, the counts in front of its six half-groups in registers -- no list of blocks filled by
@@ -395,9 +413,9 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
             uint32_t lo_n = 0, hi_n = n_nodes;                        // the last node whose first slot is <= slot (empty nodes share a first slot
             while (hi_n - lo_n > 1) {                                 // with the node behind them: the LAST of equals is the one that holds blocks)
               const uint32_t mid = (lo_n + hi_n) >> 1;
-              if (s_base[mid] <= slot) lo_n = mid; else hi_n = mid;
+              if (s_base[nofs + mid] <= slot) lo_n = mid; else hi_n = mid;
             }
-            const uint64_t blk = s_first[lo_n] + (slot - s_base[lo_n]);
+            const uint64_t blk = s_first[nofs + lo_n] + (slot - s_base[nofs + lo_n]);
 #pragma unroll
             for (uint32_t w = 0; w < 4; ++w) tmp[u][w] = fm.blocks[blk * 4 + w];
           }
@@ -433,7 +451,7 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
           kr[j] >>= 2;
           uint32_t nl, nr;
           const uint32_t bl = l[j] / BLOCK_SYMS, br = r[j] / BLOCK_SYMS;
-          const uint32_t sl = s_base[nd[j]] + (bl - s_first[nd[j]]);
+          const uint32_t sl = s_base[nofs + nd[j]] + (bl - s_first[nofs + nd[j]]);
           staged_rank_pair(fm, s_sup, s_blk, s_cum, sl, sl + (br - bl), c, l[j], r[j], nl, nr);
           l[j] = fm.C[c] + nl; r[j] = fm.C[c] + nr; nd[j] = (nd[j] * 4 + c) & (SW_NODES - 1);
           ++n_steps;
@@ -475,7 +493,7 @@ k_fm_sweep(FMView fm, const uint2* __restrict__ table, const uint4* __restrict__
           if (b > a) {
             const uint32_t ba = a / BLOCK_SYMS, bb = b / BLOCK_SYMS;
             if (staged) {
-              const uint32_t sl = s_base[p];      // (a lies in the node's first block)
+              const uint32_t sl = s_base[nofs + p];      // (a lies in the node's first block)
               staged_rank_pair(fm, s_sup, s_blk, s_cum, sl, sl + (bb - ba), c, a, b, ca, cb);
               ca += fm.C[c]; cb += fm.C[c];
             } else {
