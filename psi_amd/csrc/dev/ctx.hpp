@@ -325,10 +325,15 @@ static int upload_large(psigpu_ctx* ctx, void* dst, const void* src, size_t byte
 // PSIGPU_AB_NO_PAD_ZERO=1 leaves the pads as allocated (with PSIGPU_POISON: a known byte) -- does any answer depend on them?
 // PSIGPU_AB_EARLY_FREE=1: the ends of the engine copies go straight back to HIP (as until round 5) instead of to the pool.
 #ifdef PSIGPU_CAMPAIGN
-static bool ab_load_hole() { return getenv("PSIGPU_AB_LOAD_HOLE") != nullptr; }
+// (PSIGPU_AB_LOAD_HOLE=1: the whole hole; =2: only the pads -- filled on the null stream, nobody waits -- with the loaders' fence
+// and the checksum read-back in place; =3: only the missing fence and read-back, the pads waited for.  Which half do the events need?)
+static int ab_hole_kind() { const char* e = getenv("PSIGPU_AB_LOAD_HOLE"); return e ? (atoi(e) > 0 ? atoi(e) : 1) : 0; }
+static bool ab_load_hole() { const int k = ab_hole_kind(); return k == 1 || k == 3; }          // no fence, no read-back
+static bool ab_pads_unwaited() { const int k = ab_hole_kind(); return k == 1 || k == 2; }      // pads: nobody waits
 static bool ab_no_pad_zero() { return getenv("PSIGPU_AB_NO_PAD_ZERO") != nullptr; }
 #else
 static constexpr bool ab_load_hole() { return false; }
+static constexpr bool ab_pads_unwaited() { return false; }
 static constexpr bool ab_no_pad_zero() { return false; }
 #endif
 // every loader ends here: whatever it queued on any stream (fills, table kernels) has run when the caller gets control back
@@ -419,7 +424,7 @@ static int upload(psigpu_ctx* ctx, DevBuf& b, const T* src, uint64_t n, uint64_t
     // hipMemset on the null stream returns before the fill has run, and the query kernels run on non-blocking streams that
     // do not order against the null stream: the host waits for the fill here (round-4 review: the loaders' ordering hole)
     HIPCHK(ctx, hipMemsetAsync((char*)b.p + n * sizeof(T), 0, pad_elems * sizeof(T), nullptr));
-    if (!ab_load_hole()) HIPCHK(ctx, hipStreamSynchronize(nullptr));
+    if (!ab_pads_unwaited()) HIPCHK(ctx, hipStreamSynchronize(nullptr));
   }
   if (name && n && !ab_load_hole()) return resident_note(ctx, name, b, b.p, src, n * sizeof(T));
   return PSIGPU_OK;

@@ -15,6 +15,9 @@ for arm in $ARMS; do
   unset PSIGPU_AB_LOAD_HOLE PSIGPU_AB_EARLY_FREE PSI_AMD_LIB
   if [ "$arm" = "B" ]; then export PSI_AMD_LIB=$PWD/psi_amd/libpsi_gpu_campaign.so PSIGPU_AB_LOAD_HOLE=1; fi
   if [ "$arm" = "C" ]; then export PSI_AMD_LIB=$PWD/psi_amd/libpsi_gpu_campaign.so PSIGPU_AB_LOAD_HOLE=1 PSIGPU_AB_EARLY_FREE=1; fi
+  # (the hole in halves: P = only the pads left unwaited (fence and read-back in place), F = only the fence and the read-back missing)
+  if [ "$arm" = "P" ]; then export PSI_AMD_LIB=$PWD/psi_amd/libpsi_gpu_campaign.so PSIGPU_AB_LOAD_HOLE=2; fi
+  if [ "$arm" = "F" ]; then export PSI_AMD_LIB=$PWD/psi_amd/libpsi_gpu_campaign.so PSIGPU_AB_LOAD_HOLE=3; fi
   t0=$(date +%s)
   TAG=${TAG}_r${r}${arm} FUZZ_TIMEOUT=${FUZZ_TIMEOUT:-240} bash tools/fuzz_par.sh $first $N 100000 > $O/round_${r}${arm}.out 2>&1
   mv gpurun_out/fuzz_${TAG}_r${r}${arm}_p*.log $O/logs/ 2>/dev/null
